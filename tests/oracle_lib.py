@@ -1,0 +1,206 @@
+"""ctypes bindings for the CPU oracle (oracle/libk4lz4_oracle.so) and, when present, the
+system liblz4.so.1 second opinion.  Test infrastructure only -- never imported by the
+product package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libk4lz4_oracle.so")
+
+_u8p = C.POINTER(C.c_uint8)
+
+
+def _ptr(a: np.ndarray):
+    assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_u8p)
+
+
+def build_oracle(force: bool = False) -> str:
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("k4lz4_oracle.c", "k4lz4_oracle_hc.c")]
+    stale = (not os.path.exists(ORACLE_SO)) or any(
+        os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "-B", "libk4lz4_oracle.so"])
+    return ORACLE_SO
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = C.CDLL(build_oracle())
+        L = self.lib
+        L.k4o_compress_bound.argtypes = [C.c_int]
+        L.k4o_compress_fast.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int]
+        L.k4o_compress_hc.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int]
+        L.k4o_decompress_safe.argtypes = [_u8p, _u8p, C.c_int, C.c_int]
+        L.k4o_decompress_safe_partial.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int]
+        L.k4o_decompress_safe_using_dict.argtypes = [_u8p, _u8p, C.c_int, C.c_int, _u8p, C.c_int]
+        L.k4o_codec_encode.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.c_int]
+        L.k4o_codec_decode.argtypes = [_u8p, C.c_int, _u8p, C.c_int]
+        L.k4o_pickle_bound.argtypes = [C.c_int]
+        L.k4o_pickle.argtypes = [_u8p, C.c_int, _u8p, _u8p, C.c_int, C.c_int]
+        L.k4o_unpickle_header.argtypes = [_u8p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.k4o_unpickle.argtypes = [_u8p, C.c_int, _u8p, C.c_int]
+        L.k4o_adler32.argtypes = [_u8p, C.c_int64]
+        L.k4o_adler32.restype = C.c_uint32
+        batch = [_u8p, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.k4o_encode_batch.argtypes = batch + [C.c_int, C.c_int]
+        L.k4o_decode_batch.argtypes = batch + [C.c_int]
+
+    # ---- raw engine entry points (LLxx-level returns) --------------------------------------
+    def compress_bound(self, n: int) -> int:
+        return self.lib.k4o_compress_bound(n)
+
+    def compress_fast(self, src: np.ndarray, cap: int | None = None, accel: int = 1):
+        """returns (ret, dst array of length cap)"""
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        if cap is None:
+            cap = self.compress_bound(src.size)
+        dst = np.full(max(cap, 1), 0xCD, dtype=np.uint8)
+        ret = self.lib.k4o_compress_fast(_ptr(src if src.size else np.zeros(1, np.uint8)), _ptr(dst), src.size, cap, accel)
+        return ret, dst[:cap]
+
+    def compress_hc(self, src: np.ndarray, level: int, cap: int | None = None):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        if cap is None:
+            cap = self.compress_bound(src.size)
+        dst = np.full(max(cap, 1), 0xCD, dtype=np.uint8)
+        ret = self.lib.k4o_compress_hc(_ptr(src if src.size else np.zeros(1, np.uint8)), _ptr(dst), src.size, cap, level)
+        return ret, dst[:cap]
+
+    def decompress_safe(self, src: np.ndarray, cap: int, fill: int = 0xCD):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dst = np.full(max(cap, 1), fill, dtype=np.uint8)
+        ret = self.lib.k4o_decompress_safe(_ptr(src if src.size else np.zeros(1, np.uint8)), _ptr(dst), src.size, cap)
+        return ret, dst[:cap]
+
+    def decompress_partial(self, src: np.ndarray, target: int, cap: int):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dst = np.full(max(cap, 1), 0xCD, dtype=np.uint8)
+        ret = self.lib.k4o_decompress_safe_partial(_ptr(src), _ptr(dst), src.size, target, cap)
+        return ret, dst[:cap]
+
+    def decompress_using_dict(self, src: np.ndarray, cap: int, dictionary: np.ndarray):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dictionary = np.ascontiguousarray(dictionary, dtype=np.uint8)
+        dst = np.full(max(cap, 1), 0xCD, dtype=np.uint8)
+        ret = self.lib.k4o_decompress_safe_using_dict(_ptr(src), _ptr(dst), src.size, cap, _ptr(dictionary), dictionary.size)
+        return ret, dst[:cap]
+
+    # ---- LZ4Codec / LZ4Pickler level --------------------------------------------------------
+    def encode(self, src: np.ndarray, level: int = 0, cap: int | None = None) -> bytes | None:
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        if cap is None:
+            cap = self.compress_bound(src.size)
+        dst = np.empty(max(cap, 1), dtype=np.uint8)
+        n = self.lib.k4o_codec_encode(_ptr(src if src.size else np.zeros(1, np.uint8)), src.size, _ptr(dst), cap, level)
+        return None if n < 0 else dst[:n].tobytes()
+
+    def decode(self, src, cap: int) -> bytes | None:
+        src = np.frombuffer(bytes(src), dtype=np.uint8) if not isinstance(src, np.ndarray) else src
+        dst = np.empty(max(cap, 1), dtype=np.uint8)
+        n = self.lib.k4o_codec_decode(_ptr(src if src.size else np.zeros(1, np.uint8)), src.size, _ptr(dst), cap)
+        return None if n < 0 else dst[:n].tobytes()
+
+    def pickle(self, src: np.ndarray, level: int = 0, writer_mode: int = 0) -> bytes:
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        if src.size == 0:
+            return b""
+        dst = np.empty(self.lib.k4o_pickle_bound(src.size), dtype=np.uint8)
+        scratch = np.empty(max(src.size, 1024), dtype=np.uint8)
+        n = self.lib.k4o_pickle(_ptr(src), src.size, _ptr(dst), _ptr(scratch), level, writer_mode)
+        return dst[:n].tobytes()
+
+    def unpickle_header(self, src: bytes):
+        a = np.frombuffer(src, dtype=np.uint8)
+        off, rl, comp = C.c_int(), C.c_int(), C.c_int()
+        rc = self.lib.k4o_unpickle_header(_ptr(a if a.size else np.zeros(1, np.uint8)), a.size, C.byref(off), C.byref(rl), C.byref(comp))
+        return rc, off.value, rl.value, comp.value
+
+    def unpickle(self, src: bytes) -> bytes | None:
+        """None when the reference would throw InvalidDataException."""
+        if len(src) == 0:
+            return b""
+        rc, off, rl, comp = self.unpickle_header(src)
+        if rc < 0 or rl < 0:
+            return None
+        a = np.frombuffer(src, dtype=np.uint8)
+        dst = np.empty(max(rl, 1), dtype=np.uint8)
+        n = self.lib.k4o_unpickle(_ptr(a), a.size, _ptr(dst), rl)
+        return None if n < 0 else dst[:rl].tobytes()
+
+    def adler32(self, data) -> int:
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data)
+        return int(self.lib.k4o_adler32(_ptr(a if a.size else np.zeros(1, np.uint8)), a.size))
+
+    # ---- batch (threaded) -------------------------------------------------------------------
+    def encode_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, level=0, threads=1):
+        out = np.empty(len(src_len), dtype=np.int32)
+        rc = self.lib.k4o_encode_batch(_ptr(src), src_off.ctypes.data, src_len.ctypes.data, _ptr(dst),
+                                       dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data,
+                                       len(src_len), level, threads)
+        assert rc == 0
+        return out
+
+    def decode_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, threads=1):
+        out = np.empty(len(src_len), dtype=np.int32)
+        rc = self.lib.k4o_decode_batch(_ptr(src), src_off.ctypes.data, src_len.ctypes.data, _ptr(dst),
+                                       dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data,
+                                       len(src_len), threads)
+        assert rc == 0
+        return out
+
+
+class SystemLZ4:
+    """liblz4.so.1 (1.9.3 in this image) via dlopen -- independent cross-check, not the authority
+    (SURVEY.md 8c).  `available` is False when the library is missing."""
+
+    def __init__(self):
+        self.lib = None
+        for name in ("liblz4.so.1", "/lib/x86_64-linux-gnu/liblz4.so.1"):
+            try:
+                self.lib = C.CDLL(name)
+                break
+            except OSError:
+                continue
+        self.available = self.lib is not None
+        if not self.available:
+            return
+        L = self.lib
+        L.LZ4_versionNumber.restype = C.c_int
+        L.LZ4_compress_fast.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int]
+        L.LZ4_compress_HC.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int]
+        L.LZ4_decompress_safe.argtypes = [_u8p, _u8p, C.c_int, C.c_int]
+        L.LZ4_decompress_safe_partial.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int]
+        L.LZ4_decompress_safe_usingDict.argtypes = [_u8p, _u8p, C.c_int, C.c_int, _u8p, C.c_int]
+        self.version = L.LZ4_versionNumber()
+
+    def compress_fast(self, src: np.ndarray, cap: int, accel: int = 1):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dst = np.full(max(cap, 1), 0xCD, dtype=np.uint8)
+        ret = self.lib.LZ4_compress_fast(_ptr(src if src.size else np.zeros(1, np.uint8)), _ptr(dst), src.size, cap, accel)
+        return ret, dst[:cap]
+
+    def compress_hc(self, src: np.ndarray, cap: int, level: int):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dst = np.full(max(cap, 1), 0xCD, dtype=np.uint8)
+        ret = self.lib.LZ4_compress_HC(_ptr(src if src.size else np.zeros(1, np.uint8)), _ptr(dst), src.size, cap, level)
+        return ret, dst[:cap]
+
+    def decompress_safe(self, src: np.ndarray, cap: int):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dst = np.full(max(cap, 1), 0xCD, dtype=np.uint8)
+        ret = self.lib.LZ4_decompress_safe(_ptr(src if src.size else np.zeros(1, np.uint8)), _ptr(dst), src.size, cap)
+        return ret, dst[:cap]
+
+    def decompress_using_dict(self, src, cap, dictionary):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dictionary = np.ascontiguousarray(dictionary, dtype=np.uint8)
+        dst = np.full(max(cap, 1), 0xCD, dtype=np.uint8)
+        ret = self.lib.LZ4_decompress_safe_usingDict(_ptr(src), _ptr(dst), src.size, cap, _ptr(dictionary), dictionary.size)
+        return ret, dst[:cap]
