@@ -1,0 +1,134 @@
+"""Pins the CPU oracle (oracle/k4lz4_oracle.c) before anything is compared against it.
+
+Sources of truth:
+  * assets/issue64/input.dat -> output.dat of the reference repo (copied to tests/golden/),
+    decoded exactly as src/K4os.Compression.LZ4.Tests/Issue64.cs:16-55 does;
+  * probe values recorded at survey time from liblz4 1.9.3 == line-by-line LL64 restatement;
+  * byte equality with the system liblz4.so.1 on the reference's reproducible fixtures
+    (BlockRoundtripTests.cs:45-98: quick fox, repeated bytes, Lorem lengths).
+"""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from k4os.compression.lz4_amd import corpus
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _issue64_records():
+    raw = open(os.path.join(GOLDEN, "issue64_input.bin"), "rb").read()
+    pos = 20
+    recs = []
+    while raw[pos:pos + 4] == b"bv41":
+        u, c = struct.unpack_from("<II", raw, pos + 4)
+        recs.append((u, raw[pos + 12:pos + 12 + c]))
+        pos += 12 + c
+    assert raw[pos:pos + 4] == b"bv4$"
+    return recs
+
+
+def test_issue64_golden_decode(oracle):
+    want = open(os.path.join(GOLDEN, "issue64_output.bin"), "rb").read()
+    recs = _issue64_records()
+    assert recs[0][0] == 65536 and len(recs[0][1]) == 14505
+    out = bytearray()
+    prev = np.zeros(0, np.uint8)
+    for u, payload in recs:
+        src = np.frombuffer(payload, np.uint8)
+        if prev.size == 0:
+            n, dst = oracle.decompress_safe(src, u)
+        else:
+            n, dst = oracle.decompress_using_dict(src, u, prev)
+        assert n == u
+        prev = dst[:n].copy()
+        out += prev.tobytes()
+    assert bytes(out) == want[:len(out)]
+    assert oracle.adler32(recs[0][1]) == 0x1228b5d5
+    assert oracle.adler32(want[:65536]) == 0x5848d976
+
+
+PROBES_FAST = [(1000, 428, 0x5b689c08), (4096, 440, 0x2f5aa7cc), (65536, 681, 0x0d0097ed),
+               (0x172a5, 812, None), (0x123456, 5118, 0x208fd79e)]
+
+
+@pytest.mark.parametrize("n,size,adler", PROBES_FAST)
+def test_survey_probe_values_fast(oracle, n, size, adler):
+    ret, dst = oracle.compress_fast(corpus.lorem(n))
+    assert ret == size
+    if adler is not None:
+        assert oracle.adler32(dst[:ret]) == adler
+
+
+def test_survey_probe_small(oracle):
+    ret, dst = oracle.compress_fast(np.frombuffer(corpus.QUICK_FOX, np.uint8))
+    assert ret == 45 and oracle.adler32(dst[:ret]) == 0x8ade10e6
+    ret, dst = oracle.compress_fast(corpus.repeated(0, 1000))
+    assert dst[:ret].tobytes() == bytes.fromhex("1f000100ffffffd2500000000000")
+    ret, dst = oracle.compress_fast(corpus.repeated(0xAA, 65536))
+    assert ret == 267 and dst[:6].tobytes() == bytes.fromhex("1faa0100ffff")
+
+
+def _fixtures():
+    yield "fox", np.frombuffer(corpus.QUICK_FOX, np.uint8)
+    for n in (1, 12, 13, 14, 64, 1000, 4096, 0x7FFF, 0xFFFF, 65536, 65546, 65547, 0x172a5, 300000):
+        yield f"lorem{n}", corpus.lorem(n)
+    for n in (1, 13, 15, 17, 33, 67, 1000, 65536):
+        yield f"rep{n}", corpus.repeated(0xAA, n)
+    for n in (100, 5000, 70000, 200000):
+        yield f"rand{n}", corpus.random_bytes(n, n)
+    for i, name in enumerate(corpus.SILESIA_NAMES):
+        yield f"cls-{name}", corpus.class_bytes(name, 65536 if i % 2 else 150000, 7)
+
+
+@pytest.mark.parametrize("name,data", list(_fixtures()), ids=[n for n, _ in _fixtures()])
+def test_fast_encode_equals_liblz4_and_roundtrips(oracle, syslz4, name, data):
+    bound = oracle.compress_bound(data.size)
+    ret, dst = oracle.compress_fast(data)
+    ret2, dst2 = syslz4.compress_fast(data, bound)
+    assert ret == ret2 and dst[:ret].tobytes() == dst2[:ret2].tobytes()
+    assert (dst[ret:] == 0xCD).all()
+    # decode: exact capacity and oversize capacity (BlockRoundtripTests.cs:45-61)
+    for cap in (data.size, 2 * data.size + 64):
+        n, out = oracle.decompress_safe(dst[:ret], cap)
+        assert n == data.size and out[:n].tobytes() == data.tobytes()
+        assert (out[n:] == 0xCD).all()
+        n2, out2 = syslz4.decompress_safe(dst[:ret], cap)
+        assert n2 == n
+    # limitedOutput: cap == size succeeds with identical bytes, cap == size-1 fails
+    r3, d3 = oracle.compress_fast(data, cap=ret)
+    assert r3 == ret and d3[:ret].tobytes() == dst[:ret].tobytes()
+    if ret > 1:
+        r4, _ = oracle.compress_fast(data, cap=ret - 1)
+        assert r4 == 0
+
+
+def test_decode_malformed_matches_reference_rules(oracle, syslz4):
+    """Mutated streams: the oracle must never write outside dst and must agree with liblz4 on
+    accept/reject except for the one documented divergence class."""
+    rng = np.random.default_rng(5)
+    data = corpus.class_bytes("dickens", 3000, 3)
+    ret, dst = oracle.compress_fast(data)
+    good = dst[:ret].copy()
+    diverge = 0
+    for t in range(1500):
+        bad = good.copy()
+        kind = t % 3
+        if kind == 0:
+            bad = bad[:rng.integers(1, ret)]
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 4))):
+                bad[rng.integers(0, ret)] = rng.integers(0, 256)
+        else:
+            bad = np.concatenate([bad, rng.integers(0, 256, size=int(rng.integers(1, 9)), dtype=np.uint8)])
+        cap = data.size + int(rng.integers(-20, 21))
+        n, out = oracle.decompress_safe(bad, cap)
+        n2, out2 = syslz4.decompress_safe(bad, cap)
+        if (n < 0) != (n2 < 0):
+            diverge += 1
+            continue
+        if n >= 0:
+            assert n == n2 and out[:n].tobytes() == out2[:n].tobytes()
+    assert diverge <= 5
