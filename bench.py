@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric on MI355X: GiB/s encode+decode on batched 64 KiB blocks.
+
+Workload (config.workload): BASELINE.json configs[1] -- 4096 independent 64 KiB blocks of the
+12-class "Silesia-like" mix (corpus.silesia_like_blocks, seed = 2 + rank), L00_FAST encode then
+decode, inputs and outputs resident in HBM before the timed region.  A step = one encode pass +
+one decode pass over the batch.  `value` = uncompressed bytes through the round trip per second:
+N_gpus * sum(U) / max-over-ranks(step time), in GiB/s.  Multi-GPU: one process per GPU, every
+rank works on its own 4096 blocks (weak scaling), no data-path collective; the int32 size vector
+is all-gathered once outside the timed region.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (the encoder) -- algorithmic bytes per launch (sum(U)+sum(C)+12N)
+                / average launch duration measured with HIP events on the launch stream
+  roofline_decode  the same for the decode kernel (the BASELINE.json 50%-of-HBM target)
+  cpu_baseline  the oracle (C restatement of the reference's LL64 engine; the reference is C# and
+                cannot run here) on the host cores, same blocks, T threads
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=4096)
+    ap.add_argument("--block-size", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from k4os.compression.lz4_amd import LZ4Codec, corpus
+    from k4os.compression.lz4_amd.device import DeviceBatch, DeviceCodec
+    from k4os.compression.lz4_amd.sharding import gather_sizes
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n, bs = args.blocks, args.block_size
+    blocks = corpus.silesia_like_blocks(n, bs, seed=2 + rank)
+    dc = DeviceCodec(local_rank)
+    lens = np.full(n, bs, np.int32)
+    off = np.arange(n, dtype=np.uint64) * bs
+    bound = LZ4Codec.MaximumOutputSize(bs)
+    src = DeviceBatch.from_host(blocks.reshape(-1), off, lens, dc.device)
+    comp = DeviceBatch.empty_slots(np.full(n, bound), dc.device)
+    back = DeviceBatch.empty_slots(lens, dc.device)
+    clen = dc.new_out_len(n)
+    dlen = dc.new_out_len(n)
+    comp_src = DeviceBatch(comp.data, comp.off, clen)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        dc.encode(src, comp, clen)
+        if ev is not None:
+            ev[1].record()
+        dc.decode(comp_src, back, dlen)
+        if ev is not None:
+            ev[2].record()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])          # events sit on the launch stream (torch's current stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dc.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    enc_ms = np.array([e[0].elapsed_time(e[1]) for e in events])
+    dec_ms = np.array([e[1].elapsed_time(e[2]) for e in events])
+    clen_h = clen.cpu().numpy().astype(np.int64)
+    dlen_h = dlen.cpu().numpy()
+    sum_u, sum_c = int(n) * bs, int(clen_h.sum())
+    ok_roundtrip = bool((dlen_h == bs).all()) and bool(torch.equal(back.data[:n * bs], src.data[:n * bs]))
+
+    # the only collective: the size vector (RCCL all_gather), outside the timed region
+    if world > 1:
+        ranges = [(r * n, (r + 1) * n) for r in range(world)]
+        all_sizes = gather_sizes(clen, ranges)
+        total_c = int(all_sizes.sum().item())
+    else:
+        total_c = sum_c
+
+    result = None
+    if rank == 0:
+        from oracle_lib import Oracle
+        oracle = Oracle()
+        bit_exact = None
+        cpu = None
+        src_h = blocks.reshape(-1)
+        caps = np.full(n, bound, np.int32)
+        from k4os.compression.lz4_amd import make_arena
+        ref_dst, ref_off = make_arena(caps)
+        threads = os.cpu_count() or 1
+        if not args.no_verify or not args.no_cpu_baseline:
+            # oracle encode of the whole batch: doubles as the bit-exactness check and the CPU baseline
+            t_enc = []
+            for _ in range(2):
+                t = time.perf_counter()
+                ref_len = oracle.encode_batch(src_h, off, lens, ref_dst, ref_off, caps, threads=threads)
+                t_enc.append(time.perf_counter() - t)
+            comp_h = comp.data.cpu().numpy()
+            coff_h = comp.off.cpu().numpy()
+            bit_exact = bool(np.array_equal(ref_len, clen_h.astype(np.int32)))
+            if bit_exact:
+                for i in range(n):
+                    a = comp_h[coff_h[i]:coff_h[i] + clen_h[i]]
+                    b = ref_dst[int(ref_off[i]):int(ref_off[i]) + int(ref_len[i])]
+                    if not np.array_equal(a, b):
+                        bit_exact = False
+                        break
+            bit_exact = bit_exact and ok_roundtrip
+            if not args.no_cpu_baseline:
+                out_h, out_off = make_arena(lens)
+                t_dec = []
+                for _ in range(2):
+                    t = time.perf_counter()
+                    oracle.decode_batch(ref_dst, ref_off, ref_len, out_h, out_off, lens, threads=threads)
+                    t_dec.append(time.perf_counter() - t)
+                # single-thread sample for orientation
+                k1 = min(n, 256)
+                t = time.perf_counter()
+                oracle.encode_batch(src_h, off[:k1], lens[:k1], ref_dst, ref_off[:k1], caps[:k1], threads=1)
+                t1e = time.perf_counter() - t
+                t = time.perf_counter()
+                oracle.decode_batch(ref_dst, ref_off[:k1], ref_len[:k1], out_h, out_off[:k1], lens[:k1], threads=1)
+                t1d = time.perf_counter() - t
+                gib = sum_u / 2 ** 30
+                cpu = {
+                    "value": round(gib / (min(t_enc) + min(t_dec)), 3), "unit": "GiB/s", "cores": threads,
+                    "kind": "port",
+                    "sample": f"all {n} blocks x {bs} B of this workload, encode+decode, best of 2, {threads} threads "
+                              f"(oracle = C restatement of the reference's LL64 engine, gcc -O2)",
+                    "encode_GiBs": round(gib / min(t_enc), 3), "decode_GiBs": round(gib / min(t_dec), 3),
+                    "one_thread_encode_GiBs": round(k1 * bs / 2 ** 30 / t1e, 3),
+                    "one_thread_decode_GiBs": round(k1 * bs / 2 ** 30 / t1d, 3),
+                }
+        ms_per_step = elapsed / args.steps * 1e3
+        alg_bytes = sum_u + sum_c + 12 * n          # U read + C written (+12 B metadata) per block
+        enc_avg, dec_avg = float(enc_ms.mean()), float(dec_ms.mean())
+
+        def roof(avg_ms):
+            ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+            return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": alg_bytes}
+
+        result = {
+            "metric": "GiB/s encode+decode on batched 64 KiB blocks; bit-exact vs C# ref",
+            "value": round(world * sum_u / 2 ** 30 / (elapsed / args.steps), 3),
+            "unit": "GiB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: {n} independent {bs} B blocks per GPU, Silesia-like 12-class "
+                                   f"mix (seed 2+rank), L00_FAST encode + decode, HBM-resident",
+                       "blocks_per_gpu": n, "block_bytes": bs, "level": "L00_FAST",
+                       "ratio": round(sum_c / sum_u, 4), "total_compressed_bytes_all_gpus": total_c,
+                       "encode_GiBs_per_gpu": round(sum_u / 2 ** 30 / (enc_avg * 1e-3), 3),
+                       "decode_GiBs_per_gpu": round(sum_u / 2 ** 30 / (dec_avg * 1e-3), 3),
+                       "parallelism": f"{world} x independent block ranges, no data-path collective"},
+            "bit_exact": bit_exact,
+            "roofline": dict(roof(enc_avg), kernel="k4_encode_fast_kernel"),
+            "roofline_decode": dict(roof(dec_avg), kernel="k4_decode_kernel"),
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,141 @@
+/*
+ * k4lz4.h -- C ABI of libk4lz4.so: the MI355X (gfx950) LZ4 block codec that sits behind the
+ * K4os.Compression.LZ4 block API.  Plain pointers and sizes only; no HIP or torch types.
+ *
+ * Every entry point names the reference interface (paths relative to the reference repository,
+ * src/K4os.Compression.LZ4/...) it replaces.  INTEGRATION.md shows the C# P/Invoke stubs and
+ * the `Algorithm.Native` arm a maintainer would add to Engine/LLxx.cs.
+ *
+ * Conventions
+ *   - All block lengths are `int32_t` like the reference (`int`), offsets into batch buffers are
+ *     `uint64_t`.  Input size limit: 0x7E000000 (Engine/LL.types.cs:19).
+ *   - Per-block results in `outLen[i]` follow LZ4Codec (LZ4Codec.cs:40-52, :104-115):
+ *       > 0 bytes written, 0 for an empty input, -1 on failure (output too small / corrupt input).
+ *     With K4LZ4_FLAG_RAW_RETURN they are the LLxx-level returns instead (Engine/LLxx.cs:17-26,
+ *     :65-75): bytes written, 0 = did not fit, decode error = -(input position) - 1.
+ *   - Bytes of dst[i] beyond outLen[i] are never modified on success
+ *     (src/K4os.Compression.LZ4.Tests/SpanTests.cs:36-44).
+ *   - Call-level return: K4LZ4_OK or a negative k4lz4_status; text via k4lz4_last_error().
+ *     The library never throws, aborts or calls back.  No pointer is retained after return
+ *     (the *_device calls return after enqueueing on the given stream; the buffers must stay
+ *     valid until that stream work completes).
+ *   - There is NO CPU fallback: without a usable gfx950 device every compute entry point fails
+ *     with K4LZ4_E_NO_DEVICE.
+ *   - A k4lz4_ctx is bound to one GPU and may be used by one host thread at a time; different
+ *     contexts are independent (reentrant like the reference's static API).
+ */
+#ifndef K4LZ4_H
+#define K4LZ4_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define K4LZ4_API __attribute__((visibility("default")))
+#define K4LZ4_VERSION 100 /* 0.1.0 */
+
+typedef struct k4lz4_ctx k4lz4_ctx;
+
+enum k4lz4_status {
+    K4LZ4_OK = 0,
+    K4LZ4_E_HIP = -1,         /* HIP runtime error, see k4lz4_last_error */
+    K4LZ4_E_ARG = -2,         /* NULL pointer / negative count (the C# shim raises ArgumentException) */
+    K4LZ4_E_NOMEM = -3,
+    K4LZ4_E_NO_DEVICE = -4,   /* no gfx950 device visible */
+    K4LZ4_E_UNSUPPORTED = -5  /* level outside what the device path implements */
+};
+
+/* LZ4Level.cs:6-39 -- the numeric value is part of the ABI */
+enum k4lz4_level {
+    K4LZ4_L00_FAST = 0,
+    K4LZ4_L03_HC = 3, K4LZ4_L04_HC = 4, K4LZ4_L05_HC = 5, K4LZ4_L06_HC = 6, K4LZ4_L07_HC = 7,
+    K4LZ4_L08_HC = 8, K4LZ4_L09_HC = 9, K4LZ4_L10_OPT = 10, K4LZ4_L11_OPT = 11, K4LZ4_L12_MAX = 12
+};
+
+enum k4lz4_flags {
+    K4LZ4_FLAG_RAW_RETURN = 1,    /* outLen = LLxx-level return values */
+    K4LZ4_FLAG_PICKLE_WRITER = 2  /* LZ4Pickler IBufferWriter path header rule (LZ4Pickler.pickle.cs:113-158) */
+};
+
+K4LZ4_API int k4lz4_version(void);
+K4LZ4_API int k4lz4_device_count(void);
+
+/* device < 0: the calling thread's current HIP device */
+K4LZ4_API int k4lz4_ctx_create(k4lz4_ctx **out, int device);
+K4LZ4_API void k4lz4_ctx_destroy(k4lz4_ctx *ctx);
+/* ctx may be NULL: last error of the calling thread's implicit context / of ctx creation */
+K4LZ4_API const char *k4lz4_last_error(const k4lz4_ctx *ctx);
+K4LZ4_API int k4lz4_ctx_device(const k4lz4_ctx *ctx);
+/* blocks until everything this ctx enqueued on `stream` (NULL = default stream) has finished */
+K4LZ4_API int k4lz4_synchronize(k4lz4_ctx *ctx, void *stream);
+
+/* LZ4Codec.MaximumOutputSize (LZ4Codec.cs:30-31) == LL.LZ4_compressBound (Engine/LL.tools.cs:38-40).
+ * Pure host arithmetic. */
+K4LZ4_API int k4lz4_compress_bound(int n);
+
+/* ---- per-block entry points: the Engine/LLxx.cs seam, same argument order and returns ------
+ * (host pointers; each call is a batch of one on the calling thread's implicit context) */
+/* These mirror the reference's `int` returns, which cannot carry an infrastructure failure (no
+ * GPU, HIP error, unsupported level): such a failure returns 0 (encode) / -1 (decode) and sets the
+ * thread's status, which the host shim must check: K4LZ4_OK or a negative k4lz4_status. */
+K4LZ4_API int k4lz4_last_status(void);
+/* LLxx.LZ4_compress_fast (Engine/LLxx.cs:65-75) */
+K4LZ4_API int k4lz4_compress_fast(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap, int acceleration);
+/* LLxx.LZ4_compress_HC (Engine/LLxx.cs:94-103) */
+K4LZ4_API int k4lz4_compress_hc(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap, int level);
+/* LLxx.LZ4_decompress_safe (Engine/LLxx.cs:17-26) */
+K4LZ4_API int k4lz4_decompress_safe(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap);
+
+/* ---- batches of independent blocks (what LZ4Codec.Encode / Decode callers loop over) --------
+ * block i: input  src + srcOff[i], srcLen[i] bytes;  output dst + dstOff[i], dstCap[i] bytes.
+ * Host variants take host pointers and stage through the GPU; they return when done.      */
+K4LZ4_API int k4lz4_encode_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+                                 uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen,
+                                 int64_t n, int level, int flags);
+K4LZ4_API int k4lz4_decode_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+                                 uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen,
+                                 int64_t n, int flags);
+
+/* Device-resident variants: every pointer (including srcOff/srcLen/dstOff/dstCap/outLen) is a
+ * device pointer on ctx's GPU; `stream` is a hipStream_t (NULL = default stream).  Asynchronous. */
+K4LZ4_API int k4lz4_encode_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff,
+                                        const int32_t *srcLen, uint8_t *dst, const uint64_t *dstOff,
+                                        const int32_t *dstCap, int32_t *outLen, int64_t n, int level, int flags,
+                                        void *stream);
+K4LZ4_API int k4lz4_decode_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff,
+                                        const int32_t *srcLen, uint8_t *dst, const uint64_t *dstOff,
+                                        const int32_t *dstCap, int32_t *outLen, int64_t n, int flags, void *stream);
+
+/* ---- LZ4Pickler envelope, version 0 (LZ4Pickler.pickle.cs:51-228, LZ4Pickler.unpickle.cs:18-158)
+ * pickle:   outLen[i] = envelope bytes written to dst + dstOff[i]; dstCap[i] must be at least
+ *           k4lz4_pickle_bound(srcLen[i]); 0 for an empty message (Pickle returns an empty array).
+ * unpickle: dstCap[i] must equal the size k4lz4_unpickle_size reports (the reference allocates
+ *           exactly that); outLen[i] = that size, or -1 where the reference throws
+ *           InvalidDataException (bad version, short header, size mismatch, corrupt block).  */
+K4LZ4_API int k4lz4_pickle_bound(int srcLen);
+/* host arithmetic on one envelope: unpickled size, or -1 when the header is corrupt */
+K4LZ4_API int k4lz4_unpickle_size(const uint8_t *pickle, int pickleLen);
+K4LZ4_API int k4lz4_pickle_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+                                 uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen,
+                                 int64_t n, int level, int flags);
+K4LZ4_API int k4lz4_unpickle_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+                                   uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen,
+                                   int64_t n, int flags);
+K4LZ4_API int k4lz4_pickle_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff,
+                                        const int32_t *srcLen, uint8_t *dst, const uint64_t *dstOff,
+                                        const int32_t *dstCap, int32_t *outLen, int64_t n, int level, int flags,
+                                        void *stream);
+K4LZ4_API int k4lz4_unpickle_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff,
+                                          const int32_t *srcLen, uint8_t *dst, const uint64_t *dstOff,
+                                          const int32_t *dstCap, int32_t *outLen, int64_t n, int flags,
+                                          void *stream);
+/* device-side k4lz4_unpickle_size for a whole batch: outLen[i] = unpickled size or -1 */
+K4LZ4_API int k4lz4_unpickle_sizes_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff,
+                                          const int32_t *srcLen, int32_t *outLen, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* K4LZ4_H */

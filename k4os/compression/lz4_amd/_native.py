@@ -1,0 +1,151 @@
+"""ctypes binding of libk4lz4.so (include/k4lz4.h).  This is the ONLY compute path of the package:
+if the shared object is missing, or no gfx950 device is usable, every operation raises -- there is
+no CPU fallback (the CPU oracle under oracle/ is test infrastructure and is never imported here)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libk4lz4.so")
+
+K4LZ4_OK = 0
+E_HIP, E_ARG, E_NOMEM, E_NO_DEVICE, E_UNSUPPORTED = -1, -2, -3, -4, -5
+FLAG_RAW_RETURN = 1
+FLAG_PICKLE_WRITER = 2
+
+_u8p = C.c_void_p
+_BATCH = [C.c_void_p, _u8p, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+
+# every symbol include/k4lz4.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "k4lz4_version": (C.c_int, []),
+    "k4lz4_device_count": (C.c_int, []),
+    "k4lz4_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "k4lz4_ctx_destroy": (None, [C.c_void_p]),
+    "k4lz4_last_error": (C.c_char_p, [C.c_void_p]),
+    "k4lz4_ctx_device": (C.c_int, [C.c_void_p]),
+    "k4lz4_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "k4lz4_compress_bound": (C.c_int, [C.c_int]),
+    "k4lz4_last_status": (C.c_int, []),
+    "k4lz4_compress_fast": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int]),
+    "k4lz4_compress_hc": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int]),
+    "k4lz4_decompress_safe": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int]),
+    "k4lz4_encode_batch": (C.c_int, _BATCH + [C.c_int, C.c_int]),
+    "k4lz4_decode_batch": (C.c_int, _BATCH + [C.c_int]),
+    "k4lz4_encode_batch_device": (C.c_int, _BATCH + [C.c_int, C.c_int, C.c_void_p]),
+    "k4lz4_decode_batch_device": (C.c_int, _BATCH + [C.c_int, C.c_void_p]),
+    "k4lz4_pickle_bound": (C.c_int, [C.c_int]),
+    "k4lz4_unpickle_size": (C.c_int, [_u8p, C.c_int]),
+    "k4lz4_pickle_batch": (C.c_int, _BATCH + [C.c_int, C.c_int]),
+    "k4lz4_unpickle_batch": (C.c_int, _BATCH + [C.c_int]),
+    "k4lz4_pickle_batch_device": (C.c_int, _BATCH + [C.c_int, C.c_int, C.c_void_p]),
+    "k4lz4_unpickle_batch_device": (C.c_int, _BATCH + [C.c_int, C.c_void_p]),
+    "k4lz4_unpickle_sizes_device": (C.c_int, [C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+}
+
+
+class NativeLibraryError(RuntimeError):
+    """libk4lz4.so is missing / unusable, or a HIP call failed."""
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library(path: str | None = None):
+    """dlopen libk4lz4.so and type every declared symbol.  Does not touch the GPU."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise NativeLibraryError(
+                f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        lib = C.CDLL(p)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if path is None:
+            _lib = lib
+        return lib
+
+
+class Context:
+    """k4lz4_ctx: one per GPU per host thread."""
+
+    def __init__(self, device: int = -1):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.k4lz4_ctx_create(C.byref(h), device)
+        if rc != K4LZ4_OK:
+            msg = (self.lib.k4lz4_last_error(None) or b"").decode()
+            raise NativeLibraryError(f"k4lz4_ctx_create failed ({rc}): {msg}")
+        self.handle = h
+
+    @property
+    def device(self) -> int:
+        return self.lib.k4lz4_ctx_device(self.handle)
+
+    def check(self, rc: int):
+        if rc == K4LZ4_OK:
+            return
+        msg = (self.lib.k4lz4_last_error(self.handle) or b"").decode()
+        if rc == E_ARG:
+            raise ValueError(msg)
+        if rc == E_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        if rc == E_NOMEM:
+            raise MemoryError(msg)
+        raise NativeLibraryError(f"libk4lz4 error {rc}: {msg}")
+
+    def synchronize(self, stream: int = 0):
+        self.check(self.lib.k4lz4_synchronize(self.handle, C.c_void_p(stream)))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.k4lz4_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_tls = threading.local()
+
+
+def default_context() -> Context:
+    """Per-thread context on the current device (LOCAL_RANK when launched by torch.distributed.run)."""
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is None:
+        dev = -1
+        if "LOCAL_RANK" in os.environ:
+            lib = load_library()
+            n = lib.k4lz4_device_count()
+            if n > 0:
+                dev = int(os.environ["LOCAL_RANK"]) % n
+        ctx = Context(dev)
+        _tls.ctx = ctx
+    return ctx
+
+
+def check_last_status(lib):
+    """raise if the thread's last LLxx-shaped call failed for an infrastructure reason"""
+    rc = lib.k4lz4_last_status()
+    if rc == K4LZ4_OK:
+        return
+    msg = (lib.k4lz4_last_error(None) or b"").decode()
+    if rc == E_ARG:
+        raise ValueError(msg)
+    if rc == E_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == E_NOMEM:
+        raise MemoryError(msg)
+    raise NativeLibraryError(f"libk4lz4 error {rc}: {msg}")

@@ -1,0 +1,404 @@
+/*
+ * k4lz4_capi.hip -- host side of libk4lz4.so (see include/k4lz4.h for the contract).
+ *
+ * The only compute path is the gfx950 kernels in this directory; there is no CPU fallback.
+ * Host-pointer batch calls stage through device buffers owned by the context:
+ *   H2D  the source span + the four metadata vectors
+ *   run  one kernel launch per batch (one wavefront per block)
+ *   D2H  outLen, then the produced bytes (compact device layout -> pinned staging -> the
+ *        caller's slots, copying exactly outLen[i] bytes so dst[ret..cap) stays untouched,
+ *        SpanTests.cs:36-44).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../../../include/k4lz4.h"
+#include "k4lz4_decode.hpp"
+#include "k4lz4_encode_fast.hpp"
+#include "k4lz4_pickle.hpp"
+
+struct k4lz4_ctx {
+    int device = -1;
+    std::string error;
+    hipStream_t stream = nullptr;   /* used by the host-pointer calls */
+    int accel = 1;                  /* fast-encoder acceleration of the next launch (LLxx-level calls only) */
+    /* grow-only device / pinned scratch for the host-pointer calls */
+    uint8_t *d_src = nullptr; size_t d_src_cap = 0;
+    uint8_t *d_dst = nullptr; size_t d_dst_cap = 0;
+    uint8_t *d_meta = nullptr; size_t d_meta_cap = 0;
+    uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;
+};
+
+namespace {
+
+thread_local std::string tl_error;
+thread_local int tl_status = K4LZ4_OK;
+
+int fail(k4lz4_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->error = msg;
+    tl_error = msg;
+    return code;
+}
+
+int hip_fail(k4lz4_ctx *ctx, hipError_t e, const char *what)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return fail(ctx, K4LZ4_E_HIP, buf);
+}
+
+#define K4_HIP(ctx, call)                                                   \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call);              \
+    } while (0)
+
+enum Kind { KIND_ENCODE, KIND_DECODE, KIND_PICKLE, KIND_UNPICKLE };
+
+int check_level(k4lz4_ctx *ctx, int level)
+{
+    if (level < K4LZ4_L03_HC) return K4LZ4_OK;   /* LZ4Codec.cs:48: level < L03_HC -> fast */
+    return fail(ctx, K4LZ4_E_UNSUPPORTED, "LZ4Level >= L03_HC is not implemented by the device path yet");
+}
+
+/* enqueue the kernels for n blocks; all pointers are device pointers */
+int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+           const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level, int flags,
+           hipStream_t stream)
+{
+    if (n == 0) return K4LZ4_OK;
+    const int64_t chunk_max = 1 << 24;   /* blocks per launch (grid.x * blockDim.x must stay < 2^32) */
+    for (int64_t first = 0; first < n; first += chunk_max) {
+        const int64_t cnt = std::min<int64_t>(chunk_max, n - first);
+        k4::BatchArgs a;
+        a.src = src; a.srcOff = srcOff + first; a.srcLen = srcLen + first;
+        a.dst = dst; a.dstOff = dstOff + first; a.dstCap = dstCap + first;
+        a.outLen = outLen + first; a.n = cnt; a.level = level; a.accel = ctx->accel; a.flags = flags;
+        const unsigned wg4 = (unsigned)((cnt + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
+        switch (kind) {
+        case KIND_ENCODE:
+            hipLaunchKernelGGL(k4::k4_encode_fast_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a);
+            break;
+        case KIND_DECODE:
+            hipLaunchKernelGGL(k4::k4_decode_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
+            break;
+        case KIND_PICKLE:
+            hipLaunchKernelGGL(k4::k4_pickle_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a);
+            break;
+        case KIND_UNPICKLE:
+            hipLaunchKernelGGL(k4::k4_unpickle_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
+            break;
+        }
+        K4_HIP(ctx, hipGetLastError());
+    }
+    return K4LZ4_OK;
+}
+
+int grow(k4lz4_ctx *ctx, uint8_t **p, size_t *cap, size_t need, bool pinned)
+{
+    if (need <= *cap) return K4LZ4_OK;
+    const size_t want = std::max(need, *cap + *cap / 2);
+    if (*p) {
+        if (pinned) (void)hipHostFree(*p); else (void)hipFree(*p);
+        *p = nullptr; *cap = 0;
+    }
+    hipError_t e = pinned ? hipHostMalloc((void **)p, want, hipHostMallocDefault) : hipMalloc((void **)p, want);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(ctx, K4LZ4_E_NOMEM, "out of device/pinned memory"); }
+    *cap = want;
+    return K4LZ4_OK;
+}
+
+int check_batch_args(k4lz4_ctx *ctx, const void *src, const void *srcOff, const void *srcLen, const void *dst,
+                     const void *dstOff, const void *dstCap, const void *outLen, int64_t n)
+{
+    if (!ctx) return fail(nullptr, K4LZ4_E_ARG, "ctx is NULL");
+    if (n < 0) return fail(ctx, K4LZ4_E_ARG, "negative block count");
+    if (n > 0 && (!src || !srcOff || !srcLen || !dst || !dstOff || !dstCap || !outLen))
+        return fail(ctx, K4LZ4_E_ARG, "NULL batch pointer");
+    return K4LZ4_OK;
+}
+
+/* host-pointer batch: stage, run, scatter */
+int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+             uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level,
+             int flags)
+{
+    int rc = check_batch_args(ctx, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n);
+    if (rc != K4LZ4_OK) return rc;
+    if (kind == KIND_ENCODE || kind == KIND_PICKLE) {
+        rc = check_level(ctx, level);
+        if (rc != K4LZ4_OK) return rc;
+    }
+    if (n == 0) return K4LZ4_OK;
+    K4_HIP(ctx, hipSetDevice(ctx->device));
+
+    /* source span and compact destination layout */
+    uint64_t lo = UINT64_MAX, hi = 0;
+    std::vector<uint64_t> h_soff((size_t)n), h_doff((size_t)n);
+    std::vector<int32_t> h_cap((size_t)n);
+    uint64_t dtotal = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t len = srcLen[i];
+        if (len > 0) {
+            lo = std::min(lo, srcOff[i]);
+            hi = std::max(hi, srcOff[i] + (uint64_t)len);
+        }
+        h_cap[(size_t)i] = dstCap[i] < 0 ? 0 : dstCap[i];
+        h_doff[(size_t)i] = dtotal;
+        dtotal += ((uint64_t)h_cap[(size_t)i] + 15u) & ~(uint64_t)15u;
+    }
+    if (lo == UINT64_MAX) { lo = 0; hi = 0; }
+    for (int64_t i = 0; i < n; i++) h_soff[(size_t)i] = srcLen[i] > 0 ? srcOff[i] - lo : 0;
+    const size_t span = (size_t)(hi - lo);
+
+    const size_t meta_bytes = (size_t)n * (8 + 4 + 8 + 4 + 4);
+    if ((rc = grow(ctx, &ctx->d_src, &ctx->d_src_cap, span + 64, false)) != K4LZ4_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_dst, &ctx->d_dst_cap, (size_t)dtotal + 64, false)) != K4LZ4_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_meta, &ctx->d_meta_cap, meta_bytes + 64, false)) != K4LZ4_OK) return rc;
+    if ((rc = grow(ctx, &ctx->h_stage, &ctx->h_stage_cap, (size_t)dtotal + 64, true)) != K4LZ4_OK) return rc;
+
+    uint64_t *d_soff = (uint64_t *)ctx->d_meta;
+    uint64_t *d_doff = d_soff + n;
+    int32_t *d_slen = (int32_t *)(d_doff + n);
+    int32_t *d_cap = d_slen + n;
+    int32_t *d_out = d_cap + n;
+    hipStream_t st = ctx->stream;
+    if (span) K4_HIP(ctx, hipMemcpyAsync(ctx->d_src, src + lo, span, hipMemcpyHostToDevice, st));
+    K4_HIP(ctx, hipMemcpyAsync(d_soff, h_soff.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    K4_HIP(ctx, hipMemcpyAsync(d_doff, h_doff.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    K4_HIP(ctx, hipMemcpyAsync(d_slen, srcLen, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    K4_HIP(ctx, hipMemcpyAsync(d_cap, h_cap.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    rc = launch(ctx, kind, ctx->d_src, d_soff, d_slen, ctx->d_dst, d_doff, d_cap, d_out, n, level, flags, st);
+    if (rc != K4LZ4_OK) return rc;
+    K4_HIP(ctx, hipMemcpyAsync(outLen, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    if (dtotal) K4_HIP(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_dst, (size_t)dtotal, hipMemcpyDeviceToHost, st));
+    K4_HIP(ctx, hipStreamSynchronize(st));
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t got = outLen[i];
+        if (got > 0 && got <= h_cap[(size_t)i]) memcpy(dst + dstOff[i], ctx->h_stage + h_doff[(size_t)i], (size_t)got);
+    }
+    return K4LZ4_OK;
+}
+
+int run_device(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+               uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level,
+               int flags, void *stream)
+{
+    int rc = check_batch_args(ctx, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n);
+    if (rc != K4LZ4_OK) return rc;
+    if (kind == KIND_ENCODE || kind == KIND_PICKLE) {
+        rc = check_level(ctx, level);
+        if (rc != K4LZ4_OK) return rc;
+    }
+    if (n == 0) return K4LZ4_OK;
+    K4_HIP(ctx, hipSetDevice(ctx->device));
+    return launch(ctx, kind, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, (hipStream_t)stream);
+}
+
+struct CtxDeleter { void operator()(k4lz4_ctx *c) const { k4lz4_ctx_destroy(c); } };
+thread_local std::unique_ptr<k4lz4_ctx, CtxDeleter> tl_ctx;
+
+k4lz4_ctx *implicit_ctx()
+{
+    if (!tl_ctx) {
+        k4lz4_ctx *c = nullptr;
+        if (k4lz4_ctx_create(&c, -1) != K4LZ4_OK) return nullptr;
+        tl_ctx.reset(c);
+    }
+    return tl_ctx.get();
+}
+
+/* batch of one with LLxx-level returns */
+int single(Kind kind, const uint8_t *src, uint8_t *dst, int srcLen, int dstCap, int level, int accel = 1)
+{
+    tl_status = K4LZ4_OK;
+    k4lz4_ctx *ctx = implicit_ctx();
+    if (!ctx) { tl_status = K4LZ4_E_NO_DEVICE; return kind == KIND_DECODE ? -1 : 0; }
+    if (!src || !dst) { tl_status = fail(ctx, K4LZ4_E_ARG, "NULL buffer"); return kind == KIND_DECODE ? -1 : 0; }
+    const uint64_t off = 0;
+    int32_t slen = srcLen, cap = dstCap, out = 0;
+    ctx->accel = accel < 1 ? 1 : accel;
+    const int rc = run_host(ctx, kind, src, &off, &slen, dst, &off, &cap, &out, 1, level, K4LZ4_FLAG_RAW_RETURN);
+    ctx->accel = 1;
+    tl_status = rc;
+    if (rc != K4LZ4_OK) return kind == KIND_DECODE ? -1 : 0;
+    return out;
+}
+
+}  // namespace
+
+extern "C" {
+
+int k4lz4_version(void) { return K4LZ4_VERSION; }
+
+int k4lz4_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int k4lz4_ctx_create(k4lz4_ctx **out, int device)
+{
+    if (!out) return fail(nullptr, K4LZ4_E_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, K4LZ4_E_NO_DEVICE, "no HIP device visible (libk4lz4 has no CPU fallback)");
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); device = 0; }
+    }
+    if (device >= n) return fail(nullptr, K4LZ4_E_ARG, "device index out of range");
+    hipDeviceProp_t prop;
+    K4_HIP(nullptr, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, K4LZ4_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", libk4lz4 is built for gfx950 only");
+    k4lz4_ctx *ctx = new (std::nothrow) k4lz4_ctx();
+    if (!ctx) return fail(nullptr, K4LZ4_E_NOMEM, "out of host memory");
+    ctx->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return hip_fail(nullptr, e, "hipStreamCreate"); }
+    *out = ctx;
+    return K4LZ4_OK;
+}
+
+void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    if (ctx->d_src) (void)hipFree(ctx->d_src);
+    if (ctx->d_dst) (void)hipFree(ctx->d_dst);
+    if (ctx->d_meta) (void)hipFree(ctx->d_meta);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    delete ctx;
+}
+
+const char *k4lz4_last_error(const k4lz4_ctx *ctx) { return ctx ? ctx->error.c_str() : tl_error.c_str(); }
+
+int k4lz4_ctx_device(const k4lz4_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+int k4lz4_synchronize(k4lz4_ctx *ctx, void *stream)
+{
+    if (!ctx) return fail(nullptr, K4LZ4_E_ARG, "ctx is NULL");
+    K4_HIP(ctx, hipSetDevice(ctx->device));
+    K4_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return K4LZ4_OK;
+}
+
+int k4lz4_last_status(void) { return tl_status; }
+
+int k4lz4_compress_bound(int n) { return n > 0x7E000000 ? 0 : n + n / 255 + 16; }
+
+int k4lz4_compress_fast(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap, int acceleration)
+{
+    return single(KIND_ENCODE, src, dst, srcLen, dstCap, K4LZ4_L00_FAST, acceleration);
+}
+
+int k4lz4_compress_hc(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap, int level)
+{
+    return single(KIND_ENCODE, src, dst, srcLen, dstCap, level < K4LZ4_L03_HC ? K4LZ4_L03_HC : level);
+}
+
+int k4lz4_decompress_safe(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap)
+{
+    return single(KIND_DECODE, src, dst, srcLen, dstCap, 0);
+}
+
+int k4lz4_encode_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                       const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level, int flags)
+{
+    return run_host(ctx, KIND_ENCODE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags);
+}
+
+int k4lz4_decode_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                       const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int flags)
+{
+    return run_host(ctx, KIND_DECODE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, 0, flags);
+}
+
+int k4lz4_encode_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+                              uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n,
+                              int level, int flags, void *stream)
+{
+    return run_device(ctx, KIND_ENCODE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, stream);
+}
+
+int k4lz4_decode_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+                              uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n,
+                              int flags, void *stream)
+{
+    return run_device(ctx, KIND_DECODE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, 0, flags, stream);
+}
+
+int k4lz4_pickle_bound(int srcLen) { return srcLen <= 0 ? 0 : 1 + 4 + srcLen; }
+
+int k4lz4_unpickle_size(const uint8_t *p, int len)
+{
+    /* LZ4Pickler.unpickle.cs:131-148 */
+    if (len == 0) return 0;
+    if (!p || len < 0) return -1;
+    if ((p[0] & 7) != 0) return -1;
+    const int code = (p[0] >> 6) & 3;
+    const int sod = code == 3 ? 4 : code;
+    const int data_len = len - 1 - sod;
+    if (data_len < 0) return -1;
+    uint32_t diff = 0;
+    for (int i = 0; i < sod; i++) diff |= (uint32_t)p[1 + i] << (8 * i);
+    const int r = (int)((uint32_t)data_len + diff);
+    return r < 0 ? -1 : r;
+}
+
+int k4lz4_pickle_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                       const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level, int flags)
+{
+    return run_host(ctx, KIND_PICKLE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags);
+}
+
+int k4lz4_unpickle_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                         const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int flags)
+{
+    return run_host(ctx, KIND_UNPICKLE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, 0, flags);
+}
+
+int k4lz4_pickle_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+                              uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n,
+                              int level, int flags, void *stream)
+{
+    return run_device(ctx, KIND_PICKLE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, stream);
+}
+
+int k4lz4_unpickle_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+                                uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n,
+                                int flags, void *stream)
+{
+    return run_device(ctx, KIND_UNPICKLE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, 0, flags, stream);
+}
+
+int k4lz4_unpickle_sizes_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+                                int32_t *outLen, int64_t n, void *stream)
+{
+    if (!ctx) return fail(nullptr, K4LZ4_E_ARG, "ctx is NULL");
+    if (n < 0 || (n > 0 && (!src || !srcOff || !srcLen || !outLen))) return fail(ctx, K4LZ4_E_ARG, "bad argument");
+    if (n == 0) return K4LZ4_OK;
+    K4_HIP(ctx, hipSetDevice(ctx->device));
+    k4::BatchArgs a{};
+    a.src = src; a.srcOff = srcOff; a.srcLen = srcLen; a.outLen = outLen; a.n = n;
+    hipLaunchKernelGGL(k4::k4_unpickle_sizes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    K4_HIP(ctx, hipGetLastError());
+    return K4LZ4_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+/*
+ * k4lz4_common.hpp -- shared device-side helpers for the gfx950 LZ4 block kernels.
+ *
+ * Execution model used throughout: ONE WAVEFRONT (64 lanes) OWNS ONE LZ4 BLOCK.  All control
+ * state of a block (input/output cursors, token fields) is wave-uniform and lives in SGPRs; the
+ * 64 lanes are used for the data-parallel pieces: coalesced byte moves, 64 speculative
+ * hash-probes at once, match-length counting, run-length fills.  Cross-lane traffic goes through
+ * ballot / readlane / shuffles, or through LDS/global memory separated by wave_sync().
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace k4 {
+
+/* Block-format constants: reference src/K4os.Compression.LZ4/Engine/LL.types.cs:18-78 */
+enum : int {
+    MINMATCH = 4,
+    LASTLITERALS = 5,
+    MFLIMIT = 12,
+    MATCH_SAFEGUARD = 12,
+    ML_BITS = 4,
+    ML_MASK = 15,
+    RUN_MASK = 15,
+    DISTANCE_MAX = 65535,
+    SKIP_TRIGGER = 6,
+    LIMIT_64K = 65536 + (MFLIMIT - 1),
+    MAX_INPUT_SIZE = 0x7E000000,
+};
+
+/* per-batch flags (k4lz4.h) */
+enum : int {
+    FLAG_RAW_RETURN = 1,  /* outLen = LLxx-level return instead of the LZ4Codec mapping */
+    FLAG_PICKLE_WRITER = 2,
+};
+
+struct BatchArgs {
+    const uint8_t *src;
+    const uint64_t *srcOff;
+    const int32_t *srcLen;
+    uint8_t *dst;
+    const uint64_t *dstOff;
+    const int32_t *dstCap;
+    int32_t *outLen;
+    long long n;
+    int level;   /* encode: LZ4Level; */
+    int accel;   /* fast encoder acceleration (LZ4Codec always passes 1) */
+    int flags;
+};
+
+struct __attribute__((packed, aligned(1))) U16u { uint16_t v; };
+struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
+struct __attribute__((packed, aligned(1))) U64u { uint64_t v; };
+struct __attribute__((packed, aligned(1))) U128u { uint32_t v[4]; };
+
+__device__ __forceinline__ uint32_t ld32u(const uint8_t *p) { return ((const U32u *)p)->v; }
+__device__ __forceinline__ uint64_t ld64u(const uint8_t *p) { return ((const U64u *)p)->v; }
+__device__ __forceinline__ U128u ld128u(const uint8_t *p) { return *(const U128u *)p; }
+__device__ __forceinline__ void st128u(uint8_t *p, U128u v) { *(U128u *)p = v; }
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+/* Orders this wave's earlier LDS/global accesses (any lane) before its later ones (any lane).
+ * The hardware executes a wave's memory instructions in order; this pins the compiler. */
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int ctz64(unsigned long long m) { return __ffsll(m) - 1; }
+
+/* LL.tools.cs:38-40 */
+__device__ __forceinline__ int compress_bound(int n)
+{
+    return n > MAX_INPUT_SIZE ? 0 : n + n / 255 + 16;
+}
+
+/* Wave-cooperative copy of n bytes, regions must not overlap.  Long runs move 16 B per lane
+ * (1 KiB per wave instruction, unaligned dwordx4), the rest one byte per lane. */
+__device__ __forceinline__ void wave_copy(uint8_t *d, const uint8_t *s, uint32_t n, int lane)
+{
+    uint32_t done = 0;
+    if (n >= 128) {
+        uint32_t nv = n >> 4;
+        for (uint32_t v = (uint32_t)lane; v < nv; v += 64) st128u(d + 16ull * v, ld128u(s + 16ull * v));
+        done = nv << 4;
+    }
+    for (uint32_t k = done + (uint32_t)lane; k < n; k += 64) d[k] = s[k];
+}
+
+/* n bytes of value `b` */
+__device__ __forceinline__ void wave_fill(uint8_t *d, uint8_t b, uint32_t n, int lane)
+{
+    for (uint32_t k = (uint32_t)lane; k < n; k += 64) d[k] = b;
+}
+
+}  // namespace k4

@@ -1,0 +1,102 @@
+"""Device-resident batches: the roofline path.  Buffers are torch tensors on the GPU (torch is
+used for device memory and streams only); the kernels are reached through the *_device entry
+points of the C ABI with raw device pointers."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _native
+from .codec import LZ4Level
+
+
+def _dp(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+@dataclass
+class DeviceBatch:
+    """n independent blocks in one packed device buffer"""
+    data: torch.Tensor      # uint8
+    off: torch.Tensor       # int64 holding uint64 offsets
+    length: torch.Tensor    # int32 (lengths for a source batch, capacities for a target batch)
+
+    @property
+    def n(self) -> int:
+        return int(self.length.numel())
+
+    @staticmethod
+    def from_host(data: np.ndarray, off: np.ndarray, length: np.ndarray, device) -> "DeviceBatch":
+        d = torch.from_numpy(np.ascontiguousarray(data)).to(device, non_blocking=False)
+        o = torch.from_numpy(np.ascontiguousarray(off).view(np.int64)).to(device)
+        ln = torch.from_numpy(np.ascontiguousarray(length, dtype=np.int32)).to(device)
+        return DeviceBatch(d, o, ln)
+
+    @staticmethod
+    def empty_slots(caps: np.ndarray, device, align: int = 16, fill: Optional[int] = None) -> "DeviceBatch":
+        caps = np.asarray(caps, dtype=np.int64).clip(min=0)
+        padded = (caps + (align - 1)) // align * align
+        off = np.zeros(len(caps), dtype=np.int64)
+        if len(caps) > 1:
+            off[1:] = np.cumsum(padded[:-1])
+        total = int(padded.sum()) + 64
+        if fill is None:
+            data = torch.empty(total, dtype=torch.uint8, device=device)
+        else:
+            data = torch.full((total,), fill, dtype=torch.uint8, device=device)
+        return DeviceBatch(data, torch.from_numpy(off).to(device), torch.from_numpy(caps.astype(np.int32)).to(device))
+
+
+class DeviceCodec:
+    """Batched LZ4Codec / LZ4Pickler on HBM-resident data; asynchronous on the current torch stream."""
+
+    def __init__(self, device: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise _native.NativeLibraryError("no GPU visible: the device path has no CPU fallback")
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.ctx = _native.Context(self.device_index)
+        self.lib = self.ctx.lib
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _call(self, fn, src: DeviceBatch, dst: DeviceBatch, out_len: torch.Tensor, *tail):
+        assert src.n == dst.n == out_len.numel() and out_len.dtype == torch.int32
+        rc = fn(self.ctx.handle, _dp(src.data), _dp(src.off), _dp(src.length), _dp(dst.data), _dp(dst.off),
+                _dp(dst.length), _dp(out_len), src.n, *tail, C.c_void_p(self._stream()))
+        self.ctx.check(rc)
+        return out_len
+
+    def new_out_len(self, n: int) -> torch.Tensor:
+        return torch.empty(n, dtype=torch.int32, device=self.device)
+
+    def encode(self, src: DeviceBatch, dst: DeviceBatch, out_len: Optional[torch.Tensor] = None,
+               level: LZ4Level = LZ4Level.L00_FAST, flags: int = 0) -> torch.Tensor:
+        out_len = self.new_out_len(src.n) if out_len is None else out_len
+        return self._call(self.lib.k4lz4_encode_batch_device, src, dst, out_len, int(level), flags)
+
+    def decode(self, src: DeviceBatch, dst: DeviceBatch, out_len: Optional[torch.Tensor] = None,
+               flags: int = 0) -> torch.Tensor:
+        out_len = self.new_out_len(src.n) if out_len is None else out_len
+        return self._call(self.lib.k4lz4_decode_batch_device, src, dst, out_len, flags)
+
+    def pickle(self, src: DeviceBatch, dst: DeviceBatch, out_len: Optional[torch.Tensor] = None,
+               level: LZ4Level = LZ4Level.L00_FAST, flags: int = 0) -> torch.Tensor:
+        out_len = self.new_out_len(src.n) if out_len is None else out_len
+        return self._call(self.lib.k4lz4_pickle_batch_device, src, dst, out_len, int(level), flags)
+
+    def unpickle(self, src: DeviceBatch, dst: DeviceBatch, out_len: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out_len = self.new_out_len(src.n) if out_len is None else out_len
+        return self._call(self.lib.k4lz4_unpickle_batch_device, src, dst, out_len, 0)
+
+    def unpickle_sizes(self, src: DeviceBatch) -> torch.Tensor:
+        out = self.new_out_len(src.n)
+        rc = self.lib.k4lz4_unpickle_sizes_device(self.ctx.handle, _dp(src.data), _dp(src.off), _dp(src.length),
+                                                  _dp(out), src.n, C.c_void_p(self._stream()))
+        self.ctx.check(rc)
+        return out

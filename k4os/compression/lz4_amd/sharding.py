@@ -1,0 +1,49 @@
+"""Multi-GPU split of a batch of independent blocks.
+
+Blocks are independent, so there is no data-path collective: rank g takes a contiguous index range
+chosen by a prefix sum of the block sizes (byte-balanced), works on it in its own HBM, and only the
+int32 size vector is gathered (RCCL all_gather over xGMI when the process group is NCCL, gloo on
+CPU tests).  Pure host logic + torch.distributed; no kernels here."""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+
+def byte_balanced_ranges(lengths: Sequence[int], world_size: int) -> List[Tuple[int, int]]:
+    """Contiguous [lo, hi) per rank such that every rank gets ~ total_bytes / world_size.
+    Deterministic; ranges cover [0, n) without overlap; empty ranges are allowed."""
+    lens = np.asarray(lengths, dtype=np.int64).clip(min=0)
+    n = int(lens.size)
+    if world_size <= 0:
+        raise ValueError("world_size must be positive")
+    csum = np.concatenate(([0], np.cumsum(lens)))
+    total = int(csum[-1])
+    bounds = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        # first index whose cumulative start reaches the target (ties -> earlier), never backwards
+        idx = int(np.searchsorted(csum, target, side="left"))
+        if idx > 0 and idx <= n and abs(csum[idx - 1] - target) <= abs(csum[min(idx, n)] - target):
+            idx -= 1
+        idx = min(max(idx, bounds[-1]), n)
+        bounds.append(idx)
+    bounds.append(n)
+    return [(bounds[i], bounds[i + 1]) for i in range(world_size)]
+
+
+def gather_sizes(local_sizes, ranges: Sequence[Tuple[int, int]], group=None):
+    """all_gather the per-rank int32 size slices into the full size vector (torch tensors).
+    `local_sizes` is this rank's slice (on the device the backend needs: cuda for nccl)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    counts = [hi - lo for lo, hi in ranges]
+    maxc = max(counts) if counts else 0
+    pad = torch.zeros(maxc, dtype=torch.int32, device=local_sizes.device)
+    pad[:local_sizes.numel()] = local_sizes
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)]) if counts else pad

@@ -1,0 +1,99 @@
+"""ctypes driver for tests/emu/libk4lz4_emu.so: the product's HIP kernel source compiled by g++
+against the host wave emulator (tests/emu/hip/hip_runtime.h).  Test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_SO = os.path.join(EMU_DIR, "libk4lz4_emu.so")
+_u8p = C.POINTER(C.c_uint8)
+
+
+def build_emu() -> str:
+    srcs = glob.glob(os.path.join(EMU_DIR, "*.cpp")) + glob.glob(os.path.join(EMU_DIR, "hip", "*.h")) + \
+        glob.glob(os.path.join(ROOT, "k4os", "compression", "lz4_amd", "csrc", "*.hpp"))
+    if not os.path.exists(EMU_SO) or any(os.path.getmtime(s) > os.path.getmtime(EMU_SO) for s in srcs):
+        subprocess.check_call(["make", "-C", EMU_DIR, "-s", "-B"])
+    return EMU_SO
+
+
+def pack(blocks, caps=None, guard=0):
+    """blocks: list of uint8 arrays -> (packed, off u64, len i32).  With caps: an output arena
+    (filled 0xCD) with `guard` bytes between slots."""
+    lens = np.array([b.size for b in blocks], dtype=np.int32)
+    off = np.zeros(len(blocks), dtype=np.uint64)
+    if len(blocks):
+        off[1:] = np.cumsum(lens[:-1].astype(np.uint64))
+    buf = np.concatenate([np.asarray(b, np.uint8) for b in blocks]) if len(blocks) else np.zeros(0, np.uint8)
+    if buf.size == 0:
+        buf = np.zeros(1, np.uint8)
+    return np.ascontiguousarray(buf), off, lens
+
+
+def arena(caps, guard=16):
+    caps = np.asarray(caps, dtype=np.int32)
+    sizes = np.maximum(caps.astype(np.int64), 0) + guard
+    off = np.zeros(len(caps), dtype=np.uint64)
+    off[:] = guard + np.concatenate(([0], np.cumsum(sizes[:-1]))) if len(caps) else 0
+    total = int(sizes.sum()) + guard + 16
+    return np.full(total, 0xCD, dtype=np.uint8), off, caps
+
+
+class Emu:
+    def __init__(self):
+        self.lib = C.CDLL(build_emu())
+        b = [_u8p, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
+        self.lib.k4emu_decode_batch.argtypes = b + [C.c_int, C.c_int]
+        self.lib.k4emu_encode_batch.argtypes = b + [C.c_int, C.c_int, C.c_int, C.c_int]
+        self.lib.k4emu_pickle_batch.argtypes = b + [C.c_int, C.c_int, C.c_int]
+        self.lib.k4emu_unpickle_batch.argtypes = b + [C.c_int, C.c_int]
+        self.lib.k4emu_unpickle_sizes.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int]
+
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data_as(_u8p)
+
+    def decode_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, flags=0, threads=0):
+        out = np.full(len(src_len), -12345, dtype=np.int32)
+        rc = self.lib.k4emu_decode_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
+                                         dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data,
+                                         len(src_len), flags, threads)
+        assert rc == 0
+        return out
+
+    def encode_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, level=0, accel=1, flags=0, threads=0):
+        out = np.full(len(src_len), -12345, dtype=np.int32)
+        rc = self.lib.k4emu_encode_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
+                                         dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data,
+                                         len(src_len), level, accel, flags, threads)
+        assert rc == 0
+        return out
+
+    def pickle_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, level=0, flags=0, threads=0):
+        out = np.full(len(src_len), -12345, dtype=np.int32)
+        rc = self.lib.k4emu_pickle_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
+                                         dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data,
+                                         len(src_len), level, flags, threads)
+        assert rc == 0
+        return out
+
+    def unpickle_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, flags=0, threads=0):
+        out = np.full(len(src_len), -12345, dtype=np.int32)
+        rc = self.lib.k4emu_unpickle_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
+                                           dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data,
+                                           len(src_len), flags, threads)
+        assert rc == 0
+        return out
+
+    def unpickle_sizes(self, src, src_off, src_len, threads=0):
+        out = np.full(len(src_len), -12345, dtype=np.int32)
+        rc = self.lib.k4emu_unpickle_sizes(self._p(src), src_off.ctypes.data, src_len.ctypes.data,
+                                           out.ctypes.data, len(src_len), threads)
+        assert rc == 0
+        return out

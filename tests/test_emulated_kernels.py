@@ -1,0 +1,224 @@
+"""The product's kernel source (k4os/compression/lz4_amd/csrc/*.hpp), compiled by g++ against the
+host wave emulator (tests/emu), compared with the oracle.  This checks the kernels' *logic*
+(speculative probe rounds, in-window duplicate resolution, token parse, accept/reject rules,
+envelope arithmetic) on the CPU; the same comparisons run against the real gfx950 build in the
+`-m gpu` tests.  Nothing here is a product path."""
+import numpy as np
+import pytest
+
+from emu_lib import Emu, pack, arena
+from k4os.compression.lz4_amd import corpus
+
+FLAG_RAW = 1
+FLAG_WRITER = 2
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return Emu()
+
+
+def _fixture_blocks():
+    b = [np.frombuffer(corpus.QUICK_FOX, np.uint8)]
+    b += [corpus.lorem(n) for n in (1, 2, 11, 12, 13, 14, 15, 64, 1000, 4096, 0x7FFF, 65535, 65536, 65546)]
+    b += [corpus.repeated(0xAA, n) for n in (1, 13, 15, 17, 33, 67, 1000, 65536)]
+    b += [corpus.repeated(0, 300), np.zeros(0, np.uint8)]
+    b += [corpus.random_bytes(n, n) for n in (5, 100, 5000, 66000)]
+    b += [corpus.class_bytes(name, 20000 + 3000 * i, 11) for i, name in enumerate(corpus.SILESIA_NAMES)]
+    # short-period and near-window-edge patterns
+    b += [np.tile(np.arange(p, dtype=np.uint8), 3000 // p + 1)[:3000] for p in (1, 2, 3, 5, 7, 8, 9, 63, 64, 65, 255)]
+    rng = np.random.default_rng(3)
+    pat = rng.integers(0, 256, 40, dtype=np.uint8)
+    b += [np.concatenate([pat, rng.integers(0, 256, 60000, dtype=np.uint8), pat, pat])]
+    return b
+
+
+def test_encode_fast_matches_oracle(emu, oracle):
+    blocks = _fixture_blocks()
+    src, soff, slen = pack(blocks)
+    caps = [oracle.compress_bound(b.size) for b in blocks]
+    dst, doff, dcap = arena(caps)
+    out = emu.encode_batch(src, soff, slen, dst, doff, dcap)
+    for i, b in enumerate(blocks):
+        want = oracle.encode(b)
+        if b.size == 0:
+            assert out[i] == 0
+            continue
+        got = dst[int(doff[i]):int(doff[i]) + max(int(out[i]), 0)].tobytes()
+        assert out[i] == len(want) and got == want, f"block {i} ({b.size} B)"
+    # guard bands and slack untouched
+    mask = np.ones(dst.size, bool)
+    for i in range(len(blocks)):
+        mask[int(doff[i]):int(doff[i]) + max(int(out[i]), 0)] = False
+    assert (dst[mask] == 0xCD).all()
+
+
+def test_encode_fast_big_block_hash5(emu, oracle):
+    """>= 65547 bytes switches to the u32 table + hash5 (LL64.fast.cs:526-544)"""
+    blocks = [corpus.lorem(65547), corpus.class_bytes("samba", 200000, 5), corpus.class_bytes("mozilla", 140000, 5),
+              np.concatenate([corpus.class_bytes("dickens", 70000, 9)] * 2)]
+    src, soff, slen = pack(blocks)
+    dst, doff, dcap = arena([oracle.compress_bound(b.size) for b in blocks])
+    out = emu.encode_batch(src, soff, slen, dst, doff, dcap)
+    for i, b in enumerate(blocks):
+        want = oracle.encode(b)
+        assert out[i] == len(want)
+        assert dst[int(doff[i]):int(doff[i]) + int(out[i])].tobytes() == want
+
+
+def test_encode_limited_output_boundary(emu, oracle):
+    """BlockRoundtripTests.cs:114-125 BorderLineCompressions: cap == size succeeds, size-1 fails"""
+    blocks, caps, wants = [], [], []
+    for name in ("x-ray", "dickens", "xml", "sao"):
+        b = corpus.class_bytes(name, 30000, 2)
+        full = oracle.encode(b)
+        for cap in (len(full), len(full) - 1, len(full) + 1, 10, 0):
+            blocks.append(b); caps.append(cap); wants.append(full if cap >= len(full) else None)
+    src, soff, slen = pack(blocks)
+    dst, doff, dcap = arena(caps)
+    out = emu.encode_batch(src, soff, slen, dst, doff, dcap)
+    raw = emu.encode_batch(src, soff, slen, arena(caps)[0], doff, dcap, flags=FLAG_RAW)
+    for i, w in enumerate(wants):
+        if w is None:
+            assert out[i] == -1 and raw[i] == 0
+        else:
+            assert out[i] == len(w) and dst[int(doff[i]):int(doff[i]) + len(w)].tobytes() == w
+    for i in range(len(blocks)):   # never writes past its slot
+        lo, hi = int(doff[i]) + int(dcap[i]), int(doff[i]) + int(dcap[i]) + 16
+        assert (dst[lo:hi] == 0xCD).all()
+
+
+def test_decode_matches_oracle_and_guards(emu, oracle):
+    blocks = [b for b in _fixture_blocks() if b.size]
+    comp = [np.frombuffer(oracle.encode(b), np.uint8) for b in blocks]
+    src, soff, slen = pack(comp)
+    for slack in (0, 37):
+        dst, doff, dcap = arena([b.size + slack for b in blocks])
+        out = emu.decode_batch(src, soff, slen, dst, doff, dcap)
+        for i, b in enumerate(blocks):
+            assert out[i] == b.size
+            assert dst[int(doff[i]):int(doff[i]) + b.size].tobytes() == b.tobytes()
+            assert (dst[int(doff[i]) + b.size:int(doff[i]) + b.size + slack + 16] == 0xCD).all()
+
+
+def test_decode_golden_issue64(emu, oracle):
+    import os, struct
+    raw = open(os.path.join(os.path.dirname(__file__), "golden", "issue64_input.bin"), "rb").read()
+    want = open(os.path.join(os.path.dirname(__file__), "golden", "issue64_output.bin"), "rb").read()
+    u, c = struct.unpack_from("<II", raw, 24)
+    comp = np.frombuffer(raw[32:32 + c], np.uint8)
+    src, soff, slen = pack([comp])
+    dst, doff, dcap = arena([u])
+    out = emu.decode_batch(src, soff, slen, dst, doff, dcap)
+    assert out[0] == 65536 and dst[int(doff[0]):int(doff[0]) + u].tobytes() == want[:u]
+
+
+def test_decode_malformed_parity_with_oracle(emu, oracle):
+    """accept/reject, LLxx-level error codes and bytes identical to the oracle (LL64.dec.cs rules)"""
+    rng = np.random.default_rng(17)
+    comps, caps = [], []
+    for name, n in (("dickens", 3000), ("xml", 5000), ("x-ray", 2000), ("nci", 70000)):
+        data = corpus.class_bytes(name, n, 4)
+        good = np.frombuffer(oracle.encode(data), np.uint8)
+        for t in range(150):
+            bad = good.copy()
+            kind = t % 4
+            if kind == 0:
+                bad = bad[:rng.integers(1, good.size)]
+            elif kind == 1:
+                for _ in range(int(rng.integers(1, 4))):
+                    bad[rng.integers(0, good.size)] = rng.integers(0, 256)
+            elif kind == 2:
+                bad = np.concatenate([bad, rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8)])
+            comps.append(bad)
+            caps.append(n + int(rng.integers(-20, 21)) if kind != 3 else int(rng.integers(0, n)))
+    src, soff, slen = pack(comps)
+    dst, doff, dcap = arena(caps)
+    out = emu.decode_batch(src, soff, slen, dst, doff, dcap, flags=FLAG_RAW)
+    for i, (c, cap) in enumerate(zip(comps, caps)):
+        n, ref = oracle.decompress_safe(c, cap)
+        assert out[i] == n, f"stream {i}: kernel {out[i]} oracle {n}"
+        if n >= 0:
+            assert dst[int(doff[i]):int(doff[i]) + n].tobytes() == ref[:n].tobytes()
+        assert (dst[int(doff[i]) + cap:int(doff[i]) + cap + 16] == 0xCD).all()
+        assert (dst[int(doff[i]) - 16:int(doff[i])] == 0xCD).all()
+
+
+def test_decode_special_cases(emu, oracle):
+    """LL64.dec.cs:160-172 and the LZ4Codec mapping (LZ4Codec.cs:104-115)"""
+    comps = [np.array([0], np.uint8), np.array([0], np.uint8), np.array([0x10, 0x41], np.uint8), np.zeros(0, np.uint8),
+             np.array([0x00, 0x00], np.uint8)]
+    caps = [0, 5, 0, 10, 0]
+    src, soff, slen = pack(comps)
+    dst, doff, dcap = arena(caps)
+    raw = emu.decode_batch(src, soff, slen, dst, doff, dcap, flags=FLAG_RAW)
+    cod = emu.decode_batch(src, soff, slen, dst, doff, dcap)
+    for i, (c, cap) in enumerate(zip(comps, caps)):
+        n, _ = oracle.decompress_safe(c, cap)
+        assert raw[i] == n
+        want = oracle.decode(c, cap)
+        assert cod[i] == (0 if c.size == 0 else (-1 if want is None else len(want)))
+
+
+def test_pickle_matches_oracle(emu, oracle):
+    """PicklingTests.cs:11-50 lengths, both header rules"""
+    blocks = [np.zeros(0, np.uint8)]
+    for n in (1, 10, 32, 200, 1023, 1024, 1025, 1337, 0x10000, 0x172a5):
+        blocks += [corpus.lorem(n), corpus.random_bytes(n, n)]
+    blocks += [corpus.class_bytes("xml", 300000, 1), corpus.repeated(7, 70000)]
+    src, soff, slen = pack(blocks)
+    caps = [oracle.lib.k4o_pickle_bound(b.size) for b in blocks]
+    for writer in (0, 1):
+        dst, doff, dcap = arena(caps)
+        out = emu.pickle_batch(src, soff, slen, dst, doff, dcap, flags=FLAG_WRITER if writer else 0)
+        pickles = []
+        for i, b in enumerate(blocks):
+            want = oracle.pickle(b, 0, writer)
+            got = dst[int(doff[i]):int(doff[i]) + int(out[i])].tobytes()
+            assert got == want, f"message {i} ({b.size} B) writer={writer}"
+            assert (dst[int(doff[i]) + max(int(dcap[i]), int(out[i])):int(doff[i]) + int(dcap[i]) + 16] == 0xCD).all()
+            pickles.append(np.frombuffer(got, np.uint8))
+        # unpickle through the kernels
+        psrc, poff, plen = pack(pickles)
+        sizes = emu.unpickle_sizes(psrc, poff, plen)
+        assert list(sizes) == [b.size for b in blocks]
+        udst, uoff, ucap = arena(sizes)
+        uout = emu.unpickle_batch(psrc, poff, plen, udst, uoff, ucap)
+        for i, b in enumerate(blocks):
+            assert uout[i] == b.size
+            assert udst[int(uoff[i]):int(uoff[i]) + b.size].tobytes() == b.tobytes()
+
+
+def test_unpickle_corruption(emu, oracle):
+    """PicklingTests.cs:149-172: corrupted pickles are rejected exactly where the oracle rejects"""
+    rng = np.random.default_rng(23)
+    base = np.frombuffer(oracle.pickle(corpus.lorem(5000)), np.uint8)
+    pickles = []
+    for t in range(200):
+        p = base.copy()
+        k = t % 4
+        if k == 0:
+            p[0] = rng.integers(0, 256)
+        elif k == 1:
+            p = p[:rng.integers(0, p.size)]
+        elif k == 2:
+            p[rng.integers(0, p.size)] ^= 1 << rng.integers(0, 8)
+        else:
+            p = np.concatenate([p, rng.integers(0, 256, 3, dtype=np.uint8)])
+        pickles.append(p)
+    psrc, poff, plen = pack(pickles)
+    sizes = emu.unpickle_sizes(psrc, poff, plen)
+    caps = np.where(sizes < 0, 0, np.minimum(sizes, 1 << 20)).astype(np.int32)
+    udst, uoff, ucap = arena(caps)
+    uout = emu.unpickle_batch(psrc, poff, plen, udst, uoff, ucap)
+    for i, p in enumerate(pickles):
+        want = oracle.unpickle(p.tobytes())
+        rc, _, rl, _ = oracle.unpickle_header(p.tobytes()) if p.size else (0, 0, 0, 0)
+        if p.size == 0:
+            assert sizes[i] == 0 and uout[i] == 0
+            continue
+        assert sizes[i] == (rl if rc == 0 and rl >= 0 else -1)
+        if want is None or caps[i] != sizes[i]:
+            assert uout[i] == -1
+        else:
+            assert uout[i] == len(want) and udst[int(uoff[i]):int(uoff[i]) + len(want)].tobytes() == want

@@ -1,0 +1,275 @@
+"""Parity tests proper: the HIP path (through the C ABI of libk4lz4.so) against the oracle and the
+reference's own fixtures.  They read like the reference's tests:
+  BlockRoundtripTests.cs:45-125, SpanTests.cs:11-83, PicklingTests.cs:11-172, Issue64.cs:16-55,
+plus batch parity on the BASELINE.json configurations."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from k4os.compression.lz4_amd import (LZ4Codec, LZ4Level, LZ4Pickler, InvalidDataException, corpus, pack_blocks,
+                                      make_arena)
+from k4os.compression.lz4_amd._native import FLAG_RAW_RETURN, FLAG_PICKLE_WRITER
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def roundtrip(data: np.ndarray, oracle):
+    """TestBase-style helper: encode, compare with the oracle, decode into 2x buffer"""
+    target = np.full(LZ4Codec.MaximumOutputSize(data.size), 0xCD, np.uint8)
+    n = LZ4Codec.Encode(data, target)
+    want = oracle.encode(data)
+    assert n == len(want) and target[:n].tobytes() == want
+    assert (target[n:] == 0xCD).all()
+    out = np.full(2 * data.size + 8, 0xCD, np.uint8)
+    m = LZ4Codec.Decode(target[:n].copy(), out)
+    assert m == data.size and out[:m].tobytes() == data.tobytes()
+    assert (out[m:] == 0xCD).all()
+
+
+# ---- BlockRoundtripTests.cs -------------------------------------------------------------------
+def test_quick_fox(oracle):                                         # :45-61
+    roundtrip(np.frombuffer(corpus.QUICK_FOX, np.uint8), oracle)
+
+
+def test_single_byte(oracle):                                       # :63-68
+    roundtrip(np.array([0x7A], np.uint8), oracle)
+
+
+@pytest.mark.parametrize("n", [13, 15, 17, 33, 67, 1000, 0x10000])   # :70-84
+def test_repeated_byte(oracle, n):
+    roundtrip(corpus.repeated(0xAA, n), oracle)
+
+
+@pytest.mark.parametrize("n", [1, 1000, 0x7FFF, 0xFFFF, 0x123456])   # :86-98
+def test_lorem(oracle, n):
+    roundtrip(corpus.lorem(n), oracle)
+
+
+@pytest.mark.parametrize("seed,n", [(0, 1000), (1, 0x7FFF), (2, 0xFFFF), (3, 0x123456)])   # :100-112
+def test_incompressible(oracle, seed, n):
+    roundtrip(corpus.random_bytes(n, seed), oracle)
+
+
+def test_borderline_compressions(oracle):                           # :114-125
+    data = corpus.class_bytes("x-ray", 0x10000, 1)
+    required = len(oracle.encode(data))
+    exact = np.zeros(required, np.uint8)
+    assert LZ4Codec.Encode(data, exact) == required
+    assert exact.tobytes() == oracle.encode(data)
+    assert LZ4Codec.Encode(data, np.zeros(required - 1, np.uint8)) < 0
+
+
+# ---- SpanTests.cs -------------------------------------------------------------------------------
+def test_span_offsets_and_guards(oracle):                           # :11-83
+    payload = corpus.lorem(5000)
+    src = np.full(8000, 0xEE, np.uint8)
+    src[1234:1234 + 5000] = payload
+    tgt = np.full(9000, 0xCD, np.uint8)
+    n = LZ4Codec.Encode(src, 1234, 5000, tgt, 777, 6000)
+    want = oracle.encode(payload)
+    assert n == len(want) and tgt[777:777 + n].tobytes() == want
+    assert (tgt[:777] == 0xCD).all() and (tgt[777 + n:] == 0xCD).all()
+    out = np.full(9000, 0xCD, np.uint8)
+    m = LZ4Codec.Decode(tgt, 777, n, out, 333, 7000)
+    assert m == 5000 and out[333:5333].tobytes() == payload.tobytes()
+    assert (out[:333] == 0xCD).all() and (out[5333:] == 0xCD).all()
+
+
+def test_decode_too_small_target_is_negative(oracle):
+    data = corpus.lorem(3000)
+    comp = np.frombuffer(oracle.encode(data), np.uint8)
+    assert LZ4Codec.Decode(comp, np.zeros(2999, np.uint8)) < 0
+    assert LZ4Codec.Decode(comp, np.zeros(3000, np.uint8)) == 3000
+
+
+# ---- Issue64.cs: golden decode fixture from the reference repo ---------------------------------
+def test_issue64_golden_record0():
+    raw = open(os.path.join(GOLDEN, "issue64_input.bin"), "rb").read()
+    want = open(os.path.join(GOLDEN, "issue64_output.bin"), "rb").read()
+    u, c = struct.unpack_from("<II", raw, 24)
+    out = np.zeros(u, np.uint8)
+    assert LZ4Codec.Decode(np.frombuffer(raw[32:32 + c], np.uint8), out) == 65536
+    assert out.tobytes() == want[:u]
+
+
+# ---- PicklingTests.cs -----------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [0, 10, 32, 200, 1337, 0x10000, 0x172a5, 4 << 20])   # :11-50
+def test_pickle_lorem_and_random(oracle, n):
+    for data in (corpus.lorem(n), corpus.random_bytes(n, n)):
+        p = LZ4Pickler.Pickle(data)
+        assert p == oracle.pickle(data)
+        assert LZ4Pickler.Unpickle(p) == data.tobytes()
+        assert LZ4Pickler.UnpickledSize(p) == n
+
+
+def test_pickle_writer_and_span_forms(oracle):                      # :52-147
+    import io
+    data = corpus.lorem(70000)
+    w = io.BytesIO()
+    LZ4Pickler.Pickle(data, w)
+    assert w.getvalue() == oracle.pickle(data, 0, 1)
+    assert LZ4Pickler.Unpickle(w.getvalue()) == data.tobytes()
+    buf = np.full(80000, 0xEE, np.uint8)
+    buf[100:70100] = data
+    assert LZ4Pickler.Pickle(buf, 100, 70000) == LZ4Pickler.Pickle(data)    # array vs span: identical bytes
+    out = np.zeros(70000, np.uint8)
+    LZ4Pickler.Unpickle(LZ4Pickler.Pickle(data), out)
+    assert out.tobytes() == data.tobytes()
+    w2 = io.BytesIO()
+    LZ4Pickler.Unpickle(LZ4Pickler.Pickle(data), w2)
+    assert w2.getvalue() == data.tobytes()
+
+
+def test_pickle_corruption_raises(oracle):                          # :149-172
+    p = bytearray(LZ4Pickler.Pickle(corpus.lorem(5000)))
+    bad_version = bytes([p[0] | 1]) + bytes(p[1:])
+    with pytest.raises(InvalidDataException):
+        LZ4Pickler.Unpickle(bad_version)
+    with pytest.raises(InvalidDataException):
+        LZ4Pickler.Unpickle(bytes(p[:-7]))
+    with pytest.raises(InvalidDataException):
+        LZ4Pickler.Unpickle(bytes(p), np.zeros(4999, np.uint8))
+    flipped = bytearray(p)
+    flipped[1] ^= 0x40
+    with pytest.raises(InvalidDataException):
+        LZ4Pickler.Unpickle(bytes(flipped))
+
+
+# ---- batch parity on the BASELINE.json configurations -----------------------------------------
+def test_batch_encode_decode_silesia_like_vs_oracle(oracle):
+    """configs[1] at reduced count: 12 classes x 64 KiB, every block compared with the oracle"""
+    blocks = corpus.silesia_like_blocks(240, 65536, seed=2)
+    n = blocks.shape[0]
+    src = blocks.reshape(-1)
+    off = np.arange(n, dtype=np.uint64) * 65536
+    lens = np.full(n, 65536, np.int32)
+    caps = np.full(n, LZ4Codec.MaximumOutputSize(65536), np.int32)
+    dst, doff = make_arena(caps, fill=0xCD)
+    out = LZ4Codec.EncodeBatchPacked(src, off, lens, dst, doff, caps)
+    want_len = oracle.encode_batch(src, off, lens, np.empty_like(dst), doff, caps, threads=8)
+    assert np.array_equal(out, want_len)
+    ref = np.full_like(dst, 0xCD)
+    oracle.encode_batch(src, off, lens, ref, doff, caps, threads=8)
+    assert np.array_equal(dst, ref)          # bytes and untouched slack identical
+    back, boff = make_arena(lens, fill=0xCD)
+    dl = LZ4Codec.DecodeBatchPacked(dst, doff, out, back, boff, lens)
+    assert (dl == 65536).all() and np.array_equal(back[:n * 65536].reshape(n, 65536), blocks)
+
+
+def test_batch_small_blocks_4k_vs_oracle(oracle):
+    """configs[2] shape at reduced count: 4 KiB blocks, text + random"""
+    blocks = np.concatenate([corpus.silesia_like_blocks(600, 4096, seed=5),
+                             corpus.random_bytes(200 * 4096, 1).reshape(200, 4096)])
+    n = blocks.shape[0]
+    enc = LZ4Codec.EncodeBatch(list(blocks))
+    for i in range(n):
+        assert enc[i] == oracle.encode(blocks[i]), i
+    dec = LZ4Codec.DecodeBatch(enc, [4096] * n)
+    assert all(d == blocks[i].tobytes() for i, d in enumerate(dec))
+
+
+def test_batch_ragged_and_empty(oracle):
+    """empty, tiny, table-switch sizes and > 64 KiB blocks in one batch"""
+    sizes = [0, 1, 5, 12, 13, 14, 100, 65535, 65536, 65546, 65547, 70000, 300000, 0, 1 << 20]
+    blocks = [corpus.class_bytes(corpus.SILESIA_NAMES[i % 12], s, i) if s else np.zeros(0, np.uint8)
+              for i, s in enumerate(sizes)]
+    enc = LZ4Codec.EncodeBatch(blocks)
+    for i, b in enumerate(blocks):
+        assert enc[i] == (b"" if b.size == 0 else oracle.encode(b)), i
+    dec = LZ4Codec.DecodeBatch(enc, sizes)
+    assert all(d == b.tobytes() for d, b in zip(dec, blocks))
+
+
+def test_batch_malformed_streams_raw_returns(oracle):
+    """accept/reject + LLxx return values + bytes identical to the oracle; guards untouched"""
+    rng = np.random.default_rng(31)
+    comps, caps = [], []
+    for name, n in (("dickens", 3000), ("xml", 6000), ("mr", 66000)):
+        data = corpus.class_bytes(name, n, 4)
+        good = np.frombuffer(oracle.encode(data), np.uint8)
+        for t in range(400):
+            bad = good.copy()
+            k = t % 4
+            if k == 0:
+                bad = bad[:rng.integers(1, good.size)]
+            elif k == 1:
+                for _ in range(int(rng.integers(1, 4))):
+                    bad[rng.integers(0, good.size)] = rng.integers(0, 256)
+            elif k == 2:
+                bad = np.concatenate([bad, rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8)])
+            comps.append(bad)
+            caps.append(n + int(rng.integers(-20, 21)) if k != 3 else int(rng.integers(0, n)))
+    src, soff, slen = pack_blocks(comps)
+    caps = np.array(caps, np.int32)
+    dst, doff = make_arena(caps + 32, fill=0xCD)
+    out = LZ4Codec.DecodeBatchPacked(src, soff, slen, dst, doff, caps, flags=FLAG_RAW_RETURN)
+    for i, (c, cap) in enumerate(zip(comps, caps)):
+        n, ref = oracle.decompress_safe(c, int(cap))
+        assert out[i] == n, i
+        if n > 0:
+            assert dst[int(doff[i]):int(doff[i]) + n].tobytes() == ref[:n].tobytes()
+        assert (dst[int(doff[i]) + max(n, 0):int(doff[i]) + int(cap) + 32] == 0xCD).all()
+
+
+def test_batch_limited_output(oracle):
+    blocks, caps, wants = [], [], []
+    for name in corpus.SILESIA_NAMES:
+        b = corpus.class_bytes(name, 65536, 6)
+        full = oracle.encode(b)
+        for cap in (len(full), len(full) - 1, len(full) // 2, 0):
+            blocks.append(b); caps.append(cap); wants.append(full if cap >= len(full) else None)
+    src, soff, slen = pack_blocks(blocks)
+    caps = np.array(caps, np.int32)
+    dst, doff = make_arena(caps + 16, fill=0xCD)
+    out = LZ4Codec.EncodeBatchPacked(src, soff, slen, dst, doff, caps)
+    for i, w in enumerate(wants):
+        if w is None:
+            assert out[i] == -1
+        else:
+            assert out[i] == len(w) and dst[int(doff[i]):int(doff[i]) + len(w)].tobytes() == w
+        assert (dst[int(doff[i]) + int(caps[i]):int(doff[i]) + int(caps[i]) + 16] == 0xCD).all()
+
+
+def test_pickle_batch_variable_messages(oracle):
+    """configs[3] shape at reduced size: variable-length random/text messages, both header rules"""
+    data, off, lens = corpus.variable_messages(200, seed=4, lo=1024, hi=1 << 20, budget_bytes=24 << 20)
+    msgs = [data[int(o):int(o) + int(l)] for o, l in zip(off, lens)]
+    for writer in (False, True):
+        ps = LZ4Pickler.PickleBatch(msgs, writer_mode=writer)
+        for i, m in enumerate(msgs):
+            assert ps[i] == oracle.pickle(m, 0, int(writer)), i
+        back = LZ4Pickler.UnpickleBatch(ps)
+        assert all(b == m.tobytes() for b, m in zip(back, msgs))
+
+
+def test_full_size_config2_properties(oracle):
+    """configs[1] at full size (4096 x 64 KiB) on device-resident buffers: round trip + checksum of
+    sizes against the oracle's total (bytes compared block-by-block for a sample)."""
+    import torch
+    from k4os.compression.lz4_amd.device import DeviceBatch, DeviceCodec
+    blocks = corpus.silesia_like_blocks(4096, 65536, seed=2)
+    n = blocks.shape[0]
+    dc = DeviceCodec(0)
+    lens = np.full(n, 65536, np.int32)
+    off = np.arange(n, dtype=np.uint64) * 65536
+    src = DeviceBatch.from_host(blocks.reshape(-1), off, lens, dc.device)
+    comp = DeviceBatch.empty_slots(np.full(n, LZ4Codec.MaximumOutputSize(65536)), dc.device, fill=0xCD)
+    clen = dc.encode(src, comp)
+    back = DeviceBatch.empty_slots(lens, dc.device)
+    dlen = dc.decode(DeviceBatch(comp.data, comp.off, clen), back)
+    torch.cuda.synchronize()
+    assert (dlen.cpu().numpy() == 65536).all()
+    assert torch.equal(back.data[:n * 65536], src.data[:n * 65536])
+    clen_h = clen.cpu().numpy()
+    caps = np.full(n, LZ4Codec.MaximumOutputSize(65536), np.int32)
+    ref_dst, ref_off = make_arena(caps)
+    want = oracle.encode_batch(blocks.reshape(-1), off, lens, ref_dst, ref_off, caps, threads=os.cpu_count() or 8)
+    assert np.array_equal(clen_h, want)
+    comp_h = comp.data.cpu().numpy()
+    coff = comp.off.cpu().numpy()
+    for i in range(0, n, 7):
+        assert comp_h[coff[i]:coff[i] + clen_h[i]].tobytes() == ref_dst[int(ref_off[i]):int(ref_off[i]) + int(want[i])].tobytes()
+        assert (comp_h[coff[i] + clen_h[i]:coff[i] + caps[i]] == 0xCD).all()
