@@ -135,6 +135,18 @@ K4LZ4_API int k4lz4_unpickle_batch_device(k4lz4_ctx *ctx, const uint8_t *src, co
 K4LZ4_API int k4lz4_unpickle_sizes_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff,
                                           const int32_t *srcLen, int32_t *outLen, int64_t n, void *stream);
 
+/* ---- diagnostics -----------------------------------------------------------------------------
+ * Runs the encode (decode = 0, L00_FAST, blocks < 65547 B) or decode (decode = 1) kernel's
+ * instrumented twin on a device-resident batch and fills `counters` (device pointer, 16 x uint64
+ * per block): [0] total shader cycles, [1..3] cycles per phase (encode: probe / extend / emit;
+ * decode: parse / literals / matches), [4..7] event counts, [8]/[9] start/end on the 100 MHz
+ * real-time counter, [10] HW_ID of the executing wave.  Results in dst/outLen
+ * are identical to the normal kernels; timing is perturbed (each phase drains its memory traffic). */
+K4LZ4_API int k4lz4_profile_batch_device(k4lz4_ctx *ctx, int decode, const uint8_t *src, const uint64_t *srcOff,
+                                         const int32_t *srcLen, uint8_t *dst, const uint64_t *dstOff,
+                                         const int32_t *dstCap, int32_t *outLen, int64_t n, uint64_t *counters,
+                                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

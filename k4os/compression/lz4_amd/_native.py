@@ -42,6 +42,7 @@ SYMBOLS = {
     "k4lz4_unpickle_batch": (C.c_int, _BATCH + [C.c_int]),
     "k4lz4_pickle_batch_device": (C.c_int, _BATCH + [C.c_int, C.c_int, C.c_void_p]),
     "k4lz4_unpickle_batch_device": (C.c_int, _BATCH + [C.c_int, C.c_void_p]),
+    "k4lz4_profile_batch_device": (C.c_int, [C.c_void_p, C.c_int] + _BATCH[1:] + [C.c_void_p, C.c_void_p]),
     "k4lz4_unpickle_sizes_device": (C.c_int, [C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
 }
 

@@ -29,6 +29,7 @@ struct k4lz4_ctx {
     std::string error;
     hipStream_t stream = nullptr;   /* used by the host-pointer calls */
     int accel = 1;                  /* fast-encoder acceleration of the next launch (LLxx-level calls only) */
+    unsigned long long *prof = nullptr;   /* diagnostic counters of the next launch (k4lz4_profile_batch_device) */
     /* grow-only device / pinned scratch for the host-pointer calls */
     uint8_t *d_src = nullptr; size_t d_src_cap = 0;
     uint8_t *d_dst = nullptr; size_t d_dst_cap = 0;
@@ -83,13 +84,16 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
         a.src = src; a.srcOff = srcOff + first; a.srcLen = srcLen + first;
         a.dst = dst; a.dstOff = dstOff + first; a.dstCap = dstCap + first;
         a.outLen = outLen + first; a.n = cnt; a.level = level; a.accel = ctx->accel; a.flags = flags;
+        a.prof = ctx->prof ? ctx->prof + k4::PROF_STRIDE * first : nullptr;
         const unsigned wg4 = (unsigned)((cnt + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
         switch (kind) {
         case KIND_ENCODE:
-            hipLaunchKernelGGL(k4::k4_encode_fast_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a);
+            if (a.prof) hipLaunchKernelGGL(k4::k4_encode_fast_prof_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL(k4::k4_encode_fast_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a);
             break;
         case KIND_DECODE:
-            hipLaunchKernelGGL(k4::k4_decode_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
+            if (a.prof) hipLaunchKernelGGL(k4::k4_decode_prof_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
+            else hipLaunchKernelGGL(k4::k4_decode_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
             break;
         case KIND_PICKLE:
             hipLaunchKernelGGL(k4::k4_pickle_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a);
@@ -385,6 +389,18 @@ int k4lz4_unpickle_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64
                                 int flags, void *stream)
 {
     return run_device(ctx, KIND_UNPICKLE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, 0, flags, stream);
+}
+
+int k4lz4_profile_batch_device(k4lz4_ctx *ctx, int decode, const uint8_t *src, const uint64_t *srcOff,
+                               const int32_t *srcLen, uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap,
+                               int32_t *outLen, int64_t n, uint64_t *counters, void *stream)
+{
+    if (!ctx || !counters) return fail(ctx, K4LZ4_E_ARG, "bad argument");
+    ctx->prof = (unsigned long long *)counters;
+    const int rc = run_device(ctx, decode ? KIND_DECODE : KIND_ENCODE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n,
+                              K4LZ4_L00_FAST, 0, stream);
+    ctx->prof = nullptr;
+    return rc;
 }
 
 int k4lz4_unpickle_sizes_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,

@@ -46,6 +46,7 @@ struct BatchArgs {
     int level;   /* encode: LZ4Level; */
     int accel;   /* fast encoder acceleration (LZ4Codec always passes 1) */
     int flags;
+    unsigned long long *prof;  /* diagnostics: PROF_STRIDE counters per block, or nullptr */
 };
 
 struct __attribute__((packed, aligned(1))) U16u { uint16_t v; };
@@ -67,6 +68,32 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int PROF_STRIDE = 16;
+
+/* placement record of the diagnostic kernels: [8] start, [9] end (100 MHz real-time counter), [10] HW_ID */
+template <bool PROF> __device__ __forceinline__ void prof_place(unsigned long long *pc, int slot, int lane)
+{
+    if (!PROF || !pc) return;
+#ifndef K4_HOST_EMU
+    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    if (lane == 0) { pc[slot] = t; if (slot == 8) pc[10] = hw; }
+#else
+    (void)slot; (void)lane;
+#endif
+}
+
+/* phase timestamps for the diagnostic kernels: drain this wave's memory traffic, then read the
+ * shader clock, so that a phase's cycles include its own memory waits */
+template <bool PROF> __device__ __forceinline__ unsigned long long prof_now()
+{
+    if (!PROF) return 0ull;
+#ifndef K4_HOST_EMU
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    return (unsigned long long)__builtin_readcyclecounter();
 }
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }

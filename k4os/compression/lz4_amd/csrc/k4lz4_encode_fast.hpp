@@ -88,11 +88,21 @@ __device__ __forceinline__ uint32_t emit_length_run(uint8_t *dst, uint32_t op, u
 /*
  * LL64.LZ4_compress_generic for one block.  `tab` is this wave's 16 KiB LDS table (zeroed here:
  * LZ4_initStream, LL.tools.cs:235-239).  Returns bytes written, 0 when the output does not fit.
+ *
+ * Every iteration of the main loop produces one sequence with three dependent memory round trips:
+ *   (1) the 4 (8) source bytes of up to 64 probe positions        -> hashes -> LDS table lookups
+ *   (2) the 4 bytes at the 64 candidates                          -> first hit
+ *   (3) backward bytes + up to 256 forward bytes of both sides, and the literal bytes
+ * The reference's "test the position right after a match" step (LL64.fast.cs:393-463) rides in
+ * lane 0 of the next probe round instead of being a round trip of its own.
  */
-template <bool BYU16>
+template <bool BYU16, bool PROF = false>
 __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
-                                                 uint32_t accel, uint32_t *tabw, int lane)
+                                                 uint32_t accel, uint32_t *tabw, int lane, unsigned long long *pc = nullptr)
 {
+    unsigned long long c_probe = 0, c_ext = 0, c_emit = 0, n_seq = 0, n_round = 0, n_dup = 0, n_win = 0;
+    prof_place<PROF>(pc, 8, lane);
+    const unsigned long long t_begin = prof_now<PROF>();
     if ((uint32_t)src_len > (uint32_t)MAX_INPUT_SIZE) return 0;     /* LL64.fast.cs:90 */
     const bool limited = dst_cap < compress_bound(src_len);         /* :524 */
     const int64_t olimit = dst_cap;
@@ -103,7 +113,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
     for (int k = lane; k < 1024; k += 64) ((uint4 *)tabw)[k] = make_uint4(0u, 0u, 0u, 0u);
     wave_sync();
 
-    uint32_t ip = 0, anchor = 0;
+    uint32_t anchor = 0;
     int64_t op = 0;
 
     if (src_len >= MFLIMIT + 1) {                                   /* :117 */
@@ -111,22 +121,25 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
         const uint32_t matchlimit = U - LASTLITERALS;
 
         if (lane == 0) tab.put(FastTable<BYU16>::hash(src), 0);     /* :119-122 */
-        wave_sync();
-        ip = 1;
+        uint32_t ip = 1;
+        bool test = false;   /* true: `ip` is the position right after a match (:393-463) */
 
         for (;;) {
-            uint32_t match = 0;
-            uint32_t token_pos;
-            uint32_t token;
-            bool found = false;
-
-            /* ---- search: LL64.fast.cs:156-234, 64 probes per round ---- */
+            /* ---------------- probe rounds ---------------- */
+            const unsigned long long t0 = prof_now<PROF>();
+            if (test && lane == 0) tab.put(FastTable<BYU16>::hash(src + ip - 2), ip - 2u);   /* :394 */
+            wave_sync();
+            const uint32_t sbase = test ? ip + 1u : ip;             /* where the search loop starts (:466) */
             uint32_t jbase = 0;
+            uint32_t shift = test ? 1u : 0u;                        /* lane 0 of the first round = the test probe */
+            uint32_t match = 0;
+            bool found = false, test_hit = false;
             for (;;) {
-                const uint32_t j = jbase + (uint32_t)lane;
-                const uint32_t pos = ip + probe_offset(j, accel);
-                const uint32_t npos = ip + probe_offset(j + 1u, accel);
-                const bool valid = npos <= mflimit_plus_one && npos >= ip;   /* :172 */
+                const bool is_test = shift != 0u && lane == 0;
+                const uint32_t j = jbase + (uint32_t)lane - (is_test ? 0u : shift);
+                const uint32_t pos = is_test ? ip : sbase + probe_offset(j, accel);
+                const uint32_t npos = sbase + probe_offset(j + 1u, accel);
+                const bool valid = is_test || (npos <= mflimit_plus_one && npos >= sbase);   /* :172 */
                 uint32_t seq = 0, h = 0, cand = 0;
                 if (valid) {
                     seq = ld32u(src + pos);
@@ -137,6 +150,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 const unsigned long long vmask = __ballot(valid);
                 const unsigned long long stop0 = __ballot(hit || !valid);
                 const int W = stop0 ? ctz64(stop0) + 1 : 64;
+                if (PROF) { n_round++; n_win += (unsigned long long)W; }
 
                 /* in-window duplicates: a later lane must see the earlier lane's put */
                 uint32_t pk = 0, rank = 0;
@@ -148,6 +162,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                     }
                 }
                 if (__ballot(pk != 0)) {
+                    if (PROF) n_dup++;
                     const uint32_t ppos = __shfl(pos, lane - (int)pk);
                     if (pk != 0) {
                         cand = ppos;
@@ -159,14 +174,19 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 const bool fvalid = stop ? ((vmask >> f) & 1ull) != 0 : false;
                 const int ncommit = stop ? f + (fvalid ? 1 : 0) : W;
 
-                /* commit puts of lanes < ncommit in lane order (:213) */
+                /* commit puts of lanes < ncommit in lane order (:213, :420) */
                 for (uint32_t r = 0;; r++) {
                     if (!__ballot(lane < ncommit && rank >= r)) break;
                     if (lane < ncommit && rank == r) tab.put(h, pos);
                     wave_sync();
                 }
-                if (!stop) { jbase += (uint32_t)W; continue; }
+                if (!stop) {
+                    jbase += (uint32_t)W - shift;
+                    shift = 0;
+                    continue;
+                }
                 if (!fvalid) break;                                 /* -> _last_literals */
+                test_hit = shift != 0u && f == 0;
                 ip = __shfl(pos, f);
                 match = __shfl(cand, f);
                 found = true;
@@ -174,27 +194,62 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             }
             if (!found) break;
 
-            /* ---- backward extension (:237-242) ---- */
+            /* ---------------- extension: one round trip for both directions + literal bytes ---------------- */
+            const unsigned long long t1 = prof_now<PROF>();
+            const uint32_t lit0 = test_hit ? 0u : ip - anchor;
+            const uint32_t maxback = test_hit ? 0u : (lit0 < match ? lit0 : match);
+            const bool beq = (uint32_t)lane < maxback && src[ip - 1u - (uint32_t)lane] == src[match - 1u - (uint32_t)lane];
+            const uint8_t litbyte = (uint32_t)lane < lit0 && lit0 <= 64u ? src[anchor + (uint32_t)lane] : (uint8_t)0;
+            const uint32_t fwd_max = matchlimit - (ip + MINMATCH);
+            uint32_t neq = 0;
             {
-                const uint32_t maxback = (ip - anchor) < match ? (ip - anchor) : match;
-                uint32_t back = 0;
-                while (back < maxback) {
-                    const uint32_t i = back + (uint32_t)lane;
-                    const bool eq = i < maxback && src[ip - 1u - i] == src[match - 1u - i];
-                    const unsigned long long ne = ~__ballot(eq);
-                    const int run = ne ? ctz64(ne) : 64;
-                    back += (uint32_t)run;
-                    if (run < 64) break;
+                const uint32_t i = 4u * (uint32_t)lane;
+                if (i < fwd_max) {
+                    const uint32_t x = ld32u(src + ip + MINMATCH + i) ^ ld32u(src + match + MINMATCH + i);
+                    const uint32_t avail = fwd_max - i < 4u ? fwd_max - i : 4u;
+                    const uint32_t e = x ? (uint32_t)(__ffs(x) - 1) >> 3 : 4u;
+                    neq = e < avail ? e : avail;
                 }
-                ip -= back;
-                match -= back;
             }
-
-            /* ---- token + literals (:244-272) ---- */
+            /* backward (:237-242) */
+            uint32_t back = 0;
+            if (maxback) {
+                const unsigned long long ne = ~__ballot(beq);
+                back = (uint32_t)(ne ? ctz64(ne) : 64);
+                if (back == 64u) {
+                    while (back < maxback) {
+                        const uint32_t i = back + (uint32_t)lane;
+                        const bool eq = i < maxback && src[ip - 1u - i] == src[match - 1u - i];
+                        const unsigned long long ne2 = ~__ballot(eq);
+                        const int run = ne2 ? ctz64(ne2) : 64;
+                        back += (uint32_t)run;
+                        if (run < 64) break;
+                    }
+                }
+            }
+            /* forward (:326-329); counting from ip+4 of the un-extended position, see header */
+            uint32_t code;
             {
+                const unsigned long long notfull = __ballot(neq != 4u);
+                if (notfull) {
+                    const int fl = ctz64(notfull);
+                    code = 4u * (uint32_t)fl + __shfl(neq, fl);
+                } else {
+                    code = 256u + wave_count(src + ip + MINMATCH + 256u, src + match + MINMATCH + 256u, fwd_max - 256u, lane);
+                }
+            }
+            const uint32_t ip_end = ip + MINMATCH + code;
+            ip -= back;
+            match -= back;
+            code += back;
+
+            const unsigned long long t2 = prof_now<PROF>();
+            /* ---------------- emit (:244-382) ---------------- */
+            uint32_t token_pos = (uint32_t)op;
+            uint32_t token = 0;
+            op++;
+            if (!test_hit) {
                 const uint32_t lit = ip - anchor;
-                token_pos = (uint32_t)op;
-                op++;
                 if (limited && op + lit + (2 + 1 + LASTLITERALS) + lit / 255u > olimit) return 0;
                 if (lit >= (uint32_t)RUN_MASK) {
                     token = (uint32_t)RUN_MASK << ML_BITS;
@@ -202,51 +257,32 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 } else {
                     token = lit << ML_BITS;
                 }
-                wave_copy(dst + op, src + anchor, lit, lane);
+                if (lit0 <= 64u) {
+                    if ((uint32_t)lane < lit) dst[op + lane] = litbyte;
+                } else {
+                    wave_copy(dst + op, src + anchor, lit, lane);
+                }
                 op += lit;
             }
-
-            for (;;) {  /* _next_match */
-                /* offset (:299-304) */
-                if (lane == 0) {
-                    const uint32_t off = ip - match;
-                    dst[op] = (uint8_t)off;
-                    dst[op + 1] = (uint8_t)(off >> 8);
-                }
-                op += 2;
-
-                /* match length (:326-382) */
-                uint32_t code = wave_count(src + ip + MINMATCH, src + match + MINMATCH, matchlimit - (ip + MINMATCH), lane);
-                ip += code + MINMATCH;
-                if (limited && op + (1 + LASTLITERALS) + (code + 240u) / 255u > olimit) return 0;
-                if (code >= (uint32_t)ML_MASK) {
-                    token += ML_MASK;
-                    op = emit_length_run(dst, (uint32_t)op, code - ML_MASK, lane);
-                } else {
-                    token += code;
-                }
-                if (lane == 0) dst[token_pos] = (uint8_t)token;
-                anchor = ip;
-                if (ip >= mflimit_plus_one) break;                  /* :391 */
-
-                /* :394 fill table with ip-2, then :410-463 test position ip */
-                if (lane == 0) tab.put(FastTable<BYU16>::hash(src + ip - 2), ip - 2u);
-                wave_sync();
-                const uint32_t h = FastTable<BYU16>::hash(src + ip);
-                const uint32_t cand = uni(tab.get(h));
-                if (lane == 0) tab.put(h, ip);
-                wave_sync();
-                if ((BYU16 || cand + (uint32_t)DISTANCE_MAX >= ip) && uni(ld32u(src + cand)) == uni(ld32u(src + ip))) {
-                    token_pos = (uint32_t)op;
-                    op++;
-                    token = 0;
-                    match = cand;
-                    continue;
-                }
-                break;
+            if (lane == 0) {                                        /* offset (:299-304) */
+                const uint32_t off = ip - match;
+                dst[op] = (uint8_t)off;
+                dst[op + 1] = (uint8_t)(off >> 8);
             }
-            if (ip >= mflimit_plus_one) break;
-            ip++;                                                   /* :466 */
+            op += 2;
+            if (limited && op + (1 + LASTLITERALS) + (code + 240u) / 255u > olimit) return 0;
+            if (code >= (uint32_t)ML_MASK) {
+                token += ML_MASK;
+                op = emit_length_run(dst, (uint32_t)op, code - ML_MASK, lane);
+            } else {
+                token += code;
+            }
+            if (lane == 0) dst[token_pos] = (uint8_t)token;
+            ip = ip_end;
+            anchor = ip;
+            if (PROF) { const unsigned long long t3 = prof_now<PROF>(); c_probe += t1 - t0; c_ext += t2 - t1; c_emit += t3 - t2; n_seq++; }
+            if (ip >= mflimit_plus_one) break;                      /* :391 */
+            test = true;
         }
     }
 
@@ -264,6 +300,11 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
         wave_copy(dst + op, src + anchor, last_run, lane);
         op += last_run;
     }
+    if (PROF && pc && lane == 0) {
+        pc[0] = prof_now<PROF>() - t_begin; pc[1] = c_probe; pc[2] = c_ext; pc[3] = c_emit;
+        pc[4] = n_seq; pc[5] = n_round; pc[6] = n_dup; pc[7] = n_win;
+    }
+    prof_place<PROF>(pc, 9, lane);
     return (int)op;
 }
 
@@ -295,6 +336,20 @@ __global__ __launch_bounds__(64) void k4_encode_fast_kernel(BatchArgs a)
     uint8_t *dst = a.dst + a.dstOff[b];
     int ret = 0;
     if (src_len > 0 || (a.flags & FLAG_RAW_RETURN)) ret = compress_fast_block(src, src_len, dst, cap < 0 ? 0 : cap, a.accel, tab, lane);
+    if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
+}
+
+/* diagnostic twin (blocks < 65547 B only): per-phase cycle counters (a.prof, 8 per block) */
+__global__ __launch_bounds__(64) void k4_encode_fast_prof_kernel(BatchArgs a)
+{
+    __shared__ uint32_t tab[4096];
+    const int lane = lane_id();
+    const long long b = (long long)blockIdx.x;
+    const int src_len = a.srcLen[b];
+    const int cap = a.dstCap[b];
+    int ret = 0;
+    if (src_len > 0 && src_len < LIMIT_64K)
+        ret = encode_fast_block<true, true>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, 1u, tab, lane, a.prof + PROF_STRIDE * b);
     if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
 }
 

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void k4_pickle_kernel(BatchArgs a)
 __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_unpickle_kernel(BatchArgs a)
 {
     const int lane = lane_id();
-    const long long b = (long long)blockIdx.x * DECODE_WAVES_PER_WG + (long long)(threadIdx.x >> 6);
+    const long long b = (long long)blockIdx.x * DECODE_WAVES_PER_WG + (long long)uni(threadIdx.x >> 6);
     if (b >= a.n) return;
     const int r = unpickle_block(a.src + a.srcOff[b], a.srcLen[b], a.dst + a.dstOff[b], a.dstCap[b], lane);
     if (lane == 0) a.outLen[b] = r;

@@ -121,6 +121,9 @@ static inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t mask, uint32_t add) {
 }
 static inline void __builtin_amdgcn_wave_barrier() { (void)k4emu::wave_exchange(0); }
 #define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_readcyclecounter() 0ull
+#define __builtin_amdgcn_s_memrealtime() 0ull
+#define __builtin_amdgcn_s_getreg(x) 0u
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_s_setprio(n) ((void)0)
 #define __builtin_amdgcn_sched_barrier(n) ((void)0)
