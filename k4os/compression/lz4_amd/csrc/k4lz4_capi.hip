@@ -35,6 +35,7 @@ struct k4lz4_ctx {
     uint8_t *d_dst = nullptr; size_t d_dst_cap = 0;
     uint8_t *d_meta = nullptr; size_t d_meta_cap = 0;
     uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;
+    uint8_t *d_sched = nullptr; size_t d_sched_cap = 0;   /* dispatch-order scratch: cost[n], order[n], counters */
 };
 
 namespace {
@@ -71,6 +72,8 @@ int check_level(k4lz4_ctx *ctx, int level)
     return fail(ctx, K4LZ4_E_UNSUPPORTED, "LZ4Level >= L03_HC is not implemented by the device path yet");
 }
 
+int grow(k4lz4_ctx *ctx, uint8_t **p, size_t *cap, size_t need, bool pinned);
+
 /* enqueue the kernels for n blocks; all pointers are device pointers */
 int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
            const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level, int flags,
@@ -78,13 +81,35 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
 {
     if (n == 0) return K4LZ4_OK;
     const int64_t chunk_max = 1 << 24;   /* blocks per launch (grid.x * blockDim.x must stay < 2^32) */
+    const bool encode_like = kind == KIND_ENCODE || kind == KIND_PICKLE;
+    /* cost-ordered dispatch (most expensive blocks first): encoders by default, decoders on request */
+    const bool reorder = n > 1 &&
+                         (encode_like ? !(flags & K4LZ4_FLAG_NO_REORDER) : (flags & K4LZ4_FLAG_REORDER) != 0);
+    uint32_t *d_cost = nullptr, *d_order = nullptr, *d_hist = nullptr;
+    if (reorder) {
+        const size_t cnt_max = (size_t)std::min<int64_t>(chunk_max, n);
+        const size_t need = cnt_max * 8 + 2 * k4::COST_BUCKETS * 4 + 64;
+        if (need > ctx->d_sched_cap) K4_HIP(ctx, hipStreamSynchronize(stream));   /* scratch may still be in use */
+        int rc = grow(ctx, &ctx->d_sched, &ctx->d_sched_cap, need, false);
+        if (rc != K4LZ4_OK) return rc;
+        d_hist = (uint32_t *)ctx->d_sched;
+        d_cost = d_hist + 2 * k4::COST_BUCKETS;
+        d_order = d_cost + cnt_max;
+    }
     for (int64_t first = 0; first < n; first += chunk_max) {
         const int64_t cnt = std::min<int64_t>(chunk_max, n - first);
-        k4::BatchArgs a;
+        k4::BatchArgs a{};
         a.src = src; a.srcOff = srcOff + first; a.srcLen = srcLen + first;
         a.dst = dst; a.dstOff = dstOff + first; a.dstCap = dstCap + first;
         a.outLen = outLen + first; a.n = cnt; a.level = level; a.accel = ctx->accel; a.flags = flags;
         a.prof = ctx->prof ? ctx->prof + k4::PROF_STRIDE * first : nullptr;
+        if (reorder) {
+            a.cost = d_cost; a.hist = d_hist; a.order_out = d_order;
+            K4_HIP(ctx, hipMemsetAsync(d_hist, 0, 2 * k4::COST_BUCKETS * 4, stream));
+            hipLaunchKernelGGL(k4::k4_cost_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a, encode_like ? 0 : 1);
+            hipLaunchKernelGGL(k4::k4_order_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, a);
+            a.order = d_order;
+        }
         const unsigned wg4 = (unsigned)((cnt + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
         switch (kind) {
         case KIND_ENCODE:
@@ -287,6 +312,7 @@ void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
     if (ctx->d_dst) (void)hipFree(ctx->d_dst);
     if (ctx->d_meta) (void)hipFree(ctx->d_meta);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->d_sched) (void)hipFree(ctx->d_sched);
     delete ctx;
 }
 

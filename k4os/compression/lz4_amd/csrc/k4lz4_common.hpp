@@ -47,6 +47,10 @@ struct BatchArgs {
     int accel;   /* fast encoder acceleration (LZ4Codec always passes 1) */
     int flags;
     unsigned long long *prof;  /* diagnostics: PROF_STRIDE counters per block, or nullptr */
+    const uint32_t *order;     /* dispatch order (block index per workgroup slot), or nullptr */
+    uint32_t *cost;            /* scheduling scratch: cost bucket per block */
+    uint32_t *hist;            /* scheduling scratch: 2 x COST_BUCKETS counters (zeroed) */
+    uint32_t *order_out;       /* scheduling scratch: the order being built */
 };
 
 struct __attribute__((packed, aligned(1))) U16u { uint16_t v; };
@@ -98,6 +102,19 @@ template <bool PROF> __device__ __forceinline__ unsigned long long prof_now()
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int ctz64(unsigned long long m) { return __ffsll(m) - 1; }
+
+/* Inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS):
+ * Hillis-Steele inside each row of 16, then row 15 -> row 1/3 and lane 31 -> rows 2,3. */
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   /* row_shr:1 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   /* row_shr:2 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   /* row_shr:4 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   /* row_shr:8 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  /* row_bcast:15 -> rows 1,3 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  /* row_bcast:31 -> rows 2,3 */
+    return x;
+}
 
 /* LL.tools.cs:38-40 */
 __device__ __forceinline__ int compress_bound(int n)

@@ -8,65 +8,103 @@
  *   LL64.LZ4_decompress_generic Engine/x64/LL64.dec.cs:123-467
  * Accept/reject decisions, the error position and the produced bytes follow that function
  * (including its two-stage shortcut at :191-225, whose relaxed end-of-block rules are observable
- * on malformed input); how the bytes are moved is entirely different:
+ * on malformed input); how the work is organised is entirely different.  A block is decoded in
+ * batches of up to 64 sequences, each batch in three phases:
  *
- *   - The compressed stream is pulled with coalesced dword loads into a 512-byte window that
- *     lives in two VGPRs per lane (InputWindow).  Token / offset / length bytes are picked out of
- *     the window with v_readlane into SGPRs, so the serial parse chain of a block runs on the
- *     scalar unit and never waits on a memory round trip.
- *   - Copies are batched per 64 sequences: every lane moves the literal run / the match of its
- *     own sequence (all loads before the first store: one memory round trip per batch phase, not
- *     per sequence).  Long runs move 16 B per lane (1 KiB per wave instruction) with the whole
- *     wave; overlapping matches (offset < length) read the already-final first period, so no lane
- *     depends on a byte written by the same instruction.
- *   - The match source is the block's own earlier output in HBM/L2; the wave's stores and loads
- *     to it are ordered by program order (wave_sync() pins the compiler).
+ *   PARSE     The compressed stream sits in a 1 KiB per-wave LDS ring that is refilled with
+ *             coalesced dword loads one chunk ahead of use.  Token parsing is speculative and
+ *             lane-parallel: in one round every lane i assumes that a token starts at stream byte
+ *             ip + i and decodes that hypothetical sequence (literal length, offset, match length,
+ *             where the next token would start).  Lane 0's hypothesis is true; following the
+ *             `next` links from lane 0 with v_readlane (a handful of scalar instructions per hop)
+ *             picks out the real sequences among the 64 hypotheses and assigns their output
+ *             positions.  Only sequences that need more than that (15+ literals, multi-byte match
+ *             length, block end, any malformed input) go through the scalar parser, which follows
+ *             the reference line by line.  Each real sequence's (literal position, literal length,
+ *             output position, offset, match length) is compacted into lane k of the batch.
+ *   LITERALS  every lane moves the literal run of its own sequence (all loads before the first
+ *             store: one memory round trip for the whole batch); long runs are moved by the whole
+ *             wave, 16 B per lane.
+ *   MATCHES   a match may only be copied once every earlier match that writes into its source
+ *             range is finished.  Destination ranges are sorted by lane, so each lane finds the
+ *             lane interval it depends on with one binary search per batch; then, round by round,
+ *             all matches without unfinished dependencies copy in parallel.  Overlapping matches
+ *             (offset < length) and long ones are moved by the whole wave; overlapping copies read
+ *             the already-final first period, so no lane depends on a byte of the same instruction.
+ *
+ * The match source is the block's own earlier output in HBM/L2; this wave's stores and later loads
+ * to it are ordered by program order (wave_sync() pins the compiler).
  */
 #pragma once
 #include "k4lz4_common.hpp"
 
 namespace k4 {
 
-struct InputWindow {
+constexpr int RING_DWORDS = 256;                 /* 1 KiB of compressed stream per wave */
+constexpr int DECODE_LDS_DWORDS = RING_DWORDS + 5 * 64;   /* ring + 5 descriptor arrays */
+constexpr uint32_t LANE_COPY_MAX = 32;
+constexpr int MAX_SEQ_PER_ROUND = 22;            /* 64 hypotheses, >= 3 stream bytes per sequence */
+
+struct StreamRing {
+    uint32_t *ring;        /* LDS, RING_DWORDS dwords, slot = dword index & (RING_DWORDS-1) */
     const uint32_t *base;  /* dword-aligned address at or below the first stream byte */
     uint32_t a0;           /* misalignment of the stream start: 0..3 */
     uint32_t ndw;          /* dwords that contain stream bytes */
-    uint32_t wd;           /* dword index held by lane 0 of w0 (multiple of 64) */
-    uint32_t w0, w1;       /* lane l: dwords wd + l and wd + 64 + l (0 beyond the stream) */
+    uint32_t rhi;          /* dwords [rhi - RING_DWORDS, rhi) are in the ring (multiple of 64) */
+    uint32_t pf;           /* lane l: dword rhi + l, loaded ahead of need */
 
     __device__ __forceinline__ uint32_t load(uint32_t dw) const { return dw < ndw ? base[dw] : 0u; }
 
-    __device__ __forceinline__ void init(const uint8_t *in, uint32_t len, int lane)
+    __device__ __forceinline__ void init(uint32_t *lds, const uint8_t *in, uint32_t len, int lane)
     {
+        ring = lds;
         a0 = (uint32_t)((uintptr_t)in & 3u);
         base = (const uint32_t *)(in - a0);
         ndw = (a0 + len + 3u) >> 2;
-        wd = 0;
-        w0 = load((uint32_t)lane);
-        w1 = load(64u + (uint32_t)lane);
+        ring[lane] = load((uint32_t)lane);
+        ring[64 + lane] = load(64u + (uint32_t)lane);
+        rhi = 128u;
+        pf = load(rhi + (uint32_t)lane);
+        wave_sync();
     }
 
-    /* the 4 stream bytes at wave-uniform position p, little endian; bytes past the end read 0 */
+    /* make the ring cover [q, q + 96) (aligned byte positions) and run one chunk ahead */
+    __device__ __forceinline__ void ensure(uint32_t q, int lane)
+    {
+        const uint32_t d = q >> 2;
+        if (d + 24u > rhi + 64u) {               /* jumped past what is loaded or in flight */
+            wave_sync();
+            rhi = d & ~63u;
+            ring[(rhi + (uint32_t)lane) & (RING_DWORDS - 1)] = load(rhi + (uint32_t)lane);
+            ring[(rhi + 64u + (uint32_t)lane) & (RING_DWORDS - 1)] = load(rhi + 64u + (uint32_t)lane);
+            rhi += 128u;
+            pf = load(rhi + (uint32_t)lane);
+            wave_sync();
+            return;
+        }
+        while (rhi < d + 128u && rhi < ndw + 64u) {
+            wave_sync();
+            ring[(rhi + (uint32_t)lane) & (RING_DWORDS - 1)] = pf;
+            rhi += 64u;
+            pf = load(rhi + (uint32_t)lane);
+            wave_sync();
+        }
+    }
+
+    /* 4 stream bytes at aligned byte position q (per lane) */
+    __device__ __forceinline__ uint32_t read4(uint32_t q) const
+    {
+        const uint32_t d = q >> 2;
+        const uint32_t lo = ring[d & (RING_DWORDS - 1)];
+        const uint32_t hi = ring[(d + 1u) & (RING_DWORDS - 1)];
+        return (uint32_t)((((uint64_t)hi << 32) | lo) >> ((q & 3u) * 8u));
+    }
+
+    /* scalar parser: the 4 stream bytes at wave-uniform stream position p */
     __device__ __forceinline__ uint32_t fetch(uint32_t p, int lane)
     {
-        const uint32_t q = p + a0;
-        const uint32_t d = q >> 2;
-        uint32_t rel = d - wd;
-        if (rel >= 64u) {
-            if (rel < 128u) {
-                w0 = w1;
-                wd += 64u;
-            } else {
-                wd = d & ~63u;
-                w0 = load(wd + (uint32_t)lane);
-            }
-            w1 = load(wd + 64u + (uint32_t)lane);
-            rel = d - wd;
-        }
-        const uint32_t lo = __builtin_amdgcn_readlane(w0, (int)rel);
-        const uint32_t hi = rel == 63u ? __builtin_amdgcn_readlane(w1, 0) : __builtin_amdgcn_readlane(w0, (int)rel + 1);
-        const uint64_t v = ((uint64_t)hi << 32) | lo;
-        return (uint32_t)(v >> ((q & 3u) * 8u));
+        ensure(p + a0, lane);
+        return uni(read4(p + a0));
     }
 };
 
@@ -131,25 +169,16 @@ __device__ __forceinline__ void lane_copy32(uint8_t *d, const uint8_t *s, uint32
     }
 }
 
-constexpr uint32_t LANE_COPY_MAX = 32;
-
 /*
  * Decode one block.  Returns what LL64.LZ4_decompress_safe returns: the number of bytes written,
  * or -(input position) - 1 when the stream is malformed (LL64.dec.cs:465).
- *
- * Structure: repeat { PARSE up to 64 sequences on the scalar unit (no memory waits: the stream
- * comes out of the register window) and drop each sequence's (literal position, literal length,
- * output position, offset, match length) into lane k of five VGPRs;  LITERALS: every lane moves
- * its own literal run (one memory round trip for 64 sequences);  MATCHES: lanes whose source lies
- * entirely below the first unfinished match copy in parallel, round by round }.  Long runs and
- * overlapping matches are moved by the whole wave.  All accept/reject decisions depend only on
- * positions and lengths, so they are taken in PARSE exactly in the reference's order.
+ * `lds`: DECODE_LDS_DWORDS dwords of LDS owned by this wave.
  */
 template <bool PROF = false>
 __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uint8_t *out, int out_size, int lane,
-                                        unsigned long long *pc = nullptr)
+                                            uint32_t *lds, unsigned long long *pc = nullptr)
 {
-    unsigned long long c_parse = 0, c_lit = 0, c_match = 0, n_batch = 0, n_round = 0, n_seq = 0, n_coop = 0;
+    unsigned long long c_parse = 0, c_lit = 0, c_match = 0, n_batch = 0, n_round = 0, n_seq = 0, n_slow = 0;
     prof_place<PROF>(pc, 8, lane);
     const unsigned long long t_begin = prof_now<PROF>();
     if (out_size == 0) {                                   /* LL64.dec.cs:162-168 */
@@ -161,8 +190,10 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     }
     if (src_size <= 0) return -1;                          /* :172 */
 
-    InputWindow win;
-    win.init(in, (uint32_t)src_size, lane);
+    StreamRing win;
+    win.init(lds, in, (uint32_t)src_size, lane);
+    uint32_t *d_lpos = lds + RING_DWORDS, *d_llen = d_lpos + 64, *d_out = d_llen + 64, *d_moff = d_out + 64,
+             *d_mlen = d_moff + 64;
 
     const int64_t iend = src_size;
     const int64_t oend = out_size;
@@ -171,13 +202,103 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     int64_t ip = 0, op = 0;
 
     for (;;) {
-        /* ---------------- PARSE ---------------- */
+        /* ======================= PARSE ======================= */
         const unsigned long long t0 = prof_now<PROF>();
-        uint32_t v_lpos = 0, v_llen = 0, v_out = 0, v_moff = 0, v_mlen = 0;
         int nseq = 0;
         int err = 0;
         bool done = false;
-        while (nseq < 64) {
+        while (nseq <= 64 - MAX_SEQ_PER_ROUND && !done) {
+            /* ---- speculative round: 64 hypotheses "a token starts at ip + lane" ---- */
+            const int64_t lim = shortiend - 1 - ip;        /* hypotheses i < lim satisfy ip + i + 1 < shortiend */
+            if (lim > 0 || iend - RUN_MASK - 1 - ip > 0) {
+                win.ensure((uint32_t)ip + win.a0, lane);
+                const uint32_t q = (uint32_t)ip + win.a0 + (uint32_t)lane;
+                const uint32_t t4 = win.read4(q);
+                uint32_t L = (t4 >> 4) & 15u;
+                uint32_t M = t4 & 15u;
+                /* class S: the shortcut (:191-225), literal length in the token.
+                 * class G: 15 + one extension byte of literals -> the general literal path (:228-315) */
+                const bool cls_g = L == RUN_MASK;
+                uint32_t hdr = 1u;                          /* token (+ literal-length extension) bytes */
+                bool fast = cls_g ? (int64_t)lane < iend - RUN_MASK - 1 - ip : (int64_t)lane < lim;
+                if (cls_g) {
+                    const uint32_t ext = (t4 >> 8) & 0xffu;
+                    fast = fast && ext != 255u;
+                    L += ext;
+                    hdr = 2u;
+                    /* the run must leave room for offset + a last sequence (:247) */
+                    fast = fast && (int64_t)ip + lane + hdr + L <= iend - (2 + 1 + LASTLITERALS);
+                }
+                const uint32_t q2 = q + hdr + L;
+                const uint32_t o4 = win.read4(q2);
+                const uint32_t offset = o4 & 0xffffu;
+                /* where the match-length field ends and the next token starts, relative to ip */
+                uint32_t next = (uint32_t)lane + hdr + L + 2u;
+                uint32_t mlen = M + MINMATCH;
+                fast = fast && offset != 0u;
+                const bool general = cls_g || M == ML_MASK || offset < 8u;   /* not the shortcut's match stage */
+                if (M == ML_MASK) {                        /* one extension byte (:326-334) */
+                    const uint32_t ext = (o4 >> 16) & 0xffu;
+                    mlen += ext;
+                    next += 1u;
+                    /* the byte after the extension must stay below iend - LASTLITERALS + 1 */
+                    fast = fast && ext != 255u && (int64_t)ip + next < iend - LASTLITERALS + 1;
+                }
+                const uint32_t outlen = L + mlen;
+                const uint32_t packed = next | (outlen << 10) | (fast ? 0x80000000u : 0u);
+
+                /* follow the true chain from hypothesis 0: one v_readlane per real sequence */
+                unsigned long long T = 0;
+                uint32_t idx = 0;
+                while (idx < 64u) {
+                    const uint32_t pk = __builtin_amdgcn_readlane(packed, (int)idx);
+                    if ((int32_t)pk >= 0) break;
+                    T |= 1ull << idx;
+                    idx = pk & 0x3ffu;
+                }
+                /* output position of every chosen sequence: prefix sum of the chosen lengths */
+                bool in_t = ((T >> lane) & 1ull) != 0;
+                const uint32_t incl = wave_inclusive_scan(in_t ? outlen : 0u);
+                const int64_t v_o64 = op + (int64_t)(incl - (in_t ? outlen : 0u));
+                const uint32_t v_o = (uint32_t)v_o64;
+                /* position-dependent rules on the chosen sequences: the shortcut needs
+                 * op <= shortoend (:191), a 15+ literal run cpy <= oend - MFLIMIT (:247); the offset
+                 * must stay inside the output (:338); sequences
+                 * that left the shortcut also obey the end-of-block rule (:427-433).  The first
+                 * sequence that fails, and everything after it, is left to the scalar parser. */
+                const int64_t mdst_l = v_o64 + L;
+                const unsigned long long bad =
+                    __ballot(in_t && ((cls_g ? mdst_l > oend - MFLIMIT : v_o64 > shortoend) || (int64_t)offset > mdst_l ||
+                                      (general && mdst_l + (int64_t)mlen > oend - MATCH_SAFEGUARD)));
+                int64_t cur_op;
+                if (bad) {
+                    const int b = ctz64(bad);
+                    T &= (1ull << b) - 1ull;
+                    idx = (uint32_t)b;
+                    cur_op = op + (int64_t)(__builtin_amdgcn_readlane(incl, b) - __builtin_amdgcn_readlane(outlen, b));
+                    in_t = ((T >> lane) & 1ull) != 0;
+                } else {
+                    cur_op = op + (int64_t)__builtin_amdgcn_readlane(incl, 63);
+                }
+                if (T) {
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(T >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)T, 0u));
+                    if (in_t) {
+                        const uint32_t slot = (uint32_t)nseq + below;
+                        d_lpos[slot] = (uint32_t)ip + (uint32_t)lane + hdr;
+                        d_llen[slot] = L;
+                        d_out[slot] = v_o;
+                        d_moff[slot] = offset;
+                        d_mlen[slot] = mlen;
+                    }
+                    nseq += __popcll(T);
+                    ip += idx;
+                    op = cur_op;
+                    continue;
+                }
+            }
+
+            /* ---- scalar parser: one sequence, the reference's order of checks ---- */
+            if (PROF) n_slow++;
             uint32_t w = win.fetch((uint32_t)ip, lane);
             const uint32_t token = w & 0xffu;
             ip++;
@@ -249,19 +370,25 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 s_mlen = offset != 0u ? length : 0u;           /* offset 0 (hostile): output left as is */
                 adv = length;
             }
-            if (lane == nseq) {   /* drop the sequence into lane `nseq` */
-                v_lpos = s_lpos; v_llen = s_llen; v_out = s_out; v_moff = s_moff; v_mlen = s_mlen;
+            if (lane == 0) {
+                d_lpos[nseq] = s_lpos; d_llen[nseq] = s_llen; d_out[nseq] = s_out; d_moff[nseq] = s_moff; d_mlen[nseq] = s_mlen;
             }
             nseq++;
             op += adv;
-            if (last) { done = true; break; }
+            if (last) done = true;
         }
         if (err) return err;
+        wave_sync();
+        const bool mine = lane < nseq;
+        const uint32_t v_lpos = mine ? d_lpos[lane] : 0u;
+        const uint32_t v_llen = mine ? d_llen[lane] : 0u;
+        const uint32_t v_out = mine ? d_out[lane] : 0u;
+        const uint32_t v_moff = mine ? d_moff[lane] : 0u;
+        const uint32_t v_mlen = mine ? d_mlen[lane] : 0u;
         const unsigned long long t1 = prof_now<PROF>();
 
-        /* ---------------- LITERALS ---------------- */
+        /* ======================= LITERALS ======================= */
         {
-            const bool mine = lane < nseq;
             if (mine && v_llen != 0u && v_llen <= LANE_COPY_MAX)
                 lane_copy32(out + v_out, in + v_lpos, v_llen, (uint32_t)src_size - v_lpos);
             unsigned long long big = __ballot(mine && v_llen > LANE_COPY_MAX);
@@ -272,37 +399,47 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                           __builtin_amdgcn_readlane(v_llen, f), lane);
             }
         }
-
         const unsigned long long t2 = prof_now<PROF>();
-        /* ---------------- MATCHES ---------------- */
+
+        /* ======================= MATCHES ======================= */
         {
+            const bool has = mine && v_mlen != 0u;
             const uint32_t mdst = v_out + v_llen;
+            const uint32_t mend = mdst + v_mlen;
             const uint32_t msrc = mdst - v_moff;
-            unsigned long long pend = __ballot(lane < nseq && v_mlen != 0u);
+            const uint32_t send = msrc + v_mlen < mdst ? msrc + v_mlen : mdst;   /* source bytes below own output */
+            /* destination ranges sorted by lane: publish [mdst, mend) (sentinel for idle lanes) */
+            wave_sync();
+            d_out[lane] = mine ? mdst : 0xffffffffu;
+            d_llen[lane] = mine ? mend : 0xffffffffu;
+            wave_sync();
+            /* first lane whose match ends above msrc, first lane whose match starts at/after send */
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (uint32_t step = 32; step != 0; step >>= 1) {
+                if (d_llen[lo + step - 1u] <= msrc) lo += step;
+                if (d_out[hi + step - 1u] < send) hi += step;
+            }
+            /* dependencies: lanes [lo, hi) below this lane */
+            const uint32_t hi_c = hi < (uint32_t)lane ? hi : (uint32_t)lane;
+            unsigned long long deps = 0;
+            if (has && lo < hi_c) deps = ((hi_c >= 64u ? 0ull : (1ull << hi_c)) - 1ull) & ~((1ull << lo) - 1ull);
+            const bool coop = v_mlen > LANE_COPY_MAX || v_moff < v_mlen;
+            unsigned long long pend = __ballot(has);
             while (pend) {
-                const int f = ctz64(pend);
-                const uint32_t F = __builtin_amdgcn_readlane(mdst, f);
-                const uint32_t f_len = __builtin_amdgcn_readlane(v_mlen, f);
-                const uint32_t f_off = __builtin_amdgcn_readlane(v_moff, f);
-                const bool f_coop = f_len > LANE_COPY_MAX || f_off < f_len;
-                if (PROF) { n_round++; n_coop += f_coop ? 1 : 0; }
-                if (f_coop) wave_match_copy(out, F, f_off, f_len, lane);   /* includes the wave_sync */
-                else wave_sync();
-                const bool pending = ((pend >> lane) & 1ull) != 0;
-                const bool ready = pending && lane != f && msrc + v_mlen <= F;
-                const bool go = ready || (lane == f && !f_coop);
-                if (go && v_mlen <= LANE_COPY_MAX)
-                    lane_copy32(out + mdst, out + msrc, v_mlen, (uint32_t)out_size - msrc);
-                unsigned long long big = __ballot(ready && v_mlen > LANE_COPY_MAX);
-                const unsigned long long gone = __ballot(go) | (1ull << f);
+                if (PROF) n_round++;
+                const bool ready = ((pend >> lane) & 1ull) != 0 && (deps & pend) == 0;
+                const unsigned long long rmask = __ballot(ready);
+                wave_sync();
+                if (ready && !coop) lane_copy32(out + mdst, out + msrc, v_mlen, (uint32_t)out_size - msrc);
+                unsigned long long big = __ballot(ready && coop);
                 while (big) {
                     const int g = ctz64(big);
                     big &= big - 1;
-                    const uint32_t g_dst = __builtin_amdgcn_readlane(mdst, g);
-                    const uint32_t g_len = __builtin_amdgcn_readlane(v_mlen, g);
-                    wave_copy(out + g_dst, out + g_dst - __builtin_amdgcn_readlane(v_moff, g), g_len, lane);
+                    wave_match_copy(out, __builtin_amdgcn_readlane(mdst, g), __builtin_amdgcn_readlane(v_moff, g),
+                                    __builtin_amdgcn_readlane(v_mlen, g), lane);
                 }
-                pend &= ~gone;
+                pend &= ~rmask;
             }
             wave_sync();
         }
@@ -314,7 +451,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     }
     if (PROF && pc && lane == 0) {
         pc[0] = prof_now<PROF>() - t_begin; pc[1] = c_parse; pc[2] = c_lit; pc[3] = c_match;
-        pc[4] = n_batch; pc[5] = n_round; pc[6] = n_seq; pc[7] = n_coop;
+        pc[4] = n_batch; pc[5] = n_round; pc[6] = n_seq; pc[7] = n_slow;
     }
     prof_place<PROF>(pc, 9, lane);
     return (int)op;
@@ -332,28 +469,32 @@ constexpr int DECODE_WAVES_PER_WG = 4;
 
 __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_decode_kernel(BatchArgs a)
 {
+    __shared__ uint32_t lds[DECODE_WAVES_PER_WG][DECODE_LDS_DWORDS];
     const int lane = lane_id();
-    const long long b = (long long)blockIdx.x * DECODE_WAVES_PER_WG + (long long)uni(threadIdx.x >> 6);
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const long long b = (long long)blockIdx.x * DECODE_WAVES_PER_WG + (long long)wave;
     if (b >= a.n) return;
     const int src_len = a.srcLen[b];
     const int cap = a.dstCap[b];
     const uint8_t *in = a.src + a.srcOff[b];
     uint8_t *out = a.dst + a.dstOff[b];
     int ret = 0;
-    if (src_len > 0 || (a.flags & FLAG_RAW_RETURN)) ret = decode_block(in, src_len, out, cap < 0 ? 0 : cap, lane);
+    if (src_len > 0 || (a.flags & FLAG_RAW_RETURN)) ret = decode_block(in, src_len, out, cap < 0 ? 0 : cap, lane, lds[wave]);
     if (lane == 0) a.outLen[b] = codec_decode_result(src_len, ret, a.flags);
 }
 
-/* diagnostic twin: same decode with per-phase cycle counters (a.prof, 8 per block) */
+/* diagnostic twin: same decode with per-phase cycle counters (a.prof, PROF_STRIDE per block) */
 __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_decode_prof_kernel(BatchArgs a)
 {
+    __shared__ uint32_t lds[DECODE_WAVES_PER_WG][DECODE_LDS_DWORDS];
     const int lane = lane_id();
-    const long long b = (long long)blockIdx.x * DECODE_WAVES_PER_WG + (long long)uni(threadIdx.x >> 6);
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const long long b = (long long)blockIdx.x * DECODE_WAVES_PER_WG + (long long)wave;
     if (b >= a.n) return;
     const int src_len = a.srcLen[b];
     const int cap = a.dstCap[b];
     int ret = 0;
-    if (src_len > 0) ret = decode_block<true>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, lane, a.prof + PROF_STRIDE * b);
+    if (src_len > 0) ret = decode_block<true>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, lane, lds[wave], a.prof + PROF_STRIDE * b);
     if (lane == 0) a.outLen[b] = codec_decode_result(src_len, ret, a.flags);
 }
 

@@ -105,7 +105,7 @@ __device__ __forceinline__ PickleHeader unpickle_header(const uint8_t *src, int 
 
 /* Unpickle(source, output): returns the unpickled size (== cap), 0 for an empty pickle,
  * -1 where the reference throws (unpickle.cs:115-128,:134,:143-144) */
-__device__ __forceinline__ int unpickle_block(const uint8_t *src, int len, uint8_t *dst, int cap, int lane)
+__device__ __forceinline__ int unpickle_block(const uint8_t *src, int len, uint8_t *dst, int cap, int lane, uint32_t *lds)
 {
     if (len == 0) return 0;
     const PickleHeader h = unpickle_header(src, len);
@@ -118,7 +118,7 @@ __device__ __forceinline__ int unpickle_block(const uint8_t *src, int len, uint8
     }
     int decoded = 0;                                        /* LZ4Codec.Decode: empty -> 0 */
     if (data_len > 0) {
-        decoded = decode_block(src + h.data_offset, data_len, dst, cap, lane);
+        decoded = decode_block(src + h.data_offset, data_len, dst, cap, lane, lds);
         if (decoded <= 0) decoded = -1;
     }
     return decoded == h.result_len ? decoded : -1;
@@ -126,9 +126,9 @@ __device__ __forceinline__ int unpickle_block(const uint8_t *src, int len, uint8
 
 __global__ __launch_bounds__(64) void k4_pickle_kernel(BatchArgs a)
 {
-    __shared__ uint32_t tab[4096];
+    __shared__ __attribute__((aligned(16))) uint32_t tab[ENCODE_LDS_DWORDS];
     const int lane = lane_id();
-    const long long b = (long long)blockIdx.x;
+    const long long b = a.order ? (long long)a.order[blockIdx.x] : (long long)blockIdx.x;
     const int r = pickle_block(a.src + a.srcOff[b], a.srcLen[b], a.dst + a.dstOff[b], a.dstCap[b], a.level,
                                a.flags, tab, lane);
     if (lane == 0) a.outLen[b] = r;
@@ -136,10 +136,12 @@ __global__ __launch_bounds__(64) void k4_pickle_kernel(BatchArgs a)
 
 __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_unpickle_kernel(BatchArgs a)
 {
+    __shared__ uint32_t lds[DECODE_WAVES_PER_WG][DECODE_LDS_DWORDS];
     const int lane = lane_id();
-    const long long b = (long long)blockIdx.x * DECODE_WAVES_PER_WG + (long long)uni(threadIdx.x >> 6);
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const long long b = (long long)blockIdx.x * DECODE_WAVES_PER_WG + (long long)wave;
     if (b >= a.n) return;
-    const int r = unpickle_block(a.src + a.srcOff[b], a.srcLen[b], a.dst + a.dstOff[b], a.dstCap[b], lane);
+    const int r = unpickle_block(a.src + a.srcOff[b], a.srcLen[b], a.dst + a.dstOff[b], a.dstCap[b], lane, lds[wave]);
     if (lane == 0) a.outLen[b] = r;
 }
 

@@ -48,12 +48,18 @@ for decode in (False, True):
         print("%-8s " % name + " ".join("%10.0f" % v for v in m[:8]) + "   %.3f" % (cl[idx].mean() / bs))
     m = c.mean(axis=0)
     print("%-8s " % "ALL" + " ".join("%10.0f" % v for v in m[:8]))
+    if not decode:
+        d = c[np.arange(0, n, 12)].mean(axis=0)
+        print("dickens probe stages per sequence: s1(src loads+put) %.0f  s2(hash+table) %.0f  s3(cand loads+cmp) %.0f  s4(dedup+commit) %.0f" % tuple(d[11:15] / d[4]))
+        print("ALL     probe stages per sequence: s1 %.0f s2 %.0f s3 %.0f s4 %.0f" % tuple(m[11:15] / m[4]))
     st, en = c[:, 8], c[:, 9]
     ev = sorted([(t, 1) for t in st] + [(t, -1) for t in en])
     cur = mx = 0
     for _, d in ev:
         cur += d; mx = max(mx, cur)
     print("max concurrent waves", mx, "span ms", (en.max() - st.min()) / 1e5, "mean block ms", (en - st).mean() / 1e5)
+    t00 = st.min()
+    print("class start/end ms: " + " ".join("%s %.1f/%.1f" % (nm[:4], (st[np.arange(ci, n, 12)].mean() - t00) / 1e5, (en[np.arange(ci, n, 12)].mean() - t00) / 1e5) for ci, nm in enumerate(names)))
     hw = c[:, 10].astype(np.int64)
     print("distinct HW_ID (cu/sh/se) values", len(set((hw >> 8) & 0xffff)))
     print("max total cycles", c[:, 0].max(), "-> ms at 2.4GHz", c[:, 0].max() / 2.4e6)

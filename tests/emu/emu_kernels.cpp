@@ -11,7 +11,7 @@ int k4emu_decode_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t
                        const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int flags,
                        int threads)
 {
-    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, 0, 1, flags, nullptr};
+    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, 0, 1, flags, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n <= 0) return 0;
     unsigned grid = (unsigned)((n + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
     k4emu::launch_fn(dim3(grid), dim3(64 * k4::DECODE_WAVES_PER_WG), [=] { k4::k4_decode_kernel(a); }, threads);
@@ -22,9 +22,22 @@ int k4emu_encode_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t
                        const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int level,
                        int accel, int flags, int threads)
 {
-    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, accel, flags, nullptr};
+    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, accel, flags, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n <= 0) return 0;
     k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_encode_fast_kernel(a); }, threads);
+    return 0;
+}
+
+/* dispatch-order kernels: cost estimate (dry encoder run over a sample, or by length) + bucket order */
+int k4emu_order(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, long long n, int by_length,
+                uint32_t *cost, uint32_t *hist, uint32_t *order, int threads)
+{
+    k4::BatchArgs a{};
+    a.src = src; a.srcOff = srcOff; a.srcLen = srcLen; a.n = n; a.accel = 1;
+    a.cost = cost; a.hist = hist; a.order_out = order;
+    if (n <= 0) return 0;
+    k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_cost_kernel(a, by_length); }, threads);
+    k4emu::launch_fn(dim3((unsigned)((n + 255) / 256)), dim3(256), [=] { k4::k4_order_kernel(a); }, 1);
     return 0;
 }
 
@@ -32,7 +45,7 @@ int k4emu_pickle_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t
                        const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int level,
                        int flags, int threads)
 {
-    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, 1, flags, nullptr};
+    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, 1, flags, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n <= 0) return 0;
     k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_pickle_kernel(a); }, threads);
     return 0;
@@ -42,7 +55,7 @@ int k4emu_unpickle_batch(const uint8_t *src, const uint64_t *srcOff, const int32
                          const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int flags,
                          int threads)
 {
-    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, 0, 1, flags, nullptr};
+    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, 0, 1, flags, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n <= 0) return 0;
     unsigned grid = (unsigned)((n + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
     k4emu::launch_fn(dim3(grid), dim3(64 * k4::DECODE_WAVES_PER_WG), [=] { k4::k4_unpickle_kernel(a); }, threads);
@@ -52,7 +65,7 @@ int k4emu_unpickle_batch(const uint8_t *src, const uint64_t *srcOff, const int32
 int k4emu_unpickle_sizes(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, int32_t *outLen,
                          long long n, int threads)
 {
-    k4::BatchArgs a{src, srcOff, srcLen, nullptr, nullptr, nullptr, outLen, n, 0, 1, 0, nullptr};
+    k4::BatchArgs a{src, srcOff, srcLen, nullptr, nullptr, nullptr, outLen, n, 0, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n <= 0) return 0;
     k4emu::launch_fn(dim3((unsigned)((n + 255) / 256)), dim3(256), [=] { k4::k4_unpickle_sizes_kernel(a); }, threads);
     return 0;

@@ -119,6 +119,27 @@ static inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t mask, uint32_t add) {
     uint32_t below = l <= 32 ? 0u : ((1u << (l - 32)) - 1u);
     return add + (uint32_t)__builtin_popcount(mask & below);
 }
+/* v_mov_b32 with a DPP control word: the subset the kernels use (row_shr:1..15, row_bcast:15/31) */
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+{
+    const uint64_t *v = k4emu::wave_exchange((uint64_t)(uint32_t)src);
+    const int l = k4emu::lane_id();
+    const int row = l >> 4, bank = (l & 15) >> 2;
+    if (!((row_mask >> row) & 1) || !((bank_mask >> bank) & 1)) return old;
+    int srcl = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11f) {
+        const int n = ctrl - 0x110;
+        if ((l & 15) >= n) srcl = l - n;
+    } else if (ctrl == 0x142) {
+        if (row >= 1) srcl = row * 16 - 1;
+    } else if (ctrl == 0x143) {
+        if (row >= 2) srcl = 31;
+    } else {
+        __builtin_trap();
+    }
+    if (srcl < 0) return bound_ctrl ? 0 : old;
+    return (int)(uint32_t)v[srcl];
+}
 static inline void __builtin_amdgcn_wave_barrier() { (void)k4emu::wave_exchange(0); }
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_readcyclecounter() 0ull

@@ -51,6 +51,7 @@ class Emu:
         b = [_u8p, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
         self.lib.k4emu_decode_batch.argtypes = b + [C.c_int, C.c_int]
         self.lib.k4emu_encode_batch.argtypes = b + [C.c_int, C.c_int, C.c_int, C.c_int]
+        self.lib.k4emu_order.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         self.lib.k4emu_pickle_batch.argtypes = b + [C.c_int, C.c_int, C.c_int]
         self.lib.k4emu_unpickle_batch.argtypes = b + [C.c_int, C.c_int]
         self.lib.k4emu_unpickle_sizes.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int]
@@ -97,3 +98,11 @@ class Emu:
                                            out.ctypes.data, len(src_len), threads)
         assert rc == 0
         return out
+
+    def order(self, src, src_off, src_len, by_length=0, threads=0):
+        n = len(src_len)
+        cost = np.zeros(n, np.uint32); hist = np.zeros(128, np.uint32); order = np.full(n, 0xFFFFFFFF, np.uint32)
+        rc = self.lib.k4emu_order(self._p(src), src_off.ctypes.data, src_len.ctypes.data, n, by_length,
+                                  cost.ctypes.data, hist.ctypes.data, order.ctypes.data, threads)
+        assert rc == 0
+        return cost, order

@@ -222,3 +222,70 @@ def test_unpickle_corruption(emu, oracle):
             assert uout[i] == -1
         else:
             assert uout[i] == len(want) and udst[int(uoff[i]):int(uoff[i]) + len(want)].tobytes() == want
+
+
+def test_decode_all_classes_various_sizes(emu, oracle):
+    """speculative parse rounds + scalar fallbacks on every data class, 4 KiB .. 64 KiB blocks,
+    odd source alignments (the packed buffer puts blocks at arbitrary byte offsets)"""
+    rng = np.random.default_rng(41)
+    blocks = []
+    for i, name in enumerate(corpus.SILESIA_NAMES):
+        data = corpus.class_bytes(name, 200000, 13)
+        for size in (65536, 4096, 4097, int(rng.integers(100, 30000))):
+            start = int(rng.integers(0, data.size - size))
+            blocks.append(data[start:start + size])
+    comp = [np.frombuffer(oracle.encode(b), np.uint8) for b in blocks]
+    src, soff, slen = pack(comp)
+    dst, doff, dcap = arena([b.size for b in blocks])
+    out = emu.decode_batch(src, soff, slen, dst, doff, dcap)
+    for i, b in enumerate(blocks):
+        assert out[i] == b.size, i
+        assert dst[int(doff[i]):int(doff[i]) + b.size].tobytes() == b.tobytes(), i
+    mask = np.ones(dst.size, bool)
+    for i, b in enumerate(blocks):
+        mask[int(doff[i]):int(doff[i]) + b.size] = False
+    assert (dst[mask] == 0xCD).all()
+
+
+def test_decode_hostile_streams_random(emu, oracle):
+    """random byte soup and heavy mutations: identical LLxx returns, no write outside the slot"""
+    rng = np.random.default_rng(43)
+    comps, caps = [], []
+    good = np.frombuffer(oracle.encode(corpus.class_bytes("xml", 20000, 1)), np.uint8)
+    for t in range(300):
+        if t % 3 == 0:
+            c = rng.integers(0, 256, int(rng.integers(1, 400)), dtype=np.uint8)
+        else:
+            c = good[:int(rng.integers(20, good.size))].copy()
+            for _ in range(int(rng.integers(1, 30))):
+                c[rng.integers(0, c.size)] = rng.integers(0, 256)
+        comps.append(c)
+        caps.append(int(rng.integers(0, 25000)))
+    src, soff, slen = pack(comps)
+    dst, doff, dcap = arena(caps)
+    out = emu.decode_batch(src, soff, slen, dst, doff, dcap, flags=FLAG_RAW)
+    for i, (c, cap) in enumerate(zip(comps, caps)):
+        n, ref = oracle.decompress_safe(c, cap)
+        assert out[i] == n, f"stream {i}: kernel {out[i]} oracle {n}"
+        if n > 0:
+            assert dst[int(doff[i]):int(doff[i]) + n].tobytes() == ref[:n].tobytes()
+        assert (dst[int(doff[i]) + cap:int(doff[i]) + cap + 16] == 0xCD).all()
+        assert (dst[int(doff[i]) - 16:int(doff[i])] == 0xCD).all()
+
+
+def test_dispatch_order_is_a_permutation_by_cost(emu):
+    """the scheduling kernels: a dry encoder run over a sample estimates cost (never touches dst --
+    it is given a null output), blocks are ordered most-expensive-bucket first"""
+    blocks = [corpus.class_bytes(name, 20000, 3) for name in corpus.SILESIA_NAMES]
+    blocks += [corpus.random_bytes(20000, 5), corpus.lorem(50), np.zeros(0, np.uint8), corpus.lorem(300000)]
+    src, soff, slen = pack(blocks)
+    cost, order = emu.order(src, soff, slen)
+    assert sorted(order.tolist()) == list(range(len(blocks)))
+    assert (np.diff(cost[order].astype(np.int64)) <= 0).all()      # non-increasing cost buckets
+    names = list(corpus.SILESIA_NAMES)
+    # text-like classes (many short sequences) rank above incompressible ones of the same size
+    assert cost[names.index("dickens")] > cost[names.index("x-ray")]
+    assert cost[len(blocks) - 1] == cost.max()                       # the 300 KB block is the most expensive
+    cost_l, order_l = emu.order(src, soff, slen, by_length=1)
+    assert sorted(order_l.tolist()) == list(range(len(blocks)))
+    assert (np.diff(slen[order_l].astype(np.int64) // 1) <= 0).all() or (np.diff(cost_l[order_l].astype(np.int64)) <= 0).all()
