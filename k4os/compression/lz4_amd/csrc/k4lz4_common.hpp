@@ -141,4 +141,89 @@ __device__ __forceinline__ void wave_fill(uint8_t *d, uint8_t b, uint32_t n, int
     for (uint32_t k = (uint32_t)lane; k < n; k += 64) d[k] = b;
 }
 
+/*
+ * A sliding window over a byte stream in global memory, kept in a per-wave LDS ring and refilled
+ * with coalesced dword loads one 256-byte chunk ahead of use.  Used for the compressed stream in
+ * the decoder and for the source bytes around the cursor in the encoder: lanes can then read any
+ * byte position near the cursor at LDS latency instead of issuing 64 unaligned global requests.
+ */
+constexpr int RING_DWORDS = 256;                 /* 1 KiB of stream per wave */
+struct StreamRing {
+    uint32_t *ring;        /* LDS, RING_DWORDS dwords, slot = dword index & (RING_DWORDS-1) */
+    const uint32_t *base;  /* dword-aligned address at or below the first stream byte */
+    uint32_t a0;           /* misalignment of the stream start: 0..3 */
+    uint32_t ndw;          /* dwords that contain stream bytes */
+    uint32_t rlo, rhi;     /* dwords [rlo, rhi) are in the ring (rhi multiple of 64, rhi - rlo <= RING_DWORDS) */
+    uint32_t pf;           /* lane l: dword rhi + l, loaded ahead of need */
+
+    __device__ __forceinline__ uint32_t load(uint32_t dw) const { return dw < ndw ? base[dw] : 0u; }
+
+    __device__ __forceinline__ void init(uint32_t *lds, const uint8_t *in, uint32_t len, int lane)
+    {
+        ring = lds;
+        a0 = (uint32_t)((uintptr_t)in & 3u);
+        base = (const uint32_t *)(in - a0);
+        ndw = (a0 + len + 3u) >> 2;
+        ring[lane] = load((uint32_t)lane);
+        ring[64 + lane] = load(64u + (uint32_t)lane);
+        rlo = 0u;
+        rhi = 128u;
+        pf = load(rhi + (uint32_t)lane);
+        wave_sync();
+    }
+
+    /* make the ring cover [q, q + 96) (aligned byte positions) and run one chunk ahead */
+    __device__ __forceinline__ void ensure(uint32_t q, int lane)
+    {
+        const uint32_t d = q >> 2;
+        if (d + 24u > rhi + 64u) {               /* jumped past what is loaded or in flight */
+            wave_sync();
+            rhi = d & ~63u;
+            rlo = rhi;
+            ring[(rhi + (uint32_t)lane) & (RING_DWORDS - 1)] = load(rhi + (uint32_t)lane);
+            ring[(rhi + 64u + (uint32_t)lane) & (RING_DWORDS - 1)] = load(rhi + 64u + (uint32_t)lane);
+            rhi += 128u;
+            pf = load(rhi + (uint32_t)lane);
+            wave_sync();
+            return;
+        }
+        while (rhi < d + 128u && rhi < ndw + 64u) {
+            wave_sync();
+            ring[(rhi + (uint32_t)lane) & (RING_DWORDS - 1)] = pf;
+            rhi += 64u;
+            if (rhi - rlo > (uint32_t)RING_DWORDS) rlo = rhi - (uint32_t)RING_DWORDS;
+            pf = load(rhi + (uint32_t)lane);
+            wave_sync();
+        }
+    }
+
+    /* encoder use: keep [qlo, q + 512) readable where the stream has it; after a far jump the ring
+     * restarts at qlo.  Aligned byte positions. */
+    __device__ __forceinline__ void ensure_from(uint32_t qlo, uint32_t q, int lane)
+    {
+        const uint32_t d = q >> 2;
+        if (d + 24u > rhi + 64u || (qlo >> 2) < rlo) ensure(qlo, lane);   /* restart at qlo (or no-op) */
+        ensure(q, lane);
+    }
+    /* first / one-past-last aligned byte position readable */
+    __device__ __forceinline__ uint32_t lo_byte() const { return rlo << 2; }
+    __device__ __forceinline__ uint32_t hi_byte() const { return rhi << 2; }
+
+    /* 4 stream bytes at aligned byte position q (per lane) */
+    __device__ __forceinline__ uint32_t read4(uint32_t q) const
+    {
+        const uint32_t d = q >> 2;
+        const uint32_t lo = ring[d & (RING_DWORDS - 1)];
+        const uint32_t hi = ring[(d + 1u) & (RING_DWORDS - 1)];
+        return (uint32_t)((((uint64_t)hi << 32) | lo) >> ((q & 3u) * 8u));
+    }
+
+    /* scalar parser: the 4 stream bytes at wave-uniform stream position p */
+    __device__ __forceinline__ uint32_t fetch(uint32_t p, int lane)
+    {
+        ensure(p + a0, lane);
+        return uni(read4(p + a0));
+    }
+};
+
 }  // namespace k4

@@ -40,73 +40,9 @@
 
 namespace k4 {
 
-constexpr int RING_DWORDS = 256;                 /* 1 KiB of compressed stream per wave */
 constexpr int DECODE_LDS_DWORDS = RING_DWORDS + 5 * 64;   /* ring + 5 descriptor arrays */
 constexpr uint32_t LANE_COPY_MAX = 32;
 constexpr int MAX_SEQ_PER_ROUND = 22;            /* 64 hypotheses, >= 3 stream bytes per sequence */
-
-struct StreamRing {
-    uint32_t *ring;        /* LDS, RING_DWORDS dwords, slot = dword index & (RING_DWORDS-1) */
-    const uint32_t *base;  /* dword-aligned address at or below the first stream byte */
-    uint32_t a0;           /* misalignment of the stream start: 0..3 */
-    uint32_t ndw;          /* dwords that contain stream bytes */
-    uint32_t rhi;          /* dwords [rhi - RING_DWORDS, rhi) are in the ring (multiple of 64) */
-    uint32_t pf;           /* lane l: dword rhi + l, loaded ahead of need */
-
-    __device__ __forceinline__ uint32_t load(uint32_t dw) const { return dw < ndw ? base[dw] : 0u; }
-
-    __device__ __forceinline__ void init(uint32_t *lds, const uint8_t *in, uint32_t len, int lane)
-    {
-        ring = lds;
-        a0 = (uint32_t)((uintptr_t)in & 3u);
-        base = (const uint32_t *)(in - a0);
-        ndw = (a0 + len + 3u) >> 2;
-        ring[lane] = load((uint32_t)lane);
-        ring[64 + lane] = load(64u + (uint32_t)lane);
-        rhi = 128u;
-        pf = load(rhi + (uint32_t)lane);
-        wave_sync();
-    }
-
-    /* make the ring cover [q, q + 96) (aligned byte positions) and run one chunk ahead */
-    __device__ __forceinline__ void ensure(uint32_t q, int lane)
-    {
-        const uint32_t d = q >> 2;
-        if (d + 24u > rhi + 64u) {               /* jumped past what is loaded or in flight */
-            wave_sync();
-            rhi = d & ~63u;
-            ring[(rhi + (uint32_t)lane) & (RING_DWORDS - 1)] = load(rhi + (uint32_t)lane);
-            ring[(rhi + 64u + (uint32_t)lane) & (RING_DWORDS - 1)] = load(rhi + 64u + (uint32_t)lane);
-            rhi += 128u;
-            pf = load(rhi + (uint32_t)lane);
-            wave_sync();
-            return;
-        }
-        while (rhi < d + 128u && rhi < ndw + 64u) {
-            wave_sync();
-            ring[(rhi + (uint32_t)lane) & (RING_DWORDS - 1)] = pf;
-            rhi += 64u;
-            pf = load(rhi + (uint32_t)lane);
-            wave_sync();
-        }
-    }
-
-    /* 4 stream bytes at aligned byte position q (per lane) */
-    __device__ __forceinline__ uint32_t read4(uint32_t q) const
-    {
-        const uint32_t d = q >> 2;
-        const uint32_t lo = ring[d & (RING_DWORDS - 1)];
-        const uint32_t hi = ring[(d + 1u) & (RING_DWORDS - 1)];
-        return (uint32_t)((((uint64_t)hi << 32) | lo) >> ((q & 3u) * 8u));
-    }
-
-    /* scalar parser: the 4 stream bytes at wave-uniform stream position p */
-    __device__ __forceinline__ uint32_t fetch(uint32_t p, int lane)
-    {
-        ensure(p + a0, lane);
-        return uni(read4(p + a0));
-    }
-};
 
 /* Match copy inside the output block: out[op + i] = out[op - offset + i] with the byte-serial
  * (replicating) semantics of LL64.dec.cs:408-450.  offset >= 1. */
