@@ -132,3 +132,45 @@ def test_decode_malformed_matches_reference_rules(oracle, syslz4):
         if n >= 0:
             assert n == n2 and out[:n].tobytes() == out2[:n].tobytes()
     assert diverge <= 5
+
+
+def _hc_fixtures():
+    yield "fox", np.frombuffer(corpus.QUICK_FOX, np.uint8)
+    for n in (1, 12, 13, 14, 64, 1000, 4096, 65536, 0x123456):
+        yield f"lorem{n}", corpus.lorem(n)
+    for n in (13, 33, 1000, 65536):
+        yield f"rep{n}", corpus.repeated(0xAA, n)
+    yield "rand5000", corpus.random_bytes(5000, 5)
+    yield "pattern", np.tile(np.frombuffer(b"abcdabcdabcdabcd" * 4 + b"xyz", np.uint8), 700)
+    yield "zeros+noise", np.concatenate([np.zeros(30000, np.uint8), corpus.random_bytes(100, 1), np.zeros(30000, np.uint8)])
+    for i, name in enumerate(corpus.SILESIA_NAMES):
+        yield f"cls-{name}", corpus.class_bytes(name, 65536 if i % 2 else 100000, 7)
+
+
+PROBES_HC3 = [(1000, 425, 0x4a7d9a5a), (4096, 437, None), (65536, 678, 0x5301963f), (0x123456, 5099, None)]
+
+
+@pytest.mark.parametrize("n,size,adler", PROBES_HC3)
+def test_survey_probe_values_hc3(oracle, n, size, adler):
+    ret, dst = oracle.compress_hc(corpus.lorem(n), 3)
+    assert ret == size
+    if adler is not None:
+        assert oracle.adler32(dst[:ret]) == adler
+
+
+@pytest.mark.parametrize("level", [3, 4, 6, 8, 9])
+@pytest.mark.parametrize("name,data", list(_hc_fixtures()), ids=[n for n, _ in _hc_fixtures()])
+def test_hc_encode_equals_liblz4_and_roundtrips(oracle, syslz4, name, data, level):
+    """LZ4_compress_HC levels 3..9 (hash chain; level 9 adds pattern analysis): the restatement of
+    LL64.high.cs against liblz4 1.9.3 -- the reference's own HC goldens need the Silesia corpus."""
+    bound = oracle.compress_bound(data.size)
+    ret, dst = oracle.compress_hc(data, level)
+    ret2, dst2 = syslz4.compress_hc(data, bound, level)
+    assert ret == ret2 and dst[:ret].tobytes() == dst2[:ret2].tobytes()
+    assert (dst[ret:] == 0xCD).all()
+    n, out = oracle.decompress_safe(dst[:ret], data.size)
+    assert n == data.size and out[:n].tobytes() == data.tobytes()
+    r3, d3 = oracle.compress_hc(data, level, cap=ret)
+    assert r3 == ret and d3[:ret].tobytes() == dst[:ret].tobytes()
+    if ret > 1:
+        assert oracle.compress_hc(data, level, cap=ret - 1)[0] == 0
