@@ -78,7 +78,7 @@ __device__ __forceinline__ uint32_t wave_count(const uint8_t *a, const uint8_t *
         const unsigned long long notfull = __ballot(neq != 4u);
         if (!notfull) { done += 256u; continue; }
         const int fl = ctz64(notfull);
-        return done + 4u * (uint32_t)fl + __shfl(neq, fl);
+        return done + 4u * (uint32_t)fl + __builtin_amdgcn_readlane(neq, fl);
     }
 }
 
@@ -98,7 +98,7 @@ struct OutStage {
     __device__ __forceinline__ void flush_to(uint32_t op, int lane)
     {
         const uint32_t n = op - base;
-        if (dry) { base = op; return; }
+        if (dry) { base = uni(op); return; }
         wave_sync();
         for (uint32_t k = 16u * (uint32_t)lane; k < n; k += 1024u) {
             if (k + 16u <= n) {
@@ -111,7 +111,7 @@ struct OutStage {
             }
         }
         wave_sync();
-        base = op;
+        base = uni(op);
     }
     /* make room for `need` more staged bytes at output position op */
     __device__ __forceinline__ void reserve(uint32_t op, uint32_t need, int lane)
@@ -131,13 +131,13 @@ __device__ __forceinline__ uint32_t emit_length_run(OutStage &st, uint32_t op, u
             wave_fill(st.dst + op, 255, nb, lane);
             if (lane == 0) st.dst[op + nb] = (uint8_t)(rem - nb * 255u);
         }
-        st.base = op + nb + 1u;
-        return op + nb + 1u;
+        st.base = uni(op + nb + 1u);
+        return uni(op + nb + 1u);
     }
     st.reserve(op, nb + 1u, lane);
     wave_fill(st.at(op), 255, nb, lane);
     if (lane == 0) *st.at(op + nb) = (uint8_t)(rem - nb * 255u);
-    return op + nb + 1u;
+    return uni(op + nb + 1u);
 }
 
 /* the 16 source bytes around position p: 4 before, the 4 compared ones, 8 after */
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64) void k4_encode_fast_kernel(BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tab[ENCODE_LDS_DWORDS];
     const int lane = lane_id();
-    const long long b = a.order ? (long long)a.order[blockIdx.x] : (long long)blockIdx.x;
+    const long long b = a.order ? (long long)uni(a.order[blockIdx.x]) : (long long)blockIdx.x;
     const int src_len = a.srcLen[b];
     const int cap = a.dstCap[b];
     const uint8_t *src = a.src + a.srcOff[b];
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(64) void k4_encode_fast_prof_kernel(BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tab[ENCODE_LDS_DWORDS];
     const int lane = lane_id();
-    const long long b = a.order ? (long long)a.order[blockIdx.x] : (long long)blockIdx.x;
+    const long long b = a.order ? (long long)uni(a.order[blockIdx.x]) : (long long)blockIdx.x;
     const int src_len = a.srcLen[b];
     const int cap = a.dstCap[b];
     int ret = 0;

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void k4_pickle_kernel(BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tab[ENCODE_LDS_DWORDS];
     const int lane = lane_id();
-    const long long b = a.order ? (long long)a.order[blockIdx.x] : (long long)blockIdx.x;
+    const long long b = a.order ? (long long)uni(a.order[blockIdx.x]) : (long long)blockIdx.x;
     const int r = pickle_block(a.src + a.srcOff[b], a.srcLen[b], a.dst + a.dstOff[b], a.dstCap[b], a.level,
                                a.flags, tab, lane);
     if (lane == 0) a.outLen[b] = r;
