@@ -13,3 +13,22 @@ for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv")
     print("==", os.path.relpath(path, root))
     for k, cs in acc.items():
         print("  ", k.split("(")[0], {c: round(sum(v) / len(v), 1) for c, v in cs.items()}, "dispatches", len(next(iter(cs.values()))))
+
+# HBM traffic per launch for bench.py's roofline.traffic: (FETCH_SIZE + WRITE_SIZE) KiB -> bytes
+import json
+tr = {}
+for kind in ("fetch", "write"):
+    for path in glob.glob(os.path.join(root, kind, "*counter_collection.csv")):
+        acc = collections.defaultdict(list)
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                k = row.get("Kernel_Name", "")
+                if k.startswith("k4::") and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    acc[k.split("(")[0].replace("k4::", "")].append(float(row["Counter_Value"]))
+        for k, v in acc.items():
+            tr[k] = tr.get(k, 0.0) + 1024.0 * sum(v) / len(v)
+if tr:
+    out = {k: int(v) for k, v in tr.items()}
+    print("traffic bytes per launch:", out)
+    if len(sys.argv) > 2:
+        json.dump(out, open(sys.argv[2], "w"), indent=1)
