@@ -23,6 +23,7 @@
 #include "k4lz4_decode.hpp"
 #include "k4lz4_encode_fast.hpp"
 #include "k4lz4_pickle.hpp"
+#include "k4lz4_encode_hc.hpp"
 
 struct k4lz4_ctx {
     int device = -1;
@@ -36,6 +37,9 @@ struct k4lz4_ctx {
     uint8_t *d_meta = nullptr; size_t d_meta_cap = 0;
     uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;
     uint8_t *d_sched = nullptr; size_t d_sched_cap = 0;   /* dispatch-order scratch: cost[n], order[n], counters */
+    uint8_t *d_hc_hash = nullptr; size_t d_hc_hash_cap = 0;   /* HC: per-block hash tables of one launch chunk */
+    uint8_t *d_hc_work = nullptr; size_t d_hc_work_cap = 0;   /* HC: prev[] / cand[] of one launch chunk */
+    uint8_t *d_hc_meta = nullptr; size_t d_hc_meta_cap = 0;   /* HC: work offsets, pickle slots */
 };
 
 namespace {
@@ -68,11 +72,59 @@ enum Kind { KIND_ENCODE, KIND_DECODE, KIND_PICKLE, KIND_UNPICKLE };
 
 int check_level(k4lz4_ctx *ctx, int level)
 {
-    if (level < K4LZ4_L03_HC) return K4LZ4_OK;   /* LZ4Codec.cs:48: level < L03_HC -> fast */
-    return fail(ctx, K4LZ4_E_UNSUPPORTED, "LZ4Level >= L03_HC is not implemented by the device path yet");
+    if (level <= K4LZ4_L08_HC) return K4LZ4_OK;   /* < L03_HC -> fast (LZ4Codec.cs:48); L03..L08 -> hash chain */
+    return fail(ctx, K4LZ4_E_UNSUPPORTED,
+                "LZ4Level L09_HC (pattern analysis) and L10..L12 (optimal parser) are not implemented by the device path");
 }
 
 int grow(k4lz4_ctx *ctx, uint8_t **p, size_t *cap, size_t need, bool pinned);
+
+/* HC levels: layout -> (sync for the scratch size) -> hash-table clear -> chain kernel -> parse kernel.
+ * `pickle`: the same around the LZ4Pickler envelope (encoder slot = envelope + 5, cap U - 1). */
+int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+              const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level, int flags,
+              hipStream_t stream)
+{
+    const int64_t chunk_max = 4096;   /* 128 KiB of hash table per block in flight */
+    for (int64_t first = 0; first < n; first += chunk_max) {
+        const int64_t cnt = std::min<int64_t>(chunk_max, n - first);
+        /* the scratch of the previous chunk / call must be idle before it is resized or reused */
+        K4_HIP(ctx, hipStreamSynchronize(stream));
+        int rc = grow(ctx, &ctx->d_hc_hash, &ctx->d_hc_hash_cap, (size_t)cnt << (k4::HC_HASH_LOG + 2), false);
+        if (rc != K4LZ4_OK) return rc;
+        rc = grow(ctx, &ctx->d_hc_meta, &ctx->d_hc_meta_cap, (size_t)(cnt + 1) * 8 + (size_t)cnt * 16 + 64, false);
+        if (rc != K4LZ4_OK) return rc;
+        unsigned long long *d_woff = (unsigned long long *)ctx->d_hc_meta;
+        uint64_t *d_encoff = (uint64_t *)(d_woff + cnt + 1);
+        int32_t *d_enccap = (int32_t *)(d_encoff + cnt);
+        int32_t *d_enclen = d_enccap + cnt;
+        k4::HcArgs h{};
+        h.src = src; h.srcOff = srcOff + first; h.srcLen = srcLen + first;
+        h.dst = dst; h.dstOff = dstOff + first; h.dstCap = dstCap + first; h.outLen = outLen + first;
+        h.n = cnt; h.level = level; h.flags = flags;
+        h.hash = (uint32_t *)ctx->d_hc_hash; h.workOff = d_woff;
+        k4::BatchArgs a{};
+        a.src = src; a.srcOff = h.srcOff; a.srcLen = h.srcLen; a.dst = dst; a.dstOff = h.dstOff; a.dstCap = h.dstCap;
+        a.outLen = h.outLen; a.n = cnt; a.level = level; a.accel = 1; a.flags = flags;
+        if (pickle) {
+            hipLaunchKernelGGL(k4::k4_pickle_prep_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, a, d_encoff, d_enccap);
+            h.dstOff = d_encoff; h.dstCap = d_enccap; h.outLen = d_enclen; h.flags = K4LZ4_FLAG_RAW_RETURN;
+        }
+        hipLaunchKernelGGL(k4::k4_hc_layout_kernel, dim3(1), dim3(256), 0, stream, h);
+        unsigned long long total = 0;
+        K4_HIP(ctx, hipMemcpyAsync(&total, d_woff + cnt, 8, hipMemcpyDeviceToHost, stream));
+        K4_HIP(ctx, hipStreamSynchronize(stream));
+        rc = grow(ctx, &ctx->d_hc_work, &ctx->d_hc_work_cap, (size_t)total + 256, false);
+        if (rc != K4LZ4_OK) return rc;
+        h.work = ctx->d_hc_work;
+        K4_HIP(ctx, hipMemsetAsync(ctx->d_hc_hash, 0, (size_t)cnt << (k4::HC_HASH_LOG + 2), stream));
+        hipLaunchKernelGGL(k4::k4_hc_chain_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
+        hipLaunchKernelGGL(k4::k4_hc_parse_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
+        if (pickle) hipLaunchKernelGGL(k4::k4_pickle_finish_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a, d_enclen);
+        K4_HIP(ctx, hipGetLastError());
+    }
+    return K4LZ4_OK;
+}
 
 /* enqueue the kernels for n blocks; all pointers are device pointers */
 int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
@@ -82,6 +134,8 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
     if (n == 0) return K4LZ4_OK;
     const int64_t chunk_max = 1 << 24;   /* blocks per launch (grid.x * blockDim.x must stay < 2^32) */
     const bool encode_like = kind == KIND_ENCODE || kind == KIND_PICKLE;
+    if (encode_like && level >= K4LZ4_L03_HC)
+        return launch_hc(ctx, kind == KIND_PICKLE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, stream);
     /* cost-ordered dispatch (most expensive blocks first): encoders by default, decoders on request */
     const bool reorder = n > 1 &&
                          (encode_like ? !(flags & K4LZ4_FLAG_NO_REORDER) : (flags & K4LZ4_FLAG_REORDER) != 0);
@@ -313,6 +367,9 @@ void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
     if (ctx->d_meta) (void)hipFree(ctx->d_meta);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->d_sched) (void)hipFree(ctx->d_sched);
+    if (ctx->d_hc_hash) (void)hipFree(ctx->d_hc_hash);
+    if (ctx->d_hc_work) (void)hipFree(ctx->d_hc_work);
+    if (ctx->d_hc_meta) (void)hipFree(ctx->d_hc_meta);
     delete ctx;
 }
 

@@ -1,0 +1,436 @@
+/*
+ * k4lz4_encode_hc.hpp -- batched LZ4 HC (hash-chain) block encoder for gfx950, levels L03..L08.
+ *
+ * Replaces (for batches of independent blocks) the reference's
+ *   LZ4Codec.Encode (level >= L03_HC)        src/K4os.Compression.LZ4/LZ4Codec.cs:48-51
+ *   LLxx.LZ4_compress_HC                     Engine/LLxx.cs:94-103
+ *   LL64.LZ4_compress_HC .. _fastReset       Engine/x64/LL64.high.cs:1336-1381
+ *   LZ4HC_init_internal / clearTables        Engine/LL.high.cs:142-166
+ *   LZ4HC_compress_generic / clTable         Engine/x64/LL64.high.cs:1124-1189
+ *   LZ4HC_compress_hashChain                 Engine/x64/LL64.high.cs:512-800
+ *   LZ4HC_InsertAndGetWiderMatch             Engine/x64/LL64.high.cs:70-383 (noDictCtx, no chainSwap,
+ *                                            no pattern analysis: nbSearches <= 128, i.e. levels 3..8)
+ *   LZ4HC_Insert / LZ4HC_countBack           Engine/LL.high.cs:102-122,:216-230
+ *   LZ4HC_encodeSequence                     Engine/x64/LL64.high.cs:435-510
+ * with byte-identical output.
+ *
+ * Key observation: unlike the fast encoder, the HC tables do not depend on the parse.
+ * LZ4HC_Insert enters EVERY position, in order, before it can be searched, so the chain of
+ * candidates seen by a search at position p -- "previous position with the same 15-bit hash",
+ * repeatedly -- is a pure function of the data.  The work is therefore split in two kernels:
+ *
+ *   k4_hc_chain_kernel   (data-parallel)  64 positions per step: hash, look up / update a per-block
+ *                        hash table, resolve equal hashes inside the step in lane order -> prev[p];
+ *                        then pointer-jump prev[] three times so that every position holds its
+ *                        first four chain candidates in one 16-byte record cand[p][0..3].
+ *   k4_hc_parse_kernel   (serial per block, one wavefront) the reference's match arbitration
+ *                        (LL64.high.cs:553-749) with wave-uniform state.  A search loads one record
+ *                        and evaluates its four candidates at once, 16 lanes per candidate (4 bytes
+ *                        per lane per step forwards, bytewise backwards); the reference's
+ *                        "first candidate in chain order that beats `longest`" rule is applied to
+ *                        the four lengths.  Levels above 3 continue with the record of the last
+ *                        candidate.
+ *
+ * Scratch (context-owned, device): per block a 128 KiB hash table (u32 x 32768, zero = empty with
+ * positions stored +1), prev[U] (u32) and cand[U][4] (u32), see k4_hc_layout_kernel.
+ */
+#pragma once
+#include "k4lz4_common.hpp"
+
+namespace k4 {
+
+constexpr int HC_HASH_LOG = 15;
+constexpr uint32_t HC_NONE = 0xffffffffu;
+constexpr int HC_OPTIMAL_ML = (ML_MASK - 1) + MINMATCH;   /* LL.types.cs:74 */
+
+struct HcArgs {
+    const uint8_t *src;
+    const uint64_t *srcOff;
+    const int32_t *srcLen;
+    uint8_t *dst;
+    const uint64_t *dstOff;
+    const int32_t *dstCap;
+    int32_t *outLen;
+    long long n;
+    int level;
+    int flags;
+    uint32_t *hash;            /* n x 32768, zeroed before k4_hc_chain_kernel */
+    uint8_t *work;             /* prev[] and cand[] of every block */
+    unsigned long long *workOff;   /* n + 1: byte offset of block i's work area (k4_hc_layout_kernel) */
+};
+
+__device__ __forceinline__ uint32_t hc_hash(uint32_t v) { return (v * 2654435761u) >> (MINMATCH * 8 - HC_HASH_LOG); }
+__device__ __forceinline__ uint64_t hc_work_bytes(int len) { return len > 0 ? (((uint64_t)len + 3u) & ~3ull) * 20u : 0u; }
+
+/* exclusive scan of the per-block work sizes (one workgroup; n is at most a launch chunk) */
+__global__ __launch_bounds__(256) void k4_hc_layout_kernel(HcArgs a)
+{
+    __shared__ unsigned long long part[256];
+    const int t = (int)threadIdx.x;
+    const long long per = (a.n + 255) / 256;
+    const long long lo = (long long)t * per, hi = lo + per < a.n ? lo + per : a.n;
+    unsigned long long s = 0;
+    for (long long i = lo; i < hi; i++) s += hc_work_bytes(a.srcLen[i]);
+    part[t] = s;
+    __syncthreads();
+    unsigned long long base = 0;
+    for (int k = 0; k < t; k++) base += part[k];
+    for (long long i = lo; i < hi; i++) {
+        a.workOff[i] = base;
+        base += hc_work_bytes(a.srcLen[i]);
+    }
+    if (t == 255) a.workOff[a.n] = base;
+}
+
+/* ---- kernel 1: chains ------------------------------------------------------------------- */
+__global__ __launch_bounds__(64) void k4_hc_chain_kernel(HcArgs a)
+{
+    const int lane = lane_id();
+    const long long b = (long long)blockIdx.x;
+    const int len = a.srcLen[b];
+    if (len < MFLIMIT + 1) return;                         /* no search happens (LL64.high.cs:549) */
+    const uint32_t U = (uint32_t)len;
+    const uint8_t *src = a.src + a.srcOff[b];
+    uint32_t *tab = a.hash + (size_t)b * (1u << HC_HASH_LOG);
+    uint32_t *prev = (uint32_t *)(a.work + a.workOff[b]);
+    uint32_t *cand = prev + ((U + 3u) & ~3u);
+    const uint32_t npos = U - 3u;                          /* positions whose 4 bytes exist */
+
+    /* prev[p] = nearest earlier position with the same hash (HC_NONE if there is none) */
+    for (uint32_t p0 = 0; p0 < npos; p0 += 64u) {
+        const uint32_t p = p0 + (uint32_t)lane;
+        const bool act = p < npos;
+        uint32_t h = 0, pr = HC_NONE;
+        if (act) {
+            h = hc_hash(ld32u(src + p));
+            const uint32_t t = tab[h];
+            pr = t ? t - 1u : HC_NONE;
+        }
+        const unsigned long long am = __ballot(act);
+        const int cnt = __popcll(am);
+        bool last = act;                                   /* last lane of its hash inside this step */
+        for (int k = 0; k < cnt; k++) {
+            const uint32_t hk = __builtin_amdgcn_readlane(h, k);
+            if (act && hk == h) {
+                if (k < lane) pr = p0 + (uint32_t)k;
+                if (k > lane) last = false;
+            }
+        }
+        if (act) prev[p] = pr;
+        if (last) tab[h] = p + 1u;
+        wave_sync();
+    }
+    /* first four chain candidates of every position; a chain step of 65535 or more ends the walk
+     * (LL.high.cs:114 caps the delta, and such a candidate is below lowestMatchIndex) */
+    for (uint32_t p0 = 0; p0 < npos; p0 += 64u) {
+        const uint32_t p = p0 + (uint32_t)lane;
+        if (p < npos) {
+            uint32_t c0 = prev[p], c1 = HC_NONE, c2 = HC_NONE, c3 = HC_NONE;
+            if (c0 != HC_NONE) { const uint32_t q = prev[c0]; if (q != HC_NONE && c0 - q < (uint32_t)DISTANCE_MAX) c1 = q; }
+            if (c1 != HC_NONE) { const uint32_t q = prev[c1]; if (q != HC_NONE && c1 - q < (uint32_t)DISTANCE_MAX) c2 = q; }
+            if (c2 != HC_NONE) { const uint32_t q = prev[c2]; if (q != HC_NONE && c2 - q < (uint32_t)DISTANCE_MAX) c3 = q; }
+            ((uint4 *)cand)[p] = make_uint4(c0, c1, c2, c3);
+        }
+    }
+}
+
+/* ---- kernel 2: parse -------------------------------------------------------------------- */
+
+struct HcMatch { int len; uint32_t mpos, spos; };          /* longest, *matchpos, *startpos */
+
+/*
+ * LZ4HC_InsertAndGetWiderMatch (LL64.high.cs:70-383) at position ip with low limit ilow, best
+ * length so far `longest` (matchpos / startpos of the caller stay untouched unless it is beaten).
+ * Four candidates per step, 16 lanes each.
+ */
+__device__ __forceinline__ HcMatch hc_search(const uint8_t *src, const uint32_t *cand, uint32_t ip, uint32_t ilow,
+                                             uint32_t matchlimit, int longest, uint32_t mpos, uint32_t spos,
+                                             int max_attempts, int lane)
+{
+    HcMatch r;
+    r.len = longest; r.mpos = mpos; r.spos = spos;
+    const uint32_t pattern = uni(ld32u(src + ip));
+    const uint32_t lowest = ip > (uint32_t)DISTANCE_MAX ? ip - (uint32_t)DISTANCE_MAX : 0u;   /* :87-88 */
+    const uint32_t look_back = ip - ilow;
+    const int grp = lane >> 4, sub = lane & 15;
+    uint32_t rec_at = ip;
+    int attempts = max_attempts;
+    bool first_record = true;
+    while (attempts > 0) {
+        const uint4 rec = ((const uint4 *)cand)[rec_at];
+        uint32_t c = grp == 0 ? rec.x : grp == 1 ? rec.y : grp == 2 ? rec.z : rec.w;
+        /* the first candidate of a search may be exactly 65535 back; later chain steps may not */
+        bool ok = c != HC_NONE && c >= lowest && grp < attempts;
+        if (!first_record && grp == 0 && ok) ok = rec_at - c < (uint32_t)DISTANCE_MAX;
+        /* candidates are only reachable through their predecessors */
+        const unsigned long long okm = __ballot(ok);
+        const bool ok0 = (okm & 1ull) != 0, ok1 = ok0 && ((okm >> 16) & 1ull) != 0, ok2 = ok1 && ((okm >> 32) & 1ull) != 0,
+                   ok3 = ok2 && ((okm >> 48) & 1ull) != 0;
+        ok = grp == 0 ? ok0 : grp == 1 ? ok1 : grp == 2 ? ok2 : ok3;
+        const int nvalid = (ok0 ? 1 : 0) + (ok1 ? 1 : 0) + (ok2 ? 1 : 0) + (ok3 ? 1 : 0);
+        if (nvalid == 0) break;
+        if (!ok) c = 0;
+        const bool seq_ok = ok && ld32u(src + c) == pattern;                      /* :120 */
+        /* forward: bytes ip+4.. vs c+4.., 64 per step and group */
+        uint32_t fwd = 0;
+        {
+            const uint32_t maxn = matchlimit - (ip + MINMATCH);
+            uint32_t done = 0;
+            bool open = seq_ok;
+            for (;;) {
+                const uint32_t i = done + 4u * (uint32_t)sub;
+                uint32_t neq = 4u;
+                if (open) {
+                    neq = 0;
+                    if (i < maxn) {
+                        const uint32_t x = ld32u(src + ip + MINMATCH + i) ^ ld32u(src + c + MINMATCH + i);
+                        const uint32_t avail = maxn - i < 4u ? maxn - i : 4u;
+                        const uint32_t e = x ? (uint32_t)(__ffs(x) - 1) >> 3 : 4u;
+                        neq = e < avail ? e : avail;
+                    }
+                }
+                const unsigned long long nf = __ballot(open && neq != 4u);
+                const uint32_t gm = (uint32_t)(nf >> (16 * grp)) & 0xffffu;     /* this group's not-full lanes */
+                const int fl = gm ? __ffs(gm) - 1 : 0;
+                const uint32_t nq = (uint32_t)__shfl((int)neq, (lane & 48) + fl);
+                if (open) {
+                    if (gm) { fwd = done + 4u * (uint32_t)fl + nq; open = false; }
+                    else done += 64u;
+                }
+                if (!__ballot(open)) break;
+            }
+        }
+        /* backward: ip-1.. vs c-1.., bounded by ilow and the block start (:124-125, LL.high.cs:216-230) */
+        uint32_t back = 0;
+        if (look_back) {
+            const uint32_t maxb = look_back < c ? look_back : c;
+            uint32_t done = 0;
+            bool open = seq_ok && maxb != 0u;
+            for (;;) {
+                const uint32_t i = done + (uint32_t)sub;
+                const bool eq = open && i < maxb && src[ip - 1u - i] == src[c - 1u - i];
+                const unsigned long long ne = __ballot(open && !eq);
+                const uint32_t gm = (uint32_t)(ne >> (16 * grp)) & 0xffffu;
+                if (open) {
+                    if (gm) { back = done + (uint32_t)(__ffs(gm) - 1); open = false; }
+                    else done += 16u;
+                }
+                if (!__ballot(open)) break;
+            }
+        }
+        const int ml = seq_ok ? (int)(MINMATCH + fwd + back) : 0;                /* matchLength - back, back <= 0 */
+        /* chain order: a candidate wins only if it beats everything before it (:128-133) */
+        const int ml0 = (int)__builtin_amdgcn_readlane((uint32_t)ml, 0), ml1 = (int)__builtin_amdgcn_readlane((uint32_t)ml, 16),
+                  ml2 = (int)__builtin_amdgcn_readlane((uint32_t)ml, 32), ml3 = (int)__builtin_amdgcn_readlane((uint32_t)ml, 48);
+        const uint32_t c0 = __builtin_amdgcn_readlane(c, 0), c1 = __builtin_amdgcn_readlane(c, 16), c2 = __builtin_amdgcn_readlane(c, 32),
+                       c3 = __builtin_amdgcn_readlane(c, 48);
+        const uint32_t b0 = __builtin_amdgcn_readlane(back, 0), b1 = __builtin_amdgcn_readlane(back, 16),
+                       b2 = __builtin_amdgcn_readlane(back, 32), b3 = __builtin_amdgcn_readlane(back, 48);
+        if (ml0 > r.len) { r.len = ml0; r.mpos = c0 - b0; r.spos = ip - b0; }
+        if (nvalid > 1 && ml1 > r.len) { r.len = ml1; r.mpos = c1 - b1; r.spos = ip - b1; }
+        if (nvalid > 2 && ml2 > r.len) { r.len = ml2; r.mpos = c2 - b2; r.spos = ip - b2; }
+        if (nvalid > 3 && ml3 > r.len) { r.len = ml3; r.mpos = c3 - b3; r.spos = ip - b3; }
+        attempts -= nvalid;
+        if (nvalid < 4) break;
+        rec_at = c3;                                        /* the chain continues behind the last candidate */
+        first_record = false;
+    }
+    return r;
+}
+
+/* LZ4HC_encodeSequence (LL64.high.cs:435-510); returns false on output overflow */
+__device__ __forceinline__ bool hc_encode_sequence(const uint8_t *src, uint8_t *dst, uint32_t &ip, int64_t &op, uint32_t &anchor,
+                                                   int match_length, uint32_t match, bool limited, int64_t oend, int lane)
+{
+    const uint32_t token_pos = (uint32_t)op;
+    op++;
+    uint32_t length = ip - anchor;
+    if (limited && op + (int64_t)(length / 255u) + length + (2 + 1 + LASTLITERALS) > oend) return false;
+    uint32_t token;
+    if (length >= (uint32_t)RUN_MASK) {
+        uint32_t len = length - RUN_MASK;
+        token = (uint32_t)RUN_MASK << ML_BITS;
+        const uint32_t nb = len / 255u;
+        wave_fill(dst + op, 255, nb, lane);
+        if (lane == 0) dst[op + nb] = (uint8_t)(len - nb * 255u);
+        op += nb + 1u;
+    } else {
+        token = length << ML_BITS;
+    }
+    wave_copy(dst + op, src + anchor, length, lane);
+    op += length;
+    if (lane == 0) {
+        const uint32_t off = ip - match;
+        dst[op] = (uint8_t)off;
+        dst[op + 1] = (uint8_t)(off >> 8);
+    }
+    op += 2;
+    length = (uint32_t)match_length - MINMATCH;
+    if (limited && op + (int64_t)(length / 255u) + (1 + LASTLITERALS) > oend) return false;
+    if (length >= (uint32_t)ML_MASK) {
+        token += ML_MASK;
+        length -= ML_MASK;
+        const uint32_t nb = length / 255u;                 /* the 510-stepped loop writes the same bytes */
+        wave_fill(dst + op, 255, nb, lane);
+        if (lane == 0) dst[op + nb] = (uint8_t)(length - nb * 255u);
+        op += nb + 1u;
+    } else {
+        token += length;
+    }
+    if (lane == 0) dst[token_pos] = (uint8_t)token;
+    ip += (uint32_t)match_length;
+    anchor = ip;
+    op = (int64_t)uni((uint32_t)op);
+    return true;
+}
+
+/* clTable (LL64.high.cs:1124-1138), hash-chain levels */
+__device__ __forceinline__ int hc_nb_searches(int level)
+{
+    if (level < 1) level = 9;
+    return level <= 3 ? 4 : level == 4 ? 8 : level == 5 ? 16 : level == 6 ? 32 : level == 7 ? 64 : level == 8 ? 128 : 256;
+}
+
+/* LZ4HC_compress_hashChain (LL64.high.cs:512-800) for one block; returns bytes written, 0 = overflow */
+__device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap, int level,
+                                              const uint32_t *cand, int lane)
+{
+    if ((uint32_t)src_len > (uint32_t)MAX_INPUT_SIZE) return 0;      /* :1153 */
+    const bool limited = dst_cap < compress_bound(src_len);         /* :1348 */
+    const int64_t oend = dst_cap;
+    const int max_attempts = hc_nb_searches(level);
+    const uint32_t U = (uint32_t)src_len;
+    uint32_t ip = 0, anchor = 0;
+    int64_t op = 0;
+
+    if (src_len >= MFLIMIT + 1) {
+        const uint32_t mflimit = U - MFLIMIT;
+        const uint32_t matchlimit = U - LASTLITERALS;
+        while (ip <= mflimit) {
+            HcMatch m = hc_search(src, cand, ip, ip, matchlimit, MINMATCH - 1, 0, ip, max_attempts, lane);
+            int ml = m.len;
+            uint32_t ref = m.mpos;
+            if (ml < MINMATCH) { ip++; continue; }
+            uint32_t start0 = ip, ref0 = ref;
+            int ml0 = ml;
+            int ml2 = 0, ml3 = 0;
+            uint32_t start2 = 0, ref2 = 0, start3 = 0, ref3 = 0;
+            bool go_search2 = true;
+            for (;;) {   /* one pass = _Search2 (if requested) followed by _Search3 rounds */
+                if (go_search2) {
+                    if (ip + (uint32_t)ml <= mflimit) {
+                        const HcMatch m2 = hc_search(src, cand, ip + (uint32_t)ml - 2u, ip, matchlimit, ml, ref2, start2, max_attempts, lane);
+                        ml2 = m2.len; ref2 = m2.mpos; start2 = m2.spos;
+                    } else {
+                        ml2 = ml;
+                    }
+                    if (ml2 == ml) {                           /* no better match: encode ML1 */
+                        if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane)) return 0;
+                        break;
+                    }
+                    if (start0 < ip) {
+                        if (start2 < ip + (uint32_t)ml0) { ip = start0; ref = ref0; ml = ml0; }
+                    }
+                    if (start2 - ip < 3u) {                    /* first match too small: removed */
+                        ml = ml2; ip = start2; ref = ref2;
+                        continue;                              /* goto _Search2 */
+                    }
+                }
+                go_search2 = false;
+                /* _Search3 */
+                if (start2 - ip < (uint32_t)HC_OPTIMAL_ML) {
+                    int new_ml = ml;
+                    if (new_ml > HC_OPTIMAL_ML) new_ml = HC_OPTIMAL_ML;
+                    if (ip + (uint32_t)new_ml > start2 + (uint32_t)ml2 - MINMATCH) new_ml = (int)(start2 - ip) + ml2 - MINMATCH;
+                    const int correction = new_ml - (int)(start2 - ip);
+                    if (correction > 0) { start2 += (uint32_t)correction; ref2 += (uint32_t)correction; ml2 -= correction; }
+                }
+                if (start2 + (uint32_t)ml2 <= mflimit) {
+                    const HcMatch m3 = hc_search(src, cand, start2 + (uint32_t)ml2 - 3u, start2, matchlimit, ml2, ref3, start3, max_attempts, lane);
+                    ml3 = m3.len; ref3 = m3.mpos; start3 = m3.spos;
+                } else {
+                    ml3 = ml2;
+                }
+                if (ml3 == ml2) {                              /* no better match: encode ML1 and ML2 */
+                    if (start2 < ip + (uint32_t)ml) ml = (int)(start2 - ip);
+                    if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane)) return 0;
+                    ip = start2;
+                    if (!hc_encode_sequence(src, dst, ip, op, anchor, ml2, ref2, limited, oend, lane)) return 0;
+                    break;
+                }
+                if (start3 < ip + (uint32_t)ml + 3u) {         /* not enough space for match 2: remove it */
+                    if (start3 >= ip + (uint32_t)ml) {         /* write Seq1 now; Seq3 becomes Seq1 */
+                        if (start2 < ip + (uint32_t)ml) {
+                            const int correction = (int)(ip + (uint32_t)ml - start2);
+                            start2 += (uint32_t)correction; ref2 += (uint32_t)correction; ml2 -= correction;
+                            if (ml2 < MINMATCH) { start2 = start3; ref2 = ref3; ml2 = ml3; }
+                        }
+                        if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane)) return 0;
+                        ip = start3; ref = ref3; ml = ml3;
+                        start0 = start2; ref0 = ref2; ml0 = ml2;
+                        go_search2 = true;
+                        continue;                              /* goto _Search2 */
+                    }
+                    start2 = start3; ref2 = ref3; ml2 = ml3;
+                    continue;                                  /* goto _Search3 */
+                }
+                /* three ascending matches: write the first one */
+                if (start2 < ip + (uint32_t)ml) {
+                    if (start2 - ip < (uint32_t)HC_OPTIMAL_ML) {
+                        if (ml > HC_OPTIMAL_ML) ml = HC_OPTIMAL_ML;
+                        if (ip + (uint32_t)ml > start2 + (uint32_t)ml2 - MINMATCH) ml = (int)(start2 - ip) + ml2 - MINMATCH;
+                        const int correction = ml - (int)(start2 - ip);
+                        if (correction > 0) { start2 += (uint32_t)correction; ref2 += (uint32_t)correction; ml2 -= correction; }
+                    } else {
+                        ml = (int)(start2 - ip);
+                    }
+                }
+                if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane)) return 0;
+                ip = start2; ref = ref2; ml = ml2;             /* ML2 becomes ML1, ML3 becomes ML2 */
+                start2 = start3; ref2 = ref3; ml2 = ml3;
+                /* goto _Search3 */
+            }
+        }
+    }
+    /* _last_literals (:751-787) */
+    {
+        const uint32_t last_run = U - anchor;
+        const uint32_t lit_length = (last_run + 255u - RUN_MASK) / 255u;
+        if (limited && op + 1 + (int64_t)lit_length + last_run > oend) return 0;
+        if (last_run >= (uint32_t)RUN_MASK) {
+            const uint32_t acc = last_run - RUN_MASK;
+            const uint32_t nb = acc / 255u;
+            if (lane == 0) dst[op] = (uint8_t)(RUN_MASK << ML_BITS);
+            wave_fill(dst + op + 1, 255, nb, lane);
+            if (lane == 0) dst[op + 1 + nb] = (uint8_t)(acc - nb * 255u);
+            op += 2 + nb;
+        } else {
+            if (lane == 0) dst[op] = (uint8_t)(last_run << ML_BITS);
+            op++;
+        }
+        wave_copy(dst + op, src + anchor, last_run, lane);
+        op += last_run;
+    }
+    return (int)op;
+}
+
+__global__ __launch_bounds__(64) void k4_hc_parse_kernel(HcArgs a)
+{
+    const int lane = lane_id();
+    const long long b = (long long)blockIdx.x;
+    const int src_len = a.srcLen[b];
+    const int cap = a.dstCap[b];
+    int ret = 0;
+    if (src_len > 0 || (a.flags & FLAG_RAW_RETURN)) {
+        const uint32_t *prev = (const uint32_t *)(a.work + a.workOff[b]);
+        const uint32_t *cand = prev + (((uint32_t)(src_len > 0 ? src_len : 0) + 3u) & ~3u);
+        ret = hc_parse_block(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.level, cand, lane);
+    }
+    if (lane == 0) {
+        int r = ret;
+        if (!(a.flags & FLAG_RAW_RETURN)) r = src_len <= 0 ? 0 : (ret <= 0 ? -1 : ret);   /* LZ4Codec.cs:45-51 */
+        a.outLen[b] = r;
+    }
+}
+
+}  // namespace k4

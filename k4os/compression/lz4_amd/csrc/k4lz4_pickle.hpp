@@ -53,15 +53,9 @@ __device__ __forceinline__ void wave_shift_down(uint8_t *d, const uint8_t *s, ui
     }
 }
 
-/* one message -> envelope; returns envelope length, 0 for an empty message, -1 if dst too small */
-__device__ __forceinline__ int pickle_block(const uint8_t *src, int U, uint8_t *dst, int cap, int level, int flags,
-                                            uint32_t *tabw, int lane)
+/* envelope around an already encoded block sitting at dst + 5 (C = encoder result with cap U - 1) */
+__device__ __forceinline__ int pickle_finish(const uint8_t *src, int U, uint8_t *dst, int C, int flags, int lane)
 {
-    (void)level;
-    if (U <= 0) return 0;                                   /* pickle.cs:53-54 */
-    if (cap < 1 + 4 + U) return -1;
-    int C = 0;
-    if (U > 1) C = compress_fast_block(src, U, dst + 5, U - 1, 1, tabw, lane);
     if (C <= 0 || C >= U) {                                 /* pickle.cs:85,:135 raw */
         wave_sync();
         if (lane == 0) dst[0] = 0;
@@ -78,6 +72,18 @@ __device__ __forceinline__ int pickle_block(const uint8_t *src, int U, uint8_t *
         for (int i = 0; i < sod; i++) dst[1 + i] = (uint8_t)((uint32_t)diff >> (8 * i));
     }
     return 1 + sod + C;
+}
+
+/* one message -> envelope; returns envelope length, 0 for an empty message, -1 if dst too small */
+__device__ __forceinline__ int pickle_block(const uint8_t *src, int U, uint8_t *dst, int cap, int level, int flags,
+                                            uint32_t *tabw, int lane)
+{
+    (void)level;
+    if (U <= 0) return 0;                                   /* pickle.cs:53-54 */
+    if (cap < 1 + 4 + U) return -1;
+    int C = 0;
+    if (U > 1) C = compress_fast_block(src, U, dst + 5, U - 1, 1, tabw, lane);
+    return pickle_finish(src, U, dst, C, flags, lane);
 }
 
 struct PickleHeader { int data_offset; int result_len; bool compressed; bool ok; };
@@ -142,6 +148,29 @@ __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_unpickle_kernel(B
     const long long b = (long long)blockIdx.x * DECODE_WAVES_PER_WG + (long long)wave;
     if (b >= a.n) return;
     const int r = unpickle_block(a.src + a.srcOff[b], a.srcLen[b], a.dst + a.dstOff[b], a.dstCap[b], lane, lds[wave]);
+    if (lane == 0) a.outLen[b] = r;
+}
+
+/* HC levels: the block encoder runs as its own kernels between these two.
+ * prep: encoder slot = envelope slot + 5, capacity U - 1 (or -1 = slot too small / empty message) */
+__global__ __launch_bounds__(256) void k4_pickle_prep_kernel(BatchArgs a, uint64_t *encOff, int32_t *encCap)
+{
+    const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (b >= a.n) return;
+    const int U = a.srcLen[b];
+    encOff[b] = a.dstOff[b] + 5u;
+    encCap[b] = (U > 0 && a.dstCap[b] >= 1 + 4 + U) ? U - 1 : 0;
+}
+/* finish: encLen[i] = LLxx-level encoder result for message i */
+__global__ __launch_bounds__(64) void k4_pickle_finish_kernel(BatchArgs a, const int32_t *encLen)
+{
+    const int lane = lane_id();
+    const long long b = (long long)blockIdx.x;
+    const int U = a.srcLen[b];
+    int r;
+    if (U <= 0) r = 0;
+    else if (a.dstCap[b] < 1 + 4 + U) r = -1;
+    else r = pickle_finish(a.src + a.srcOff[b], U, a.dst + a.dstOff[b], U > 1 ? encLen[b] : 0, a.flags, lane);
     if (lane == 0) a.outLen[b] = r;
 }
 

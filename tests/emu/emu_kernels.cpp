@@ -4,6 +4,8 @@
 #include "k4lz4_decode.hpp"
 #include "k4lz4_encode_fast.hpp"
 #include "k4lz4_pickle.hpp"
+#include "k4lz4_encode_hc.hpp"
+#include <vector>
 
 extern "C" {
 
@@ -38,6 +40,24 @@ int k4emu_order(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLe
     if (n <= 0) return 0;
     k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_cost_kernel(a, by_length); }, threads);
     k4emu::launch_fn(dim3((unsigned)((n + 255) / 256)), dim3(256), [=] { k4::k4_order_kernel(a); }, 1);
+    return 0;
+}
+
+/* HC: layout + chain + parse kernels, scratch on the host heap */
+int k4emu_encode_hc_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                          const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int level,
+                          int flags, int threads)
+{
+    if (n <= 0) return 0;
+    std::vector<unsigned long long> off((size_t)n + 1);
+    k4::HcArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, nullptr, nullptr, off.data()};
+    k4emu::launch_fn(dim3(1), dim3(256), [=] { k4::k4_hc_layout_kernel(a); }, 1);
+    std::vector<uint32_t> hash((size_t)n << k4::HC_HASH_LOG, 0u);
+    std::vector<uint8_t> work((size_t)off[(size_t)n] + 64);
+    a.hash = hash.data();
+    a.work = work.data();
+    k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_hc_chain_kernel(a); }, threads);
+    k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_hc_parse_kernel(a); }, threads);
     return 0;
 }
 

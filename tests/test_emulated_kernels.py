@@ -289,3 +289,48 @@ def test_dispatch_order_is_a_permutation_by_cost(emu):
     cost_l, order_l = emu.order(src, soff, slen, by_length=1)
     assert sorted(order_l.tolist()) == list(range(len(blocks)))
     assert (np.diff(slen[order_l].astype(np.int64) // 1) <= 0).all() or (np.diff(cost_l[order_l].astype(np.int64)) <= 0).all()
+
+
+@pytest.mark.parametrize("level", [3, 4, 6, 8])
+def test_encode_hc_matches_oracle(emu, oracle, level):
+    """HC chain + parse kernels (levels 3..8) against the oracle's LL64.high.cs restatement"""
+    blocks = [np.frombuffer(corpus.QUICK_FOX, np.uint8), np.zeros(0, np.uint8)]
+    blocks += [corpus.lorem(n) for n in (1, 12, 13, 14, 1000, 65536)]
+    blocks += [corpus.repeated(0xAA, n) for n in (13, 33, 1000, 70000)]
+    blocks += [corpus.random_bytes(5000, 5), np.tile(np.frombuffer(b"abcdabcdabcdabcd" * 4 + b"xyz", np.uint8), 300)]
+    blocks += [np.concatenate([np.zeros(20000, np.uint8), corpus.random_bytes(100, 1), np.zeros(20000, np.uint8)])]
+    blocks += [corpus.class_bytes(name, 30000 + 5000 * (i % 3), 7) for i, name in enumerate(corpus.SILESIA_NAMES)]
+    blocks += [corpus.class_bytes("samba", 150000, 3)]          # > 64 KiB: lowestMatchIndex slides
+    src, soff, slen = pack(blocks)
+    caps = [oracle.compress_bound(b.size) for b in blocks]
+    dst, doff, dcap = arena(caps)
+    out = emu.encode_hc_batch(src, soff, slen, dst, doff, dcap, level=level)
+    for i, b in enumerate(blocks):
+        if b.size == 0:
+            assert out[i] == 0
+            continue
+        r, w = oracle.compress_hc(b, level)
+        assert out[i] == r, f"block {i} ({b.size} B) level {level}"
+        assert dst[int(doff[i]):int(doff[i]) + r].tobytes() == w[:r].tobytes(), f"block {i} level {level}"
+    mask = np.ones(dst.size, bool)
+    for i in range(len(blocks)):
+        mask[int(doff[i]):int(doff[i]) + max(int(out[i]), 0)] = False
+    assert (dst[mask] == 0xCD).all()
+
+
+def test_encode_hc_limited_output(emu, oracle):
+    blocks, caps, wants = [], [], []
+    for name in ("dickens", "xml", "x-ray"):
+        b = corpus.class_bytes(name, 20000, 2)
+        r, w = oracle.compress_hc(b, 3)
+        for cap in (r, r - 1, r + 1, 10, 0):
+            blocks.append(b); caps.append(cap); wants.append(w[:r].tobytes() if cap >= r else None)
+    src, soff, slen = pack(blocks)
+    dst, doff, dcap = arena(caps)
+    out = emu.encode_hc_batch(src, soff, slen, dst, doff, dcap, level=3)
+    for i, w in enumerate(wants):
+        if w is None:
+            assert out[i] == -1
+        else:
+            assert out[i] == len(w) and dst[int(doff[i]):int(doff[i]) + len(w)].tobytes() == w
+        assert (dst[int(doff[i]) + int(dcap[i]):int(doff[i]) + int(dcap[i]) + 16] == 0xCD).all()

@@ -273,3 +273,63 @@ def test_full_size_config2_properties(oracle):
     for i in range(0, n, 7):
         assert comp_h[coff[i]:coff[i] + clen_h[i]].tobytes() == ref_dst[int(ref_off[i]):int(ref_off[i]) + int(want[i])].tobytes()
         assert (comp_h[coff[i] + clen_h[i]:coff[i] + caps[i]] == 0xCD).all()
+
+
+# ---- HC levels (BASELINE.json configs[4]) -----------------------------------
+@pytest.mark.parametrize("level", [LZ4Level.L03_HC, LZ4Level.L04_HC, LZ4Level.L06_HC, LZ4Level.L08_HC])
+def test_hc_single_block_roundtrip(oracle, level):
+    for data in (corpus.lorem(0x172a5), corpus.class_bytes("webster", 65536, 3), corpus.repeated(7, 1000)):
+        target = np.full(LZ4Codec.MaximumOutputSize(data.size), 0xCD, np.uint8)
+        n = LZ4Codec.Encode(data, target, level)
+        r, w = oracle.compress_hc(data, int(level))
+        assert n == r and target[:n].tobytes() == w[:r].tobytes() and (target[n:] == 0xCD).all()
+        out = np.zeros(data.size, np.uint8)
+        assert LZ4Codec.Decode(target[:n].copy(), out) == data.size and out.tobytes() == data.tobytes()
+
+
+def test_hc_batch_silesia_like_vs_oracle(oracle):
+    """configs[4] at reduced count: 64 KiB blocks, L03_HC, every block byte-compared; ratio equal"""
+    blocks = corpus.silesia_like_blocks(120, 65536, seed=2)
+    enc = LZ4Codec.EncodeBatch(list(blocks), LZ4Level.L03_HC)
+    total = 0
+    for i in range(blocks.shape[0]):
+        r, w = oracle.compress_hc(blocks[i], 3)
+        assert enc[i] == w[:r].tobytes(), i
+        total += r
+    assert sum(len(e) for e in enc) == total
+    dec = LZ4Codec.DecodeBatch(enc, [65536] * blocks.shape[0])
+    assert all(d == blocks[i].tobytes() for i, d in enumerate(dec))
+
+
+def test_hc_ragged_batch_and_limits(oracle):
+    sizes = [0, 1, 12, 13, 100, 4096, 65536, 70000, 300000]
+    blocks = [corpus.class_bytes(corpus.SILESIA_NAMES[(3 * i) % 12], s, i) if s else np.zeros(0, np.uint8)
+              for i, s in enumerate(sizes)]
+    enc = LZ4Codec.EncodeBatch(blocks, LZ4Level.L05_HC)
+    for i, b in enumerate(blocks):
+        if b.size == 0:
+            assert enc[i] == b""
+        else:
+            r, w = oracle.compress_hc(b, 5)
+            assert enc[i] == w[:r].tobytes(), i
+    # limitedOutput: exact size fits, one byte less does not
+    b = blocks[6]
+    r, w = oracle.compress_hc(b, 3)
+    assert LZ4Codec.Encode(b, np.zeros(r, np.uint8), LZ4Level.L03_HC) == r
+    assert LZ4Codec.Encode(b, np.zeros(r - 1, np.uint8), LZ4Level.L03_HC) < 0
+
+
+def test_hc_pickle_levels(oracle):
+    """PicklingTests.cs:11-50 at an HC level"""
+    msgs = [corpus.lorem(n) for n in (0, 10, 200, 1337, 0x10000)] + [corpus.random_bytes(5000, 3)]
+    ps = LZ4Pickler.PickleBatch(msgs, LZ4Level.L03_HC)
+    for m, p in zip(msgs, ps):
+        assert p == oracle.pickle(m, 3)
+    assert [LZ4Pickler.Unpickle(p) for p in ps] == [m.tobytes() for m in msgs]
+
+
+def test_unsupported_levels_fail_loudly():
+    data = corpus.lorem(5000)
+    for level in (LZ4Level.L09_HC, LZ4Level.L10_OPT, LZ4Level.L12_MAX):
+        with pytest.raises(NotImplementedError):
+            LZ4Codec.Encode(data, np.zeros(6000, np.uint8), level)
