@@ -92,10 +92,10 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
         K4_HIP(ctx, hipStreamSynchronize(stream));
         int rc = grow(ctx, &ctx->d_hc_hash, &ctx->d_hc_hash_cap, (size_t)cnt << (k4::HC_HASH_LOG + 2), false);
         if (rc != K4LZ4_OK) return rc;
-        rc = grow(ctx, &ctx->d_hc_meta, &ctx->d_hc_meta_cap, (size_t)(cnt + 1) * 8 + (size_t)cnt * 16 + 64, false);
+        rc = grow(ctx, &ctx->d_hc_meta, &ctx->d_hc_meta_cap, (size_t)(cnt + 2) * 8 + (size_t)cnt * 16 + 64, false);
         if (rc != K4LZ4_OK) return rc;
         unsigned long long *d_woff = (unsigned long long *)ctx->d_hc_meta;
-        uint64_t *d_encoff = (uint64_t *)(d_woff + cnt + 1);
+        uint64_t *d_encoff = (uint64_t *)(d_woff + cnt + 2);
         int32_t *d_enccap = (int32_t *)(d_encoff + cnt);
         int32_t *d_enclen = d_enccap + cnt;
         k4::HcArgs h{};
@@ -111,14 +111,22 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
             h.dstOff = d_encoff; h.dstCap = d_enccap; h.outLen = d_enclen; h.flags = K4LZ4_FLAG_RAW_RETURN;
         }
         hipLaunchKernelGGL(k4::k4_hc_layout_kernel, dim3(1), dim3(256), 0, stream, h);
-        unsigned long long total = 0;
-        K4_HIP(ctx, hipMemcpyAsync(&total, d_woff + cnt, 8, hipMemcpyDeviceToHost, stream));
+        unsigned long long tail[2] = {0, 0};   /* total work bytes, longest block */
+        K4_HIP(ctx, hipMemcpyAsync(tail, d_woff + cnt, 16, hipMemcpyDeviceToHost, stream));
         K4_HIP(ctx, hipStreamSynchronize(stream));
-        rc = grow(ctx, &ctx->d_hc_work, &ctx->d_hc_work_cap, (size_t)total + 256, false);
+        rc = grow(ctx, &ctx->d_hc_work, &ctx->d_hc_work_cap, (size_t)tail[0] + 256, false);
         if (rc != K4LZ4_OK) return rc;
         h.work = ctx->d_hc_work;
         K4_HIP(ctx, hipMemsetAsync(ctx->d_hc_hash, 0, (size_t)cnt << (k4::HC_HASH_LOG + 2), stream));
         hipLaunchKernelGGL(k4::k4_hc_chain_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
+        if (tail[1] >= 13) {
+            const unsigned gy = (unsigned)((tail[1] + k4::HC_CAND_POS_PER_WG - 1) / k4::HC_CAND_POS_PER_WG);
+            for (unsigned y0 = 0; y0 < gy; y0 += 65535u) {   /* grid.y limit */
+                k4::HcArgs hy = h;
+                hy.posBase = y0 * (unsigned)k4::HC_CAND_POS_PER_WG;
+                hipLaunchKernelGGL(k4::k4_hc_cand_kernel, dim3((unsigned)cnt, std::min(65535u, gy - y0)), dim3(256), 0, stream, hy);
+            }
+        }
         hipLaunchKernelGGL(k4::k4_hc_parse_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
         if (pickle) hipLaunchKernelGGL(k4::k4_pickle_finish_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a, d_enclen);
         K4_HIP(ctx, hipGetLastError());

@@ -32,7 +32,11 @@
  *                        candidate.
  *
  * Scratch (context-owned, device): per block a 128 KiB hash table (u32 x 32768, zero = empty with
- * positions stored +1), prev[U] (u32) and cand[U][4] (u32), see k4_hc_layout_kernel.
+ * positions stored +1), prev[U] (u32), cand[U][4] (u32), flen[U][4] and blen[U][4] (u16: forward /
+ * backward match length of position p against its k-th candidate, exact below HC_FLEN_CAP /
+ * HC_BLEN_CAP), see k4_hc_layout_kernel.  With the lengths precomputed, level 3 (4 attempts =
+ * exactly one record) needs no data compare at all in the common case: a search is one record
+ * load, literal runs are skipped 64 positions per load.
  */
 #pragma once
 #include "k4lz4_common.hpp"
@@ -56,25 +60,38 @@ struct HcArgs {
     int flags;
     uint32_t *hash;            /* n x 32768, zeroed before k4_hc_chain_kernel */
     uint8_t *work;             /* prev[] and cand[] of every block */
-    unsigned long long *workOff;   /* n + 1: byte offset of block i's work area (k4_hc_layout_kernel) */
+    unsigned int posBase;      /* k4_hc_cand_kernel: first position covered by blockIdx.y == 0 */
+    unsigned long long *workOff;   /* n + 2: byte offset of block i's work area, [n] = total, [n+1] = longest block (k4_hc_layout_kernel) */
 };
 
 __device__ __forceinline__ uint32_t hc_hash(uint32_t v) { return (v * 2654435761u) >> (MINMATCH * 8 - HC_HASH_LOG); }
-__device__ __forceinline__ uint64_t hc_work_bytes(int len) { return len > 0 ? (((uint64_t)len + 3u) & ~3ull) * 20u : 0u; }
+constexpr uint32_t HC_FLEN_CAP = 4 + 32;   /* precomputed match lengths are exact below this value */
+constexpr uint32_t HC_BLEN_CAP = 32;       /* precomputed backward lengths are exact below this value */
+__device__ __forceinline__ uint64_t hc_work_bytes(int len) { return len > 0 ? (((uint64_t)len + 3u) & ~3ull) * 36u : 0u; }
 
 /* exclusive scan of the per-block work sizes (one workgroup; n is at most a launch chunk) */
 __global__ __launch_bounds__(256) void k4_hc_layout_kernel(HcArgs a)
 {
     __shared__ unsigned long long part[256];
+    __shared__ unsigned long long pmax[256];
     const int t = (int)threadIdx.x;
     const long long per = (a.n + 255) / 256;
     const long long lo = (long long)t * per, hi = lo + per < a.n ? lo + per : a.n;
-    unsigned long long s = 0;
-    for (long long i = lo; i < hi; i++) s += hc_work_bytes(a.srcLen[i]);
+    unsigned long long s = 0, mx = 0;
+    for (long long i = lo; i < hi; i++) {
+        s += hc_work_bytes(a.srcLen[i]);
+        if (a.srcLen[i] > 0 && (unsigned long long)a.srcLen[i] > mx) mx = (unsigned long long)a.srcLen[i];
+    }
     part[t] = s;
+    pmax[t] = mx;
     __syncthreads();
     unsigned long long base = 0;
     for (int k = 0; k < t; k++) base += part[k];
+    if (t == 0) {
+        unsigned long long m = 0;
+        for (int k = 0; k < 256; k++) m = pmax[k] > m ? pmax[k] : m;
+        a.workOff[a.n + 1] = m;
+    }
     for (long long i = lo; i < hi; i++) {
         a.workOff[i] = base;
         base += hc_work_bytes(a.srcLen[i]);
@@ -93,7 +110,6 @@ __global__ __launch_bounds__(64) void k4_hc_chain_kernel(HcArgs a)
     const uint8_t *src = a.src + a.srcOff[b];
     uint32_t *tab = a.hash + (size_t)b * (1u << HC_HASH_LOG);
     uint32_t *prev = (uint32_t *)(a.work + a.workOff[b]);
-    uint32_t *cand = prev + ((U + 3u) & ~3u);
     const uint32_t npos = U - 3u;                          /* positions whose 4 bytes exist */
 
     /* prev[p] = nearest earlier position with the same hash (HC_NONE if there is none) */
@@ -120,16 +136,73 @@ __global__ __launch_bounds__(64) void k4_hc_chain_kernel(HcArgs a)
         if (last) tab[h] = p + 1u;
         wave_sync();
     }
+}
+
+/* ---- kernel 1b: candidates + forward lengths, every position independently ------------------ */
+constexpr int HC_CAND_POS_PER_WG = 1024;
+__global__ __launch_bounds__(256) void k4_hc_cand_kernel(HcArgs a)
+{
+    const long long b = (long long)blockIdx.x;
+    const int len = a.srcLen[b];
+    if (len < MFLIMIT + 1) return;
+    const uint32_t U = (uint32_t)len;
+    const uint32_t npos = U - 3u;
+    const uint32_t first = a.posBase + (uint32_t)blockIdx.y * (uint32_t)HC_CAND_POS_PER_WG;
+    if (first >= npos) return;
+    const uint8_t *src = a.src + a.srcOff[b];
+    const uint32_t *prev = (const uint32_t *)(a.work + a.workOff[b]);
+    uint32_t *cand = (uint32_t *)prev + ((U + 3u) & ~3u);
+    uint2 *flen = (uint2 *)(cand + 4u * ((U + 3u) & ~3u));
+    uint2 *blen = flen + ((U + 3u) & ~3u);
     /* first four chain candidates of every position; a chain step of 65535 or more ends the walk
      * (LL.high.cs:114 caps the delta, and such a candidate is below lowestMatchIndex) */
-    for (uint32_t p0 = 0; p0 < npos; p0 += 64u) {
-        const uint32_t p = p0 + (uint32_t)lane;
+    for (uint32_t p = first + threadIdx.x; p < first + (uint32_t)HC_CAND_POS_PER_WG; p += 256u) {
         if (p < npos) {
             uint32_t c0 = prev[p], c1 = HC_NONE, c2 = HC_NONE, c3 = HC_NONE;
             if (c0 != HC_NONE) { const uint32_t q = prev[c0]; if (q != HC_NONE && c0 - q < (uint32_t)DISTANCE_MAX) c1 = q; }
             if (c1 != HC_NONE) { const uint32_t q = prev[c1]; if (q != HC_NONE && c1 - q < (uint32_t)DISTANCE_MAX) c2 = q; }
             if (c2 != HC_NONE) { const uint32_t q = prev[c2]; if (q != HC_NONE && c2 - q < (uint32_t)DISTANCE_MAX) c3 = q; }
             ((uint4 *)cand)[p] = make_uint4(c0, c1, c2, c3);
+            /* forward match length against each candidate a search at p may use (:87-88 lowest,
+             * :120 4-byte test, :126 LZ4_count up to matchlimit), capped at HC_FLEN_CAP */
+            const uint32_t lowest = p > (uint32_t)DISTANCE_MAX ? p - (uint32_t)DISTANCE_MAX : 0u;
+            const uint32_t matchlimit = U - LASTLITERALS;
+            const uint32_t maxn = p + MINMATCH < matchlimit ? matchlimit - (p + MINMATCH) : 0u;
+            const uint32_t seq = ld32u(src + p);
+            uint32_t fl[4], bl[4];
+            bool chain_ok = true;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t c = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
+                chain_ok = chain_ok && c != HC_NONE && c >= lowest;
+                uint32_t f = 0;
+                if (chain_ok && ld32u(src + c) == seq) {
+                    uint32_t i = 0;
+                    const uint32_t lim = maxn < HC_FLEN_CAP - MINMATCH ? maxn : HC_FLEN_CAP - MINMATCH;
+                    while (i + 8u <= lim) {
+                        const uint64_t x = ld64u(src + p + MINMATCH + i) ^ ld64u(src + c + MINMATCH + i);
+                        if (x) { i += (uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3; break; }
+                        i += 8u;
+                    }
+                    if (i + 8u > lim) while (i < lim && src[p + MINMATCH + i] == src[c + MINMATCH + i]) i++;
+                    f = MINMATCH + i;
+                }
+                fl[k] = f;
+                /* equal bytes before the two positions (LZ4HC_countBack without its limits) */
+                uint32_t bk = 0;
+                if (f) {
+                    const uint32_t blim = c < HC_BLEN_CAP ? c : HC_BLEN_CAP;       /* c < p */
+                    while (bk + 8u <= blim) {
+                        const uint64_t x = ld64u(src + p - 8u - bk) ^ ld64u(src + c - 8u - bk);
+                        if (x) { bk += (uint32_t)__clzll((unsigned long long)x) >> 3; break; }
+                        bk += 8u;
+                    }
+                    if (bk + 8u > blim) while (bk < blim && src[p - 1u - bk] == src[c - 1u - bk]) bk++;
+                }
+                bl[k] = bk;
+            }
+            flen[p] = make_uint2(fl[0] | (fl[1] << 16), fl[2] | (fl[3] << 16));
+            blen[p] = make_uint2(bl[0] | (bl[1] << 16), bl[2] | (bl[3] << 16));
         }
     }
 }
@@ -238,9 +311,71 @@ __device__ __forceinline__ HcMatch hc_search(const uint8_t *src, const uint32_t 
     return r;
 }
 
+/* one position's precomputed record, wave-uniform */
+struct HcRec { uint32_t c0, c1, c2, c3, fl01, fl23, bl01, bl23; };
+
+__device__ __forceinline__ HcRec hc_load_rec(const uint32_t *cand, const uint2 *flen, const uint2 *blen, uint32_t p)
+{
+    const uint4 rc = ((const uint4 *)cand)[p];
+    const uint2 f = flen[p], b = blen[p];
+    HcRec r;
+    r.c0 = uni(rc.x); r.c1 = uni(rc.y); r.c2 = uni(rc.z); r.c3 = uni(rc.w);
+    r.fl01 = uni(f.x); r.fl23 = uni(f.y); r.bl01 = uni(b.x); r.bl23 = uni(b.y);
+    return r;
+}
+
+/* the records of 64 consecutive positions, one per lane (loaded by the literal-run scan) */
+struct HcWindow { uint32_t base; bool valid; uint4 rc; uint2 f, b; };
+
+__device__ __forceinline__ HcRec hc_get_rec(const HcWindow &w, const uint32_t *cand, const uint2 *flen, const uint2 *blen, uint32_t p)
+{
+    if (w.valid && p - w.base < 64u) {
+        const int l = (int)(p - w.base);
+        HcRec r;
+        r.c0 = __builtin_amdgcn_readlane(w.rc.x, l); r.c1 = __builtin_amdgcn_readlane(w.rc.y, l);
+        r.c2 = __builtin_amdgcn_readlane(w.rc.z, l); r.c3 = __builtin_amdgcn_readlane(w.rc.w, l);
+        r.fl01 = __builtin_amdgcn_readlane(w.f.x, l); r.fl23 = __builtin_amdgcn_readlane(w.f.y, l);
+        r.bl01 = __builtin_amdgcn_readlane(w.b.x, l); r.bl23 = __builtin_amdgcn_readlane(w.b.y, l);
+        return r;
+    }
+    return hc_load_rec(cand, flen, blen, p);
+}
+
+/*
+ * The same search when the whole chain walk is one record (level 3: 4 attempts): match lengths
+ * come from the precomputed record, nothing is compared.  Falls back to hc_search when a length
+ * sits at its cap and could be longer.
+ */
+__device__ __forceinline__ HcMatch hc_search_l3(const uint8_t *src, const uint32_t *cand, const HcRec &rec, uint32_t ip, uint32_t ilow,
+                                                uint32_t matchlimit, int longest, uint32_t mpos, uint32_t spos, int lane)
+{
+    const uint32_t l0 = rec.fl01 & 0xffffu, l1 = rec.fl01 >> 16, l2 = rec.fl23 & 0xffffu, l3 = rec.fl23 >> 16;
+    const uint32_t look_back = ip - ilow;
+    bool slow = l0 == HC_FLEN_CAP || l1 == HC_FLEN_CAP || l2 == HC_FLEN_CAP || l3 == HC_FLEN_CAP;
+    uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    if (look_back) {                                        /* LZ4HC_countBack = min(equal bytes, ip - ilow, match - 0) */
+        const uint32_t s0 = rec.bl01 & 0xffffu, s1 = rec.bl01 >> 16, s2 = rec.bl23 & 0xffffu, s3 = rec.bl23 >> 16;
+        const uint32_t m0 = look_back < rec.c0 ? look_back : rec.c0, m1 = look_back < rec.c1 ? look_back : rec.c1,
+                       m2 = look_back < rec.c2 ? look_back : rec.c2, m3 = look_back < rec.c3 ? look_back : rec.c3;
+        b0 = s0 < m0 ? s0 : m0; b1 = s1 < m1 ? s1 : m1; b2 = s2 < m2 ? s2 : m2; b3 = s3 < m3 ? s3 : m3;
+        slow = slow || (l0 && s0 == HC_BLEN_CAP && m0 > HC_BLEN_CAP) || (l1 && s1 == HC_BLEN_CAP && m1 > HC_BLEN_CAP) ||
+               (l2 && s2 == HC_BLEN_CAP && m2 > HC_BLEN_CAP) || (l3 && s3 == HC_BLEN_CAP && m3 > HC_BLEN_CAP);
+    }
+    if (slow) return hc_search(src, cand, ip, ilow, matchlimit, longest, mpos, spos, 4, lane);
+    HcMatch r;
+    r.len = longest; r.mpos = mpos; r.spos = spos;
+    const int m0 = l0 ? (int)(l0 + b0) : 0, m1 = l1 ? (int)(l1 + b1) : 0, m2 = l2 ? (int)(l2 + b2) : 0, m3 = l3 ? (int)(l3 + b3) : 0;
+    if (m0 > r.len) { r.len = m0; r.mpos = rec.c0 - b0; r.spos = ip - b0; }
+    if (m1 > r.len) { r.len = m1; r.mpos = rec.c1 - b1; r.spos = ip - b1; }
+    if (m2 > r.len) { r.len = m2; r.mpos = rec.c2 - b2; r.spos = ip - b2; }
+    if (m3 > r.len) { r.len = m3; r.mpos = rec.c3 - b3; r.spos = ip - b3; }
+    return r;
+}
+
 /* LZ4HC_encodeSequence (LL64.high.cs:435-510); returns false on output overflow */
 __device__ __forceinline__ bool hc_encode_sequence(const uint8_t *src, uint8_t *dst, uint32_t &ip, int64_t &op, uint32_t &anchor,
-                                                   int match_length, uint32_t match, bool limited, int64_t oend, int lane)
+                                                   int match_length, uint32_t match, bool limited, int64_t oend, int lane,
+                                                   uint32_t pf_anchor = HC_NONE, uint8_t pf_byte = 0)
 {
     const uint32_t token_pos = (uint32_t)op;
     op++;
@@ -257,7 +392,11 @@ __device__ __forceinline__ bool hc_encode_sequence(const uint8_t *src, uint8_t *
     } else {
         token = length << ML_BITS;
     }
-    wave_copy(dst + op, src + anchor, length, lane);
+    if (anchor == pf_anchor && length <= 64u) {            /* literal bytes were requested ahead of time */
+        if ((uint32_t)lane < length) dst[op + lane] = pf_byte;
+    } else {
+        wave_copy(dst + op, src + anchor, length, lane);
+    }
     op += length;
     if (lane == 0) {
         const uint32_t off = ip - match;
@@ -292,9 +431,13 @@ __device__ __forceinline__ int hc_nb_searches(int level)
 }
 
 /* LZ4HC_compress_hashChain (LL64.high.cs:512-800) for one block; returns bytes written, 0 = overflow */
+template <bool L3>
 __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap, int level,
-                                              const uint32_t *cand, int lane)
+                                              const uint32_t *cand, const uint2 *flen, const uint2 *blen, int lane)
 {
+#define K4_HC_SEARCH(P, LOW, LONGEST, MPOS, SPOS) \
+    (L3 ? hc_search_l3(src, cand, hc_get_rec(win, cand, flen, blen, (P)), (P), (LOW), matchlimit, (LONGEST), (MPOS), (SPOS), lane) \
+        : hc_search(src, cand, (P), (LOW), matchlimit, (LONGEST), (MPOS), (SPOS), max_attempts, lane))
     if ((uint32_t)src_len > (uint32_t)MAX_INPUT_SIZE) return 0;      /* :1153 */
     const bool limited = dst_cap < compress_bound(src_len);         /* :1348 */
     const int64_t oend = dst_cap;
@@ -302,12 +445,39 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
     const uint32_t U = (uint32_t)src_len;
     uint32_t ip = 0, anchor = 0;
     int64_t op = 0;
+    HcWindow win;
+    win.base = 0; win.valid = false;
+    win.rc = make_uint4(0u, 0u, 0u, 0u); win.f = make_uint2(0u, 0u); win.b = make_uint2(0u, 0u);
 
     if (src_len >= MFLIMIT + 1) {
         const uint32_t mflimit = U - MFLIMIT;
         const uint32_t matchlimit = U - LASTLITERALS;
         while (ip <= mflimit) {
-            HcMatch m = hc_search(src, cand, ip, ip, matchlimit, MINMATCH - 1, 0, ip, max_attempts, lane);
+            uint32_t pf_anchor = HC_NONE;
+            uint8_t pf_byte = 0;
+            HcMatch m;
+            if (L3) {
+                /* positions without a 4-byte candidate match cannot start a sequence: literal runs
+                 * are skipped 64 positions per load of the precomputed records, and the record of
+                 * the first position that can is already in registers */
+                const uint32_t pos = ip + (uint32_t)lane;
+                win.rc = make_uint4(0u, 0u, 0u, 0u);
+                win.f = make_uint2(0u, 0u);
+                win.b = make_uint2(0u, 0u);
+                if (pos < U - 3u) { win.rc = ((const uint4 *)cand)[pos]; win.f = flen[pos]; win.b = blen[pos]; }
+                win.base = ip;
+                win.valid = true;
+                if (anchor + (uint32_t)lane < U) pf_byte = src[anchor + (uint32_t)lane];
+                pf_anchor = anchor;
+                const unsigned long long hm = __ballot(pos <= mflimit && (win.f.x | win.f.y) != 0u);
+                if (!hm) { ip += 64u; continue; }
+                const int fz = ctz64(hm);
+                ip += (uint32_t)fz;
+                const HcRec rec = hc_get_rec(win, cand, flen, blen, ip);
+                m = hc_search_l3(src, cand, rec, ip, ip, matchlimit, MINMATCH - 1, 0u, ip, lane);
+            } else {
+                m = hc_search(src, cand, ip, ip, matchlimit, MINMATCH - 1, 0u, ip, max_attempts, lane);
+            }
             int ml = m.len;
             uint32_t ref = m.mpos;
             if (ml < MINMATCH) { ip++; continue; }
@@ -319,13 +489,13 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
             for (;;) {   /* one pass = _Search2 (if requested) followed by _Search3 rounds */
                 if (go_search2) {
                     if (ip + (uint32_t)ml <= mflimit) {
-                        const HcMatch m2 = hc_search(src, cand, ip + (uint32_t)ml - 2u, ip, matchlimit, ml, ref2, start2, max_attempts, lane);
+                        const HcMatch m2 = K4_HC_SEARCH(ip + (uint32_t)ml - 2u, ip, ml, ref2, start2);
                         ml2 = m2.len; ref2 = m2.mpos; start2 = m2.spos;
                     } else {
                         ml2 = ml;
                     }
                     if (ml2 == ml) {                           /* no better match: encode ML1 */
-                        if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane)) return 0;
+                        if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane, pf_anchor, pf_byte)) return 0;
                         break;
                     }
                     if (start0 < ip) {
@@ -346,14 +516,14 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
                     if (correction > 0) { start2 += (uint32_t)correction; ref2 += (uint32_t)correction; ml2 -= correction; }
                 }
                 if (start2 + (uint32_t)ml2 <= mflimit) {
-                    const HcMatch m3 = hc_search(src, cand, start2 + (uint32_t)ml2 - 3u, start2, matchlimit, ml2, ref3, start3, max_attempts, lane);
+                    const HcMatch m3 = K4_HC_SEARCH(start2 + (uint32_t)ml2 - 3u, start2, ml2, ref3, start3);
                     ml3 = m3.len; ref3 = m3.mpos; start3 = m3.spos;
                 } else {
                     ml3 = ml2;
                 }
                 if (ml3 == ml2) {                              /* no better match: encode ML1 and ML2 */
                     if (start2 < ip + (uint32_t)ml) ml = (int)(start2 - ip);
-                    if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane)) return 0;
+                    if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane, pf_anchor, pf_byte)) return 0;
                     ip = start2;
                     if (!hc_encode_sequence(src, dst, ip, op, anchor, ml2, ref2, limited, oend, lane)) return 0;
                     break;
@@ -365,7 +535,7 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
                             start2 += (uint32_t)correction; ref2 += (uint32_t)correction; ml2 -= correction;
                             if (ml2 < MINMATCH) { start2 = start3; ref2 = ref3; ml2 = ml3; }
                         }
-                        if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane)) return 0;
+                        if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane, pf_anchor, pf_byte)) return 0;
                         ip = start3; ref = ref3; ml = ml3;
                         start0 = start2; ref0 = ref2; ml0 = ml2;
                         go_search2 = true;
@@ -385,7 +555,7 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
                         ml = (int)(start2 - ip);
                     }
                 }
-                if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane)) return 0;
+                if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane, pf_anchor, pf_byte)) return 0;
                 ip = start2; ref = ref2; ml = ml2;             /* ML2 becomes ML1, ML3 becomes ML2 */
                 start2 = start3; ref2 = ref3; ml2 = ml3;
                 /* goto _Search3 */
@@ -412,6 +582,7 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
         op += last_run;
     }
     return (int)op;
+#undef K4_HC_SEARCH
 }
 
 __global__ __launch_bounds__(64) void k4_hc_parse_kernel(HcArgs a)
@@ -423,8 +594,14 @@ __global__ __launch_bounds__(64) void k4_hc_parse_kernel(HcArgs a)
     int ret = 0;
     if (src_len > 0 || (a.flags & FLAG_RAW_RETURN)) {
         const uint32_t *prev = (const uint32_t *)(a.work + a.workOff[b]);
-        const uint32_t *cand = prev + (((uint32_t)(src_len > 0 ? src_len : 0) + 3u) & ~3u);
-        ret = hc_parse_block(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.level, cand, lane);
+        const uint32_t al = ((uint32_t)(src_len > 0 ? src_len : 0) + 3u) & ~3u;
+        const uint32_t *cand = prev + al;
+        const uint2 *flen = (const uint2 *)(cand + 4u * al);
+        const uint2 *blen = flen + al;
+        const uint8_t *s = a.src + a.srcOff[b];
+        uint8_t *d = a.dst + a.dstOff[b];
+        if (hc_nb_searches(a.level) <= 4) ret = hc_parse_block<true>(s, src_len, d, cap < 0 ? 0 : cap, a.level, cand, flen, blen, lane);
+        else ret = hc_parse_block<false>(s, src_len, d, cap < 0 ? 0 : cap, a.level, cand, flen, blen, lane);
     }
     if (lane == 0) {
         int r = ret;

@@ -49,14 +49,18 @@ int k4emu_encode_hc_batch(const uint8_t *src, const uint64_t *srcOff, const int3
                           int flags, int threads)
 {
     if (n <= 0) return 0;
-    std::vector<unsigned long long> off((size_t)n + 1);
-    k4::HcArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, nullptr, nullptr, off.data()};
+    std::vector<unsigned long long> off((size_t)n + 2);
+    k4::HcArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, nullptr, nullptr, 0u, off.data()};
     k4emu::launch_fn(dim3(1), dim3(256), [=] { k4::k4_hc_layout_kernel(a); }, 1);
     std::vector<uint32_t> hash((size_t)n << k4::HC_HASH_LOG, 0u);
     std::vector<uint8_t> work((size_t)off[(size_t)n] + 64);
     a.hash = hash.data();
     a.work = work.data();
     k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_hc_chain_kernel(a); }, threads);
+    if (off[(size_t)n + 1] >= 13) {
+        const unsigned gy = (unsigned)((off[(size_t)n + 1] + k4::HC_CAND_POS_PER_WG - 1) / k4::HC_CAND_POS_PER_WG);
+        k4emu::launch_fn(dim3((unsigned)n, gy), dim3(256), [=] { k4::k4_hc_cand_kernel(a); }, threads);
+    }
     k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_hc_parse_kernel(a); }, threads);
     return 0;
 }
