@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <memory>
@@ -37,6 +38,9 @@ struct k4lz4_ctx {
     uint8_t *d_meta = nullptr; size_t d_meta_cap = 0;
     uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;
     uint8_t *d_sched = nullptr; size_t d_sched_cap = 0;   /* dispatch-order scratch: cost[n], order[n], counters */
+    uint8_t *d_gtab = nullptr; size_t d_gtab_cap = 0;         /* fast encoder: hash tables of the blocks encoded without an LDS table */
+    hipStream_t aux = nullptr;                                /* second queue: those blocks run beside the LDS-table kernel */
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint8_t *d_hc_hash = nullptr; size_t d_hc_hash_cap = 0;   /* HC: per-block hash tables of one launch chunk */
     uint8_t *d_hc_work = nullptr; size_t d_hc_work_cap = 0;   /* HC: prev[] / cand[] of one launch chunk */
     uint8_t *d_hc_meta = nullptr; size_t d_hc_meta_cap = 0;   /* HC: work offsets, pickle slots */
@@ -176,6 +180,32 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
         switch (kind) {
         case KIND_ENCODE:
             if (a.prof) hipLaunchKernelGGL(k4::k4_encode_fast_prof_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a);
+            else if (reorder && cnt > 512 && !(flags & K4LZ4_FLAG_NO_SPLIT)) {
+                /* Only 8 blocks per CU fit with their hash table in LDS.  The most expensive blocks
+                 * (front of the dispatch order) take those slots; the others are encoded at the same
+                 * time on a second queue by the global-memory-table variant of the kernel. */
+                const char *pct_env = getenv("K4LZ4_SPLIT_PCT");
+                const int64_t pct = pct_env ? atoi(pct_env) : 45;
+                const int64_t n_lds = pct_env ? std::max<int64_t>(1, cnt * pct / 100) : std::max<int64_t>(std::min<int64_t>(cnt, 2048), cnt * 45 / 100);
+                const int64_t n_g = cnt - n_lds;
+                const int64_t gchunk = 8192;
+                if ((size_t)std::min(n_g, gchunk) * 16384 > ctx->d_gtab_cap) {
+                    K4_HIP(ctx, hipStreamSynchronize(ctx->aux));
+                    int rc2 = grow(ctx, &ctx->d_gtab, &ctx->d_gtab_cap, (size_t)std::min(n_g, gchunk) * 16384, false);
+                    if (rc2 != K4LZ4_OK) return rc2;
+                }
+                K4_HIP(ctx, hipEventRecord(ctx->ev_fork, stream));
+                K4_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+                for (int64_t g0 = 0; g0 < n_g; g0 += gchunk) {
+                    k4::BatchArgs ag = a;
+                    ag.order = a.order + n_lds + g0;
+                    ag.gtab = (uint32_t *)ctx->d_gtab;
+                    hipLaunchKernelGGL(k4::k4_encode_fast_gtab_kernel, dim3((unsigned)std::min(gchunk, n_g - g0)), dim3(64), 0, ctx->aux, ag);
+                }
+                K4_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+                hipLaunchKernelGGL(k4::k4_encode_fast_kernel, dim3((unsigned)n_lds), dim3(64), 0, stream, a);
+                K4_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_join, 0));
+            }
             else hipLaunchKernelGGL(k4::k4_encode_fast_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a);
             break;
         case KIND_DECODE:
@@ -360,6 +390,9 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     ctx->device = device;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) { delete ctx; return hip_fail(nullptr, e, "hipStreamCreate"); }
     *out = ctx;
     return K4LZ4_OK;
@@ -370,6 +403,10 @@ void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
     if (ctx->d_src) (void)hipFree(ctx->d_src);
     if (ctx->d_dst) (void)hipFree(ctx->d_dst);
     if (ctx->d_meta) (void)hipFree(ctx->d_meta);

@@ -51,6 +51,7 @@ struct BatchArgs {
     uint32_t *cost;            /* scheduling scratch: cost bucket per block */
     uint32_t *hist;            /* scheduling scratch: 2 x COST_BUCKETS counters (zeroed) */
     uint32_t *order_out;       /* scheduling scratch: the order being built */
+    uint32_t *gtab;            /* k4_encode_fast_gtab_kernel: 4096 dwords of table per workgroup */
 };
 
 struct __attribute__((packed, aligned(1))) U16u { uint16_t v; };

@@ -175,7 +175,7 @@ __device__ __forceinline__ Around load_around(const uint8_t *src, uint32_t p)
 template <bool BYU16, bool PROF = false>
 __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
                                                  uint32_t accel, uint32_t *ldsw, int lane, unsigned long long *pc = nullptr,
-                                                 bool dry = false, uint32_t *seq_count = nullptr)
+                                                 bool dry = false, uint32_t *seq_count = nullptr, uint32_t *gtab = nullptr)
 {
     uint32_t sequences = 0;
     unsigned long long c_probe = 0, c_ext = 0, c_emit = 0, n_seq = 0, n_round = 0, n_dup = 0, n_rt3 = 0;
@@ -187,14 +187,16 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
     const int64_t olimit = dst_cap;
     const uint32_t U = (uint32_t)src_len;
     FastTable<BYU16> tab;
-    tab.t = (decltype(tab.t))ldsw;
+    /* the table normally lives in LDS; `gtab` (16 KiB of global memory) lets more blocks run per CU */
+    uint32_t *const tabmem = gtab ? gtab : ldsw;
+    tab.t = (decltype(tab.t))tabmem;
     OutStage st;
-    st.lds = (uint8_t *)(ldsw + 4096);
+    st.lds = (uint8_t *)(gtab ? ldsw : ldsw + 4096);
     st.dst = dst;
     st.base = 0;
     st.dry = dry;
 
-    for (int k = lane; k < 1024; k += 64) ((uint4 *)ldsw)[k] = make_uint4(0u, 0u, 0u, 0u);
+    for (int k = lane; k < 1024; k += 64) ((uint4 *)tabmem)[k] = make_uint4(0u, 0u, 0u, 0u);
     wave_sync();
 
     uint32_t anchor = 0;
@@ -446,11 +448,11 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
 
 /* LL64.LZ4_compress_fast (LL64.fast.cs:517-576): table type by input size */
 __device__ __forceinline__ int compress_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
-                                                   int accel, uint32_t *ldsw, int lane)
+                                                   int accel, uint32_t *ldsw, int lane, uint32_t *gtab = nullptr)
 {
     const uint32_t a = accel < 1 ? 1u : (accel > 65536 ? 65536u : (uint32_t)accel);
-    if (src_len < LIMIT_64K) return encode_fast_block<true>(src, src_len, dst, dst_cap, a, ldsw, lane);
-    return encode_fast_block<false>(src, src_len, dst, dst_cap, a, ldsw, lane);
+    if (src_len < LIMIT_64K) return encode_fast_block<true>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
+    return encode_fast_block<false>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
 }
 
 /* LZ4Codec.Encode mapping (LZ4Codec.cs:40-52) */
@@ -527,6 +529,22 @@ __global__ __launch_bounds__(64) void k4_encode_fast_kernel(BatchArgs a)
     uint8_t *dst = a.dst + a.dstOff[b];
     int ret = 0;
     if (src_len > 0 || (a.flags & FLAG_RAW_RETURN)) ret = compress_fast_block(src, src_len, dst, cap < 0 ? 0 : cap, a.accel, tab, lane);
+    if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
+}
+
+/* the same encoder with its hash table in global memory (a.gtab: 16 KiB per workgroup slot) and
+ * only the output stage in LDS: twice as many blocks resident per CU, each a little slower */
+__global__ __launch_bounds__(64) void k4_encode_fast_gtab_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t stage[ENCODE_STAGE_BYTES / 4];
+    const int lane = lane_id();
+    const long long b = a.order ? (long long)uni(a.order[blockIdx.x]) : (long long)blockIdx.x;
+    const int src_len = a.srcLen[b];
+    const int cap = a.dstCap[b];
+    int ret = 0;
+    if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
+        ret = compress_fast_block(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.accel, stage, lane,
+                                  a.gtab + 4096ull * (unsigned long long)blockIdx.x);
     if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
 }
 
