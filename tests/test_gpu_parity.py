@@ -333,3 +333,23 @@ def test_unsupported_levels_fail_loudly():
     for level in (LZ4Level.L09_HC, LZ4Level.L10_OPT, LZ4Level.L12_MAX):
         with pytest.raises(NotImplementedError):
             LZ4Codec.Encode(data, np.zeros(6000, np.uint8), level)
+
+
+def test_dispatch_variants_give_identical_bytes(oracle):
+    """cost-ordered dispatch and the LDS-table / global-memory-table split are scheduling only:
+    K4LZ4_FLAG_NO_REORDER (4) and K4LZ4_FLAG_NO_SPLIT (16) must not change a byte"""
+    blocks = corpus.silesia_like_blocks(1200, 16384, seed=9)
+    n = blocks.shape[0]
+    src = blocks.reshape(-1)
+    off = np.arange(n, dtype=np.uint64) * 16384
+    lens = np.full(n, 16384, np.int32)
+    caps = np.full(n, LZ4Codec.MaximumOutputSize(16384), np.int32)
+    outs = []
+    for flags in (0, 4, 16, 4 | 16):
+        dst, doff = make_arena(caps, fill=0xCD)
+        out = LZ4Codec.EncodeBatchPacked(src, off, lens, dst, doff, caps, flags=flags)
+        outs.append((out.copy(), dst.copy()))
+    ref_dst = np.full_like(outs[0][1], 0xCD)
+    want = oracle.encode_batch(src, off, lens, ref_dst, make_arena(caps)[1], caps, threads=8)
+    for out, dst in outs:
+        assert np.array_equal(out, want) and np.array_equal(dst, ref_dst)
