@@ -59,7 +59,8 @@ enum k4lz4_flags {
     K4LZ4_FLAG_PICKLE_WRITER = 2, /* LZ4Pickler IBufferWriter path header rule (LZ4Pickler.pickle.cs:113-158) */
     K4LZ4_FLAG_NO_REORDER = 4,    /* encode/pickle: dispatch blocks in index order instead of most-expensive-first */
     K4LZ4_FLAG_REORDER = 8,       /* decode/unpickle: dispatch longest inputs first (useful for ragged batches) */
-    K4LZ4_FLAG_NO_SPLIT = 16      /* encode: do not run part of the batch on the global-memory-table kernel */
+    K4LZ4_FLAG_NO_SPLIT = 16,     /* encode: do not run part of the batch on the global-memory-table kernel */
+    K4LZ4_FLAG_PARTIAL = 32       /* decode: LZ4Codec.PartialDecode -- stop once dstCap[i] bytes are produced (LZ4Codec.cs:123-173) */
 };
 
 K4LZ4_API int k4lz4_version(void);
@@ -90,6 +91,13 @@ K4LZ4_API int k4lz4_compress_fast(const uint8_t *src, uint8_t *dst, int srcLen, 
 K4LZ4_API int k4lz4_compress_hc(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap, int level);
 /* LLxx.LZ4_decompress_safe (Engine/LLxx.cs:17-26) */
 K4LZ4_API int k4lz4_decompress_safe(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap);
+/* LLxx.LZ4_decompress_safe_partial (Engine/LLxx.cs:29-39): decoding stops at targetLen bytes */
+K4LZ4_API int k4lz4_decompress_safe_partial(const uint8_t *src, uint8_t *dst, int srcLen, int targetLen);
+/* LLxx.LZ4_decompress_safe_usingDict (Engine/LLxx.cs:41-55; LL64.dec.cs:523-546) behind
+ * LZ4Codec.Decode(source, target, dictionary) (LZ4Codec.cs:144-160).  A dictionary that ends exactly at dst is
+ * decoded with the reference's prefix semantics, any other one with its external-dictionary semantics. */
+K4LZ4_API int k4lz4_decompress_safe_using_dict(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap,
+                                               const uint8_t *dict, int dictLen);
 
 /* ---- batches of independent blocks (what LZ4Codec.Encode / Decode callers loop over) --------
  * block i: input  src + srcOff[i], srcLen[i] bytes;  output dst + dstOff[i], dstCap[i] bytes.
@@ -110,6 +118,20 @@ K4LZ4_API int k4lz4_encode_batch_device(k4lz4_ctx *ctx, const uint8_t *src, cons
 K4LZ4_API int k4lz4_decode_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff,
                                         const int32_t *srcLen, uint8_t *dst, const uint64_t *dstOff,
                                         const int32_t *dstCap, int32_t *outLen, int64_t n, int flags, void *stream);
+
+/* Batched LZ4Codec.Decode(source, target, dictionary): block i is decoded against
+ * dict[dictOff[i] .. dictOff[i]+dictLen[i]) (dictLen[i] <= 0: no dictionary).  Chained blocks of one
+ * stream (LZ4ChainDecoder's layout: each block's dictionary is the previous 64 KiB of output) are NOT a
+ * batch -- they depend on each other; independent streams each holding a dictionary are. */
+K4LZ4_API int k4lz4_decode_dict_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+                                      uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen,
+                                      int64_t n, int flags, const uint8_t *dict, const uint64_t *dictOff,
+                                      const int32_t *dictLen);
+K4LZ4_API int k4lz4_decode_dict_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff,
+                                             const int32_t *srcLen, uint8_t *dst, const uint64_t *dstOff,
+                                             const int32_t *dstCap, int32_t *outLen, int64_t n, int flags,
+                                             const uint8_t *dict, const uint64_t *dictOff, const int32_t *dictLen,
+                                             void *stream);
 
 /* ---- LZ4Pickler envelope, version 0 (LZ4Pickler.pickle.cs:51-228, LZ4Pickler.unpickle.cs:18-158)
  * pickle:   outLen[i] = envelope bytes written to dst + dstOff[i]; dstCap[i] must be at least

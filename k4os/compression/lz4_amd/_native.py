@@ -14,6 +14,10 @@ K4LZ4_OK = 0
 E_HIP, E_ARG, E_NOMEM, E_NO_DEVICE, E_UNSUPPORTED = -1, -2, -3, -4, -5
 FLAG_RAW_RETURN = 1
 FLAG_PICKLE_WRITER = 2
+FLAG_NO_REORDER = 4
+FLAG_REORDER = 8
+FLAG_NO_SPLIT = 16
+FLAG_PARTIAL = 32
 
 _u8p = C.c_void_p
 _BATCH = [C.c_void_p, _u8p, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
@@ -32,8 +36,12 @@ SYMBOLS = {
     "k4lz4_compress_fast": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int]),
     "k4lz4_compress_hc": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int]),
     "k4lz4_decompress_safe": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int]),
+    "k4lz4_decompress_safe_partial": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int]),
     "k4lz4_encode_batch": (C.c_int, _BATCH + [C.c_int, C.c_int]),
+    "k4lz4_decompress_safe_using_dict": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, _u8p, C.c_int]),
     "k4lz4_decode_batch": (C.c_int, _BATCH + [C.c_int]),
+    "k4lz4_decode_dict_batch": (C.c_int, _BATCH + [C.c_int, _u8p, C.c_void_p, C.c_void_p]),
+    "k4lz4_decode_dict_batch_device": (C.c_int, _BATCH + [C.c_int, _u8p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "k4lz4_encode_batch_device": (C.c_int, _BATCH + [C.c_int, C.c_int, C.c_void_p]),
     "k4lz4_decode_batch_device": (C.c_int, _BATCH + [C.c_int, C.c_void_p]),
     "k4lz4_pickle_bound": (C.c_int, [C.c_int]),

@@ -122,6 +122,8 @@ class LZ4Codec:
         """Decode(source, target) or Decode(source, sourceOffset, sourceLength, target,
         targetOffset, targetLength).  Returns bytes written, 0 for an empty source, or a negative
         value if the target is too small / the block is corrupt."""
+        if len(args) == 3:                                       # Decode(source, target, dictionary): LZ4Codec.cs:144-160
+            return LZ4Codec._decode_with_dictionary(*args)
         long = _split_args(args, 2, "Decode")
         if long is None:
             src, dst = _ro_view(args[0], "source"), _rw_view(args[1], "target")
@@ -138,6 +140,39 @@ class LZ4Codec:
         n = lib.k4lz4_decompress_safe(_ptr(src) + so, _ptr(scratch) + to, sl, tl)
         _raise_if_native_failed(lib)
         return -1 if n <= 0 else n                               # LZ4Codec.cs:114
+
+    @staticmethod
+    def _decode_with_dictionary(source, target, dictionary) -> int:
+        src, dst, dct = _ro_view(source, "source"), _rw_view(target, "target"), _ro_view(dictionary, "dictionary")
+        if src.size <= 0:
+            return 0                                             # LZ4Codec.cs:149-150
+        lib = _native.load_library()
+        scratch = dst if dst.size else np.zeros(1, np.uint8)
+        dpt = _ptr(dct) if dct.size else None
+        n = lib.k4lz4_decompress_safe_using_dict(_ptr(src), _ptr(scratch), src.size, dst.size, dpt, dct.size)
+        _raise_if_native_failed(lib)
+        return -1 if n <= 0 else n                               # LZ4Codec.cs:156
+
+    @staticmethod
+    def PartialDecode(*args) -> int:
+        """PartialDecode(source, target) or (source, sourceOffset, sourceLength, target, targetOffset,
+        targetLength): decoding stops once the target is full (LZ4Codec.cs:123-173)."""
+        long = _split_args(args, 2, "PartialDecode")
+        if long is None:
+            src, dst = _ro_view(args[0], "source"), _rw_view(args[1], "target")
+            so, sl, to, tl = 0, src.size, 0, dst.size
+        else:
+            src, dst = _ro_view(long[0], "source"), _rw_view(long[3], "target")
+            so, sl, to, tl = int(long[1]), int(long[2]), int(long[4]), int(long[5])
+            _validate(src, so, sl, "source")
+            _validate(dst, to, tl, "target")
+        if sl <= 0:
+            return 0                                             # LZ4Codec.cs:127-128
+        lib = _native.load_library()
+        scratch = dst if dst.size else np.zeros(1, np.uint8)
+        n = lib.k4lz4_decompress_safe_partial(_ptr(src) + so, _ptr(scratch) + to, sl, tl)
+        _raise_if_native_failed(lib)
+        return -1 if n <= 0 else n                               # LZ4Codec.cs:133
 
     # ---- batches --------------------------------------------------------------------------------
     @staticmethod
@@ -158,6 +193,23 @@ class LZ4Codec:
         out = np.empty(len(src_len), dtype=np.int32)
         a = _batch_args(src, src_off, src_len, dst, dst_off, dst_cap, out)
         ctx.check(ctx.lib.k4lz4_decode_batch(ctx.handle, *a, flags))
+        return out
+
+    @staticmethod
+    def DecodeDictBatchPacked(src: np.ndarray, src_off: np.ndarray, src_len: np.ndarray, dst: np.ndarray,
+                              dst_off: np.ndarray, dst_cap: np.ndarray, dictionaries: np.ndarray, dict_off: np.ndarray,
+                              dict_len: np.ndarray, flags: int = 0, ctx: Optional[_native.Context] = None) -> np.ndarray:
+        """Batched Decode(source, target, dictionary): block i uses dictionaries[dict_off[i]:+dict_len[i]]."""
+        ctx = ctx or _native.default_context()
+        out = np.empty(len(src_len), dtype=np.int32)
+        a = _batch_args(src, src_off, src_len, dst, dst_off, dst_cap, out)
+        dct = np.ascontiguousarray(dictionaries, dtype=np.uint8)
+        doff = np.ascontiguousarray(dict_off, dtype=np.uint64)
+        dlen = np.ascontiguousarray(dict_len, dtype=np.int32)
+        if len(doff) != len(src_len) or len(dlen) != len(src_len):
+            raise ValueError("dict_off / dict_len must have one entry per block")
+        ctx.check(ctx.lib.k4lz4_decode_dict_batch(ctx.handle, *a, flags, _ptr(dct) if dct.size else None,
+                                                  doff.ctypes.data, dlen.ctypes.data))
         return out
 
     @staticmethod

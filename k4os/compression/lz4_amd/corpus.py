@@ -78,7 +78,8 @@ def _word_text(n: int, rng: np.random.Generator, vocab_size: int, zipf_a: float,
         out[m] = alpha[rng.integers(0, alpha.size, size=int(m.sum()))]
     punct = rng.random(nwords) < 0.08
     out[(starts + lens - 1)[punct]] = seps[rng.integers(0, seps.size, size=int(punct.sum()))]
-    assert total >= n
+    if total < n:                       # short draw (small n, long-tailed word lengths): wrap around
+        out = np.resize(out, n)
     return out[:n].copy()
 
 

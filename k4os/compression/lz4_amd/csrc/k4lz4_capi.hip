@@ -38,6 +38,7 @@ struct k4lz4_ctx {
     uint8_t *d_meta = nullptr; size_t d_meta_cap = 0;
     uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;
     uint8_t *d_sched = nullptr; size_t d_sched_cap = 0;   /* dispatch-order scratch: cost[n], order[n], counters */
+    uint8_t *d_dict = nullptr; size_t d_dict_cap = 0;         /* host-pointer decode with dictionaries: staged dictionaries + their metadata */
     uint8_t *d_gtab = nullptr; size_t d_gtab_cap = 0;         /* fast encoder: hash tables of the blocks encoded without an LDS table */
     hipStream_t aux = nullptr;                                /* second queue: those blocks run beside the LDS-table kernel */
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -138,10 +139,18 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
     return K4LZ4_OK;
 }
 
+/* per-block dictionaries for decode (device pointers) */
+struct DictArgs {
+    const uint8_t *dict;
+    const uint64_t *off;
+    const int32_t *len;
+    const signed char *mode;
+};
+
 /* enqueue the kernels for n blocks; all pointers are device pointers */
 int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
            const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level, int flags,
-           hipStream_t stream)
+           hipStream_t stream, const DictArgs *dd = nullptr)
 {
     if (n == 0) return K4LZ4_OK;
     const int64_t chunk_max = 1 << 24;   /* blocks per launch (grid.x * blockDim.x must stay < 2^32) */
@@ -169,6 +178,10 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
         a.dst = dst; a.dstOff = dstOff + first; a.dstCap = dstCap + first;
         a.outLen = outLen + first; a.n = cnt; a.level = level; a.accel = ctx->accel; a.flags = flags;
         a.prof = ctx->prof ? ctx->prof + k4::PROF_STRIDE * first : nullptr;
+        if (dd && dd->dict) {
+            a.dict = dd->dict; a.dictOff = dd->off + first; a.dictLen = dd->len + first;
+            a.dictMode = dd->mode ? dd->mode + first : nullptr;
+        }
         if (reorder) {
             a.cost = d_cost; a.hist = d_hist; a.order_out = d_order;
             K4_HIP(ctx, hipMemsetAsync(d_hist, 0, 2 * k4::COST_BUCKETS * 4, stream));
@@ -251,7 +264,7 @@ int check_batch_args(k4lz4_ctx *ctx, const void *src, const void *srcOff, const 
 /* host-pointer batch: stage, run, scatter */
 int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
              uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level,
-             int flags)
+             int flags, const DictArgs *hd = nullptr)
 {
     int rc = check_batch_args(ctx, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n);
     if (rc != K4LZ4_OK) return rc;
@@ -298,7 +311,39 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
     K4_HIP(ctx, hipMemcpyAsync(d_doff, h_doff.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
     K4_HIP(ctx, hipMemcpyAsync(d_slen, srcLen, (size_t)n * 4, hipMemcpyHostToDevice, st));
     K4_HIP(ctx, hipMemcpyAsync(d_cap, h_cap.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-    rc = launch(ctx, kind, ctx->d_src, d_soff, d_slen, ctx->d_dst, d_doff, d_cap, d_out, n, level, flags, st);
+    DictArgs ddev{nullptr, nullptr, nullptr, nullptr};
+    std::vector<uint64_t> h_dictoff;
+    std::vector<signed char> h_mode;
+    if (hd && hd->dict) {
+        /* dictionaries: stage their span; prefix-vs-external is decided on the HOST addresses
+         * (LL64.dec.cs:531-541: dictStart + dictSize == dest) because staging breaks adjacency */
+        uint64_t dlo = UINT64_MAX, dhi = 0;
+        h_dictoff.assign((size_t)n, 0);
+        h_mode.assign((size_t)n, 0);
+        for (int64_t i = 0; i < n; i++) {
+            const int32_t len = hd->len[i];
+            if (len <= 0) continue;
+            dlo = std::min(dlo, hd->off[i]);
+            dhi = std::max(dhi, hd->off[i] + (uint64_t)len);
+            h_mode[(size_t)i] = hd->dict + hd->off[i] + len == dst + dstOff[i] ? 1 : 2;
+        }
+        if (dlo != UINT64_MAX) {
+            for (int64_t i = 0; i < n; i++) h_dictoff[(size_t)i] = hd->len[i] > 0 ? hd->off[i] - dlo : 0;
+            const size_t dspan = (size_t)(dhi - dlo);
+            const size_t need = dspan + 64 + (size_t)n * (8 + 4 + 1) + 64;
+            if ((rc = grow(ctx, &ctx->d_dict, &ctx->d_dict_cap, need, false)) != K4LZ4_OK) return rc;
+            uint8_t *base = ctx->d_dict;
+            uint64_t *d_dictoff = (uint64_t *)(base + ((dspan + 63) & ~(size_t)63));
+            int32_t *d_dictlen = (int32_t *)(d_dictoff + n);
+            signed char *d_mode = (signed char *)(d_dictlen + n);
+            K4_HIP(ctx, hipMemcpyAsync(base, hd->dict + dlo, dspan, hipMemcpyHostToDevice, st));
+            K4_HIP(ctx, hipMemcpyAsync(d_dictoff, h_dictoff.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+            K4_HIP(ctx, hipMemcpyAsync(d_dictlen, hd->len, (size_t)n * 4, hipMemcpyHostToDevice, st));
+            K4_HIP(ctx, hipMemcpyAsync(d_mode, h_mode.data(), (size_t)n, hipMemcpyHostToDevice, st));
+            ddev = DictArgs{base, d_dictoff, d_dictlen, d_mode};
+        }
+    }
+    rc = launch(ctx, kind, ctx->d_src, d_soff, d_slen, ctx->d_dst, d_doff, d_cap, d_out, n, level, flags, st, &ddev);
     if (rc != K4LZ4_OK) return rc;
     K4_HIP(ctx, hipMemcpyAsync(outLen, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     if (dtotal) K4_HIP(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_dst, (size_t)dtotal, hipMemcpyDeviceToHost, st));
@@ -312,7 +357,7 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
 
 int run_device(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
                uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level,
-               int flags, void *stream)
+               int flags, void *stream, const DictArgs *dd = nullptr)
 {
     int rc = check_batch_args(ctx, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n);
     if (rc != K4LZ4_OK) return rc;
@@ -322,7 +367,7 @@ int run_device(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *sr
     }
     if (n == 0) return K4LZ4_OK;
     K4_HIP(ctx, hipSetDevice(ctx->device));
-    return launch(ctx, kind, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, (hipStream_t)stream);
+    return launch(ctx, kind, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, (hipStream_t)stream, dd);
 }
 
 struct CtxDeleter { void operator()(k4lz4_ctx *c) const { k4lz4_ctx_destroy(c); } };
@@ -339,7 +384,8 @@ k4lz4_ctx *implicit_ctx()
 }
 
 /* batch of one with LLxx-level returns */
-int single(Kind kind, const uint8_t *src, uint8_t *dst, int srcLen, int dstCap, int level, int accel = 1)
+int single(Kind kind, const uint8_t *src, uint8_t *dst, int srcLen, int dstCap, int level, int accel = 1, int extra_flags = 0,
+           const uint8_t *dict = nullptr, int dictLen = 0)
 {
     tl_status = K4LZ4_OK;
     k4lz4_ctx *ctx = implicit_ctx();
@@ -348,7 +394,10 @@ int single(Kind kind, const uint8_t *src, uint8_t *dst, int srcLen, int dstCap, 
     const uint64_t off = 0;
     int32_t slen = srcLen, cap = dstCap, out = 0;
     ctx->accel = accel < 1 ? 1 : accel;
-    const int rc = run_host(ctx, kind, src, &off, &slen, dst, &off, &cap, &out, 1, level, K4LZ4_FLAG_RAW_RETURN);
+    int32_t dlen = dictLen;
+    const DictArgs hd{dict, &off, &dlen, nullptr};
+    const int rc = run_host(ctx, kind, src, &off, &slen, dst, &off, &cap, &out, 1, level, K4LZ4_FLAG_RAW_RETURN | extra_flags,
+                            dict && dictLen > 0 ? &hd : nullptr);
     ctx->accel = 1;
     tl_status = rc;
     if (rc != K4LZ4_OK) return kind == KIND_DECODE ? -1 : 0;
@@ -407,6 +456,7 @@ void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
+    if (ctx->d_dict) (void)hipFree(ctx->d_dict);
     if (ctx->d_src) (void)hipFree(ctx->d_src);
     if (ctx->d_dst) (void)hipFree(ctx->d_dst);
     if (ctx->d_meta) (void)hipFree(ctx->d_meta);
@@ -449,10 +499,39 @@ int k4lz4_decompress_safe(const uint8_t *src, uint8_t *dst, int srcLen, int dstC
     return single(KIND_DECODE, src, dst, srcLen, dstCap, 0);
 }
 
+int k4lz4_decompress_safe_partial(const uint8_t *src, uint8_t *dst, int srcLen, int targetLen)
+{
+    return single(KIND_DECODE, src, dst, srcLen, targetLen, 0, 1, K4LZ4_FLAG_PARTIAL);
+}
+
 int k4lz4_encode_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
                        const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level, int flags)
 {
     return run_host(ctx, KIND_ENCODE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags);
+}
+
+int k4lz4_decompress_safe_using_dict(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap, const uint8_t *dict, int dictLen)
+{
+    return single(KIND_DECODE, src, dst, srcLen, dstCap, 0, 1, 0, dict, dictLen);
+}
+
+int k4lz4_decode_dict_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                            const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int flags,
+                            const uint8_t *dict, const uint64_t *dictOff, const int32_t *dictLen)
+{
+    if (dict && n > 0 && (!dictOff || !dictLen)) return fail(ctx, K4LZ4_E_ARG, "NULL dictionary offsets/lengths");
+    const DictArgs hd{dict, dictOff, dictLen, nullptr};
+    return run_host(ctx, KIND_DECODE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, 0, flags, dict ? &hd : nullptr);
+}
+
+int k4lz4_decode_dict_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+                                   uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n,
+                                   int flags, const uint8_t *dict, const uint64_t *dictOff, const int32_t *dictLen,
+                                   void *stream)
+{
+    if (dict && n > 0 && (!dictOff || !dictLen)) return fail(ctx, K4LZ4_E_ARG, "NULL dictionary offsets/lengths");
+    const DictArgs dd{dict, dictOff, dictLen, nullptr};
+    return run_device(ctx, KIND_DECODE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, 0, flags, stream, dict ? &dd : nullptr);
 }
 
 int k4lz4_decode_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,

@@ -32,6 +32,7 @@ enum : int {
 enum : int {
     FLAG_RAW_RETURN = 1,  /* outLen = LLxx-level return instead of the LZ4Codec mapping */
     FLAG_PICKLE_WRITER = 2,
+    FLAG_PARTIAL = 32,     /* decode: LZ4_decompress_safe_partial semantics, dstCap = target size */
 };
 
 struct BatchArgs {
@@ -52,6 +53,10 @@ struct BatchArgs {
     uint32_t *hist;            /* scheduling scratch: 2 x COST_BUCKETS counters (zeroed) */
     uint32_t *order_out;       /* scheduling scratch: the order being built */
     uint32_t *gtab;            /* k4_encode_fast_gtab_kernel: 4096 dwords of table per workgroup */
+    const uint8_t *dict;       /* decode with dictionaries: packed dictionaries, or nullptr */
+    const uint64_t *dictOff;
+    const int32_t *dictLen;
+    const signed char *dictMode;   /* optional: 1 = prefix semantics, 2 = external (host staging); nullptr = by address */
 };
 
 struct __attribute__((packed, aligned(1))) U16u { uint16_t v; };

@@ -105,6 +105,22 @@ __device__ __forceinline__ void lane_copy32(uint8_t *d, const uint8_t *s, uint32
     }
 }
 
+/* Dictionary of a block (LZ4Codec.Decode(..., dictionary), LL64.LZ4_decompress_safe_usingDict,
+ * LL64.dec.cs:523-546): mode 0 none, 1 prefix (the dictionary sits immediately before the output:
+ * `size` bytes, 65536 when it is 64 KiB-1 or more -- withPrefix64k), 2 external.
+ * `end` = one past the last dictionary byte (mode 1: == out). */
+struct DecodeDict { const uint8_t *end; uint32_t size; int mode; };
+
+/* match that starts before the block: `from_dict` bytes come out of the dictionary, the rest from
+ * the start of the output with the usual replicating semantics (LL64.dec.cs:342-378) */
+__device__ __forceinline__ void wave_dict_copy(uint8_t *out, const uint8_t *dict_end, uint32_t op, uint32_t from_dict, uint32_t len, int lane)
+{
+    const uint32_t n1 = len < from_dict ? len : from_dict;
+    wave_sync();
+    wave_copy(out + op, dict_end - from_dict, n1, lane);
+    if (len > n1) wave_match_copy(out, op + n1, op + n1, len - n1, lane);
+}
+
 /*
  * Decode one block.  Returns what LL64.LZ4_decompress_safe returns: the number of bytes written,
  * or -(input position) - 1 when the stream is malformed (LL64.dec.cs:465).
@@ -112,12 +128,19 @@ __device__ __forceinline__ void lane_copy32(uint8_t *d, const uint8_t *s, uint32
  */
 template <bool PROF = false>
 __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uint8_t *out, int out_size, int lane,
-                                            uint32_t *lds, unsigned long long *pc = nullptr)
+                                            uint32_t *lds, unsigned long long *pc = nullptr, bool partial = false,
+                                            DecodeDict dict = DecodeDict{nullptr, 0u, 0})
 {
+    /* lowPrefix relative to out (<= 0), the size used by the offset check (:149,:338) */
+    const int64_t low_prefix = dict.mode == 1 ? -(int64_t)dict.size : 0;
+    const int64_t chk_size = dict.mode == 2 ? (int64_t)dict.size : 0;
+    const bool check_offset = chk_size < 65536;
+    const bool prefix64 = dict.mode == 1 && dict.size == 65536u;
     unsigned long long c_parse = 0, c_lit = 0, c_match = 0, n_batch = 0, n_round = 0, n_seq = 0, n_slow = 0;
     prof_place<PROF>(pc, 8, lane);
     const unsigned long long t_begin = prof_now<PROF>();
     if (out_size == 0) {                                   /* LL64.dec.cs:162-168 */
+        if (partial) return 0;
         if (src_size == 1) {
             uint32_t b = uni(lane == 0 ? (uint32_t)in[0] : 0u);
             return b == 0 ? 0 : -1;
@@ -253,7 +276,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 ip += 2;
                 match = op - (int64_t)offset;
                 length = token & ML_MASK;
-                if (length != ML_MASK && offset >= 8u && match >= 0) {
+                if (length != ML_MASK && offset >= 8u && (prefix64 || match >= low_prefix)) {   /* :213 */
                     s_moff = offset; s_mlen = length + MINMATCH; adv = s_mlen;
                     need_match = false;
                 }
@@ -272,11 +295,28 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 const int64_t cpy = op + (int64_t)length;      /* :246-315 */
                 s_lpos = (uint32_t)ip; s_llen = length; s_out = (uint32_t)op;
                 if (cpy > oend - MFLIMIT || ip + (int64_t)length > iend - (2 + 1 + LASTLITERALS)) {
-                    if (ip + (int64_t)length != iend || cpy > oend) { err = (int)(-ip) - 1; break; }
-                    ip += length;
-                    op += length;
-                    last = true;
-                    need_match = false;
+                    if (partial) {                             /* :250-270: stop early, never past oend */
+                        if (ip + (int64_t)length > iend - (2 + 1 + LASTLITERALS) && ip + (int64_t)length != iend) { err = (int)(-ip) - 1; break; }
+                        bool at_end = cpy == oend;
+                        if (cpy > oend) { length = (uint32_t)(oend - op); s_llen = length; at_end = true; }
+                        ip += length;
+                        op += length;
+                        if (at_end || ip == iend) {
+                            last = true;
+                            need_match = false;
+                        } else {                               /* :303: keep going with the match */
+                            offset = win.fetch((uint32_t)ip, lane) & 0xffffu;
+                            ip += 2;
+                            match = op - (int64_t)offset;
+                            length = token & ML_MASK;
+                        }
+                    } else {
+                        if (ip + (int64_t)length != iend || cpy > oend) { err = (int)(-ip) - 1; break; }
+                        ip += length;
+                        op += length;
+                        last = true;
+                        need_match = false;
+                    }
                 } else {
                     ip += length;
                     op = cpy;
@@ -299,12 +339,28 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                     if (err) break;
                 }
                 length += MINMATCH;
-                if (match < 0) { err = (int)(-ip) - 1; break; }              /* :338 */
+                if (check_offset && match + chk_size < low_prefix) { err = (int)(-ip) - 1; break; }   /* :338 */
                 const int64_t cpy = op + (int64_t)length;
-                if (cpy > oend - MATCH_SAFEGUARD && cpy > oend - LASTLITERALS) { err = (int)(-ip) - 1; break; }  /* :427-433 */
-                s_moff = offset;
-                s_mlen = offset != 0u ? length : 0u;           /* offset 0 (hostile): output left as is */
-                adv = length;
+                if (dict.mode == 2 && match < 0) {                 /* :342-378 match starts in the external dictionary */
+                    if (cpy > oend - LASTLITERALS) {
+                        if (!partial) { err = (int)(-ip) - 1; break; }
+                        if ((int64_t)length > oend - op) length = (uint32_t)(oend - op);
+                    }
+                    s_moff = offset;
+                    s_mlen = length;
+                    adv = length;
+                } else if (partial && cpy > oend - MATCH_SAFEGUARD) {     /* :387-406: truncated final match */
+                    const uint32_t mlen = (int64_t)length < oend - op ? length : (uint32_t)(oend - op);
+                    s_moff = offset;
+                    s_mlen = offset != 0u ? mlen : 0u;
+                    adv = mlen;
+                    if (op + (int64_t)mlen == oend) last = true;
+                } else {
+                    if (cpy > oend - MATCH_SAFEGUARD && cpy > oend - LASTLITERALS) { err = (int)(-ip) - 1; break; }  /* :427-433 */
+                    s_moff = offset;
+                    s_mlen = offset != 0u ? length : 0u;       /* offset 0 (hostile): output left as is */
+                    adv = length;
+                }
             }
             if (lane == 0) {
                 d_lpos[nseq] = s_lpos; d_llen[nseq] = s_llen; d_out[nseq] = s_out; d_moff[nseq] = s_moff; d_mlen[nseq] = s_mlen;
@@ -360,7 +416,12 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             const uint32_t hi_c = hi < (uint32_t)lane ? hi : (uint32_t)lane;
             unsigned long long deps = 0;
             if (has && lo < hi_c) deps = ((hi_c >= 64u ? 0ull : (1ull << hi_c)) - 1ull) & ~((1ull << lo) - 1ull);
-            const bool coop = v_mlen > LANE_COPY_MAX || v_moff < v_mlen;
+            /* a match that starts before the block (dictionary) waits for everything below it and is
+             * moved by the whole wave */
+            const bool neg = has && v_moff > mdst;
+            if (neg) deps = lane == 0 ? 0ull : ((1ull << lane) - 1ull);
+            const unsigned long long negmask = __ballot(neg);
+            const bool coop = v_mlen > LANE_COPY_MAX || v_moff < v_mlen || neg;
             unsigned long long pend = __ballot(has);
             while (pend) {
                 if (PROF) n_round++;
@@ -372,8 +433,10 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 while (big) {
                     const int g = ctz64(big);
                     big &= big - 1;
-                    wave_match_copy(out, __builtin_amdgcn_readlane(mdst, g), __builtin_amdgcn_readlane(v_moff, g),
-                                    __builtin_amdgcn_readlane(v_mlen, g), lane);
+                    const uint32_t g_dst = __builtin_amdgcn_readlane(mdst, g), g_off = __builtin_amdgcn_readlane(v_moff, g),
+                                   g_len = __builtin_amdgcn_readlane(v_mlen, g);
+                    if ((negmask >> g) & 1ull) wave_dict_copy(out, dict.end, g_dst, g_off - g_dst, g_len, lane);
+                    else wave_match_copy(out, g_dst, g_off, g_len, lane);
                 }
                 pend &= ~rmask;
             }
@@ -403,6 +466,21 @@ __device__ __forceinline__ int codec_decode_result(int src_len, int ret, int fla
 
 constexpr int DECODE_WAVES_PER_WG = 4;
 
+/* LL64.LZ4_decompress_safe_usingDict (LL64.dec.cs:523-546): no dictionary / prefix / external */
+__device__ __forceinline__ DecodeDict block_dict(const BatchArgs &a, long long b, const uint8_t *out)
+{
+    DecodeDict d{nullptr, 0u, 0};
+    if (!a.dict || !a.dictLen) return d;
+    const int len = a.dictLen[b];
+    if (len <= 0) return d;
+    const uint8_t *p = a.dict + a.dictOff[b];
+    const bool prefix = a.dictMode ? a.dictMode[b] == 1 : p + len == out;
+    d.end = p + len;
+    d.size = prefix ? (len >= 65535 ? 65536u : (uint32_t)len) : (uint32_t)len;
+    d.mode = prefix ? 1 : 2;
+    return d;
+}
+
 __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_decode_kernel(BatchArgs a)
 {
     __shared__ uint32_t lds[DECODE_WAVES_PER_WG][DECODE_LDS_DWORDS];
@@ -415,7 +493,8 @@ __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_decode_kernel(Bat
     const uint8_t *in = a.src + a.srcOff[b];
     uint8_t *out = a.dst + a.dstOff[b];
     int ret = 0;
-    if (src_len > 0 || (a.flags & FLAG_RAW_RETURN)) ret = decode_block(in, src_len, out, cap < 0 ? 0 : cap, lane, lds[wave]);
+    if (src_len > 0 || (a.flags & FLAG_RAW_RETURN)) ret = decode_block(in, src_len, out, cap < 0 ? 0 : cap, lane, lds[wave], nullptr, (a.flags & FLAG_PARTIAL) != 0,
+                           block_dict(a, b, out));
     if (lane == 0) a.outLen[b] = codec_decode_result(src_len, ret, a.flags);
 }
 

@@ -13,7 +13,20 @@ int k4emu_decode_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t
                        const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int flags,
                        int threads)
 {
-    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, 0, 1, flags, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, 0, 1, flags, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (n <= 0) return 0;
+    unsigned grid = (unsigned)((n + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
+    k4emu::launch_fn(dim3(grid), dim3(64 * k4::DECODE_WAVES_PER_WG), [=] { k4::k4_decode_kernel(a); }, threads);
+    return 0;
+}
+
+int k4emu_decode_dict_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                            const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int flags,
+                            const uint8_t *dict, const uint64_t *dictOff, const int32_t *dictLen, int threads)
+{
+    k4::BatchArgs a{};
+    a.src = src; a.srcOff = srcOff; a.srcLen = srcLen; a.dst = dst; a.dstOff = dstOff; a.dstCap = dstCap;
+    a.outLen = outLen; a.n = n; a.accel = 1; a.flags = flags; a.dict = dict; a.dictOff = dictOff; a.dictLen = dictLen;
     if (n <= 0) return 0;
     unsigned grid = (unsigned)((n + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
     k4emu::launch_fn(dim3(grid), dim3(64 * k4::DECODE_WAVES_PER_WG), [=] { k4::k4_decode_kernel(a); }, threads);
@@ -24,7 +37,7 @@ int k4emu_encode_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t
                        const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int level,
                        int accel, int flags, int threads)
 {
-    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, accel, flags, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, accel, flags, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n <= 0) return 0;
     k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_encode_fast_kernel(a); }, threads);
     return 0;
@@ -69,7 +82,7 @@ int k4emu_pickle_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t
                        const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int level,
                        int flags, int threads)
 {
-    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, 1, flags, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, 1, flags, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n <= 0) return 0;
     k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_pickle_kernel(a); }, threads);
     return 0;
@@ -79,7 +92,7 @@ int k4emu_unpickle_batch(const uint8_t *src, const uint64_t *srcOff, const int32
                          const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int flags,
                          int threads)
 {
-    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, 0, 1, flags, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, 0, 1, flags, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n <= 0) return 0;
     unsigned grid = (unsigned)((n + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
     k4emu::launch_fn(dim3(grid), dim3(64 * k4::DECODE_WAVES_PER_WG), [=] { k4::k4_unpickle_kernel(a); }, threads);
@@ -89,7 +102,7 @@ int k4emu_unpickle_batch(const uint8_t *src, const uint64_t *srcOff, const int32
 int k4emu_unpickle_sizes(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, int32_t *outLen,
                          long long n, int threads)
 {
-    k4::BatchArgs a{src, srcOff, srcLen, nullptr, nullptr, nullptr, outLen, n, 0, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    k4::BatchArgs a{src, srcOff, srcLen, nullptr, nullptr, nullptr, outLen, n, 0, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n <= 0) return 0;
     k4emu::launch_fn(dim3((unsigned)((n + 255) / 256)), dim3(256), [=] { k4::k4_unpickle_sizes_kernel(a); }, threads);
     return 0;

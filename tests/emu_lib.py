@@ -51,6 +51,7 @@ class Emu:
         b = [_u8p, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
         self.lib.k4emu_decode_batch.argtypes = b + [C.c_int, C.c_int]
         self.lib.k4emu_encode_batch.argtypes = b + [C.c_int, C.c_int, C.c_int, C.c_int]
+        self.lib.k4emu_decode_dict_batch.argtypes = b + [C.c_int, _u8p, C.c_void_p, C.c_void_p, C.c_int]
         self.lib.k4emu_encode_hc_batch.argtypes = b + [C.c_int, C.c_int, C.c_int]
         self.lib.k4emu_order.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         self.lib.k4emu_pickle_batch.argtypes = b + [C.c_int, C.c_int, C.c_int]
@@ -113,5 +114,13 @@ class Emu:
         rc = self.lib.k4emu_encode_hc_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
                                             dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data,
                                             len(src_len), level, flags, threads)
+        assert rc == 0
+        return out
+
+    def decode_dict_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, dct, dict_off, dict_len, flags=0, threads=0):
+        out = np.full(len(src_len), -12345, dtype=np.int32)
+        rc = self.lib.k4emu_decode_dict_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
+                                              dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data, len(src_len),
+                                              flags, self._p(dct), dict_off.ctypes.data, dict_len.ctypes.data, threads)
         assert rc == 0
         return out

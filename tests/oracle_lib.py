@@ -92,6 +92,16 @@ class Oracle:
         ret = self.lib.k4o_decompress_safe_using_dict(_ptr(src), _ptr(dst), src.size, cap, _ptr(dictionary), dictionary.size)
         return ret, dst[:cap]
 
+    def decompress_using_prefix_dict(self, src: np.ndarray, cap: int, dictionary: np.ndarray):
+        """dictionary placed immediately before the output (the reference's withPrefix modes)"""
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        buf = np.full(dictionary.size + max(cap, 1), 0xCD, dtype=np.uint8)
+        buf[:dictionary.size] = dictionary
+        dptr = C.cast(buf.ctypes.data, _u8p)
+        optr = C.cast(buf.ctypes.data + dictionary.size, _u8p)
+        ret = self.lib.k4o_decompress_safe_using_dict(_ptr(src), optr, src.size, cap, dptr, dictionary.size)
+        return ret, buf[dictionary.size:dictionary.size + cap]
+
     # ---- LZ4Codec / LZ4Pickler level --------------------------------------------------------
     def encode(self, src: np.ndarray, level: int = 0, cap: int | None = None) -> bytes | None:
         src = np.ascontiguousarray(src, dtype=np.uint8)
@@ -178,7 +188,27 @@ class SystemLZ4:
         L.LZ4_decompress_safe.argtypes = [_u8p, _u8p, C.c_int, C.c_int]
         L.LZ4_decompress_safe_partial.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int]
         L.LZ4_decompress_safe_usingDict.argtypes = [_u8p, _u8p, C.c_int, C.c_int, _u8p, C.c_int]
+        L.LZ4_createStream.restype = C.c_void_p
+        L.LZ4_freeStream.argtypes = [C.c_void_p]
+        L.LZ4_loadDict.argtypes = [C.c_void_p, _u8p, C.c_int]
+        L.LZ4_compress_fast_continue.argtypes = [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int]
         self.version = L.LZ4_versionNumber()
+
+    def compress_with_dict(self, src: np.ndarray, dictionary: np.ndarray) -> np.ndarray:
+        """LZ4_loadDict + LZ4_compress_fast_continue: a block whose matches may reach into the dictionary
+        (what the reference's chain encoder emits for every block after the first)"""
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dictionary = np.ascontiguousarray(dictionary, dtype=np.uint8)
+        cap = src.size + src.size // 255 + 16
+        dst = np.zeros(cap, np.uint8)
+        st = self.lib.LZ4_createStream()
+        try:
+            self.lib.LZ4_loadDict(st, _ptr(dictionary), dictionary.size)
+            n = self.lib.LZ4_compress_fast_continue(st, _ptr(src), _ptr(dst), src.size, cap, 1)
+        finally:
+            self.lib.LZ4_freeStream(st)
+        assert n > 0
+        return dst[:n].copy()
 
     def compress_fast(self, src: np.ndarray, cap: int, accel: int = 1):
         src = np.ascontiguousarray(src, dtype=np.uint8)

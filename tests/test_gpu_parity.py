@@ -353,3 +353,90 @@ def test_dispatch_variants_give_identical_bytes(oracle):
     want = oracle.encode_batch(src, off, lens, ref_dst, make_arena(caps)[1], caps, threads=8)
     for out, dst in outs:
         assert np.array_equal(out, want) and np.array_equal(dst, ref_dst)
+
+
+# ---- PartialDecode (LZ4Codec.cs:123-173; reference test PartialDecodeTests) ---------------------
+@pytest.mark.parametrize("cls", ["dickens", "xml", "x-ray", "nci"])
+def test_partial_decode_matches_oracle(oracle, cls):
+    data = corpus.class_bytes(cls, 40000, 5)
+    comp = np.frombuffer(oracle.encode(data), np.uint8)
+    for want in (0, 1, 7, 64, 65, 1000, 12345, 39990, 39995, 40000, 40001, 50000):
+        tgt = np.full(want + 32, 0xCD, np.uint8)
+        n = LZ4Codec.PartialDecode(comp, 0, comp.size, tgt, 0, want)
+        ref_n, ref = oracle.decompress_partial(comp, want, want)
+        ref_n = -1 if ref_n <= 0 else ref_n
+        assert n == ref_n, (cls, want, n, ref_n)
+        if n > 0:
+            assert tgt[:n].tobytes() == ref[:n].tobytes() == data[:n].tobytes()
+        assert (tgt[max(want, 0):] == 0xCD).all()
+
+
+# ---- Decode with dictionary (LZ4Codec.cs:144-160; Issue64.cs: dictionary-chained records) -------
+def _issue64_records():
+    raw = open(os.path.join(GOLDEN, "issue64_input.bin"), "rb").read()
+    want = np.frombuffer(open(os.path.join(GOLDEN, "issue64_output.bin"), "rb").read(), np.uint8)
+    pos, recs = 20, []
+    while raw[pos:pos + 4] == b"bv41":
+        u, c = struct.unpack_from("<II", raw, pos + 4)
+        recs.append((u, np.frombuffer(raw[pos + 12:pos + 12 + c], np.uint8)))
+        pos += 12 + c
+    return recs, want
+
+
+def test_issue64_chained_record_with_dictionary(oracle):
+    recs, want = _issue64_records()
+    u0, c0 = recs[0]
+    u1, c1 = recs[1]
+    first = np.zeros(u0, np.uint8)
+    assert LZ4Codec.Decode(c0, first) == u0 and first.tobytes() == want[:u0].tobytes()
+    # external dictionary
+    second = np.full(u1 + 16, 0xCD, np.uint8)
+    assert LZ4Codec.Decode(c1, second[:u1], first) == u1
+    assert second[:u1].tobytes() == want[u0:u0 + u1].tobytes() and (second[u1:] == 0xCD).all()
+    # prefix placement (the dictionary ends where the target starts)
+    both = np.full(u0 + u1, 0xCD, np.uint8)
+    both[:u0] = first
+    assert LZ4Codec.Decode(c1, both[u0:], both[:u0]) == u1
+    assert both.tobytes() == want[:u0 + u1].tobytes()
+    # without its dictionary the record is rejected, exactly as the oracle rejects it
+    n, _ = oracle.decompress_safe(c1, u1)
+    assert n < 0 and LZ4Codec.Decode(c1, np.zeros(u1, np.uint8)) == -1
+    # too small a target
+    assert LZ4Codec.Decode(c1, np.zeros(u1 - 1, np.uint8), first) == -1
+
+
+def test_dictionary_batch_matches_oracle(oracle):
+    """independent streams, each with its own dictionary: liblz4-made streams (LZ4_compress_fast_continue
+    after LZ4_loadDict is what the reference's chain encoder does) are not available here, so the streams are
+    issue64's record plus blocks whose matches are re-pointed into the dictionary by construction"""
+    recs, want = _issue64_records()
+    u0 = recs[0][0]
+    u1, c1 = recs[1]
+    d0 = want[:u0]
+    rng = np.random.default_rng(9)
+    cases = []
+    for k in range(40):
+        cut = int(rng.integers(0, u0))
+        cases.append((c1, int(u1 + rng.integers(-2, 3)), d0[cut:] if k % 3 else d0))
+    from oracle_lib import SystemLZ4
+    sysl = SystemLZ4()
+    if sysl.available:
+        for k, cls in enumerate(corpus.SILESIA_NAMES):
+            dn, n = (65536, 65536) if k % 2 else (int(rng.integers(100, 70000)), int(rng.integers(1000, 65536)))
+            text = corpus.class_bytes(cls, dn + n, 4)
+            dd, data = text[:dn].copy(), text[dn:].copy()
+            c = sysl.compress_with_dict(data, dd)
+            got = np.zeros(n, np.uint8)
+            assert LZ4Codec.Decode(c, got, dd) == n and got.tobytes() == data.tobytes()
+            cases += [(c, n, dd), (c, n - 1, dd), (c, n + 7, dd), (c, n, dd[1:])]
+    comps = [c for c, _, _ in cases]
+    src, soff, slen = pack_blocks(comps)
+    dpk, doffs, dlens = pack_blocks([d for _, _, d in cases])
+    caps = np.array([c for _, c, _ in cases], np.int32)
+    dst, doff = make_arena(caps)
+    out = LZ4Codec.DecodeDictBatchPacked(src, soff, slen, dst, doff, caps, dpk, doffs, dlens, flags=FLAG_RAW_RETURN)
+    for i, (c, cap, d) in enumerate(cases):
+        n, ref = oracle.decompress_using_dict(c, cap, np.ascontiguousarray(d))
+        assert out[i] == n, (i, out[i], n)
+        if n > 0:
+            assert dst[int(doff[i]):int(doff[i]) + n].tobytes() == ref[:n].tobytes()
