@@ -107,6 +107,8 @@ template <bool PROF> __device__ __forceinline__ unsigned long long prof_now()
 }
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+/* the builtin returns int: widening its result directly would sign-extend */
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ int ctz64(unsigned long long m) { return __ffsll(m) - 1; }
 
 /* Inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS):
@@ -145,6 +147,43 @@ __device__ __forceinline__ void wave_copy(uint8_t *d, const uint8_t *s, uint32_t
 __device__ __forceinline__ void wave_fill(uint8_t *d, uint8_t b, uint32_t n, int lane)
 {
     for (uint32_t k = (uint32_t)lane; k < n; k += 64) d[k] = b;
+}
+
+constexpr uint32_t LANE_COPY_MAX = 32;
+
+/* up to 7 bytes at p (fewer than 8 readable): little-endian assemble without reading past them */
+__device__ __forceinline__ uint64_t load_tail(const uint8_t *p, uint32_t avail)
+{
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < 8u && i < avail; i++) v |= (uint64_t)p[i] << (8u * i);
+    return v;
+}
+
+/* Per-lane copy of len <= 32 bytes, regions must not overlap.  All (up to four) 8-byte loads are
+ * issued before the first store, so a lane pays one memory round trip; the stores write exactly
+ * len bytes.  `readable` = bytes that may be read starting at s (>= len). */
+__device__ __forceinline__ void lane_copy32(uint8_t *d, const uint8_t *s, uint32_t len, uint32_t readable)
+{
+    uint64_t v[4];
+#pragma unroll
+    for (uint32_t c = 0; c < 4u; c++) {
+        v[c] = 0;
+        if (8u * c < len) v[c] = (8u * c + 8u <= readable) ? ld64u(s + 8u * c) : load_tail(s + 8u * c, readable - 8u * c);
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < 4u; c++) {
+        if (8u * c >= len) break;
+        uint32_t rem = len - 8u * c;
+        uint8_t *q = d + 8u * c;
+        uint64_t x = v[c];
+        if (rem >= 8u) {
+            ((U64u *)q)->v = x;
+        } else {
+            if (rem & 4u) { ((U32u *)q)->v = (uint32_t)x; x >>= 32; q += 4; }
+            if (rem & 2u) { ((U16u *)q)->v = (uint16_t)x; x >>= 16; q += 2; }
+            if (rem & 1u) { *q = (uint8_t)x; }
+        }
+    }
 }
 
 /*

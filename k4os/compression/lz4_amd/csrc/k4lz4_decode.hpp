@@ -41,7 +41,6 @@
 namespace k4 {
 
 constexpr int DECODE_LDS_DWORDS = RING_DWORDS + 5 * 64;   /* ring + 5 descriptor arrays */
-constexpr uint32_t LANE_COPY_MAX = 32;
 constexpr int MAX_SEQ_PER_ROUND = 22;            /* 64 hypotheses, >= 3 stream bytes per sequence */
 
 /* Match copy inside the output block: out[op + i] = out[op - offset + i] with the byte-serial
@@ -66,41 +65,6 @@ __device__ __forceinline__ void wave_match_copy(uint8_t *out, uint32_t op, uint3
         for (uint32_t k0 = 0; k0 < len; k0 += chunk) {
             const uint32_t k = k0 + (uint32_t)lane;
             if ((uint32_t)lane < chunk && k < len) d[k] = m[r];
-        }
-    }
-}
-
-/* up to 7 bytes at p (fewer than 8 readable): little-endian assemble without reading past them */
-__device__ __forceinline__ uint64_t load_tail(const uint8_t *p, uint32_t avail)
-{
-    uint64_t v = 0;
-    for (uint32_t i = 0; i < 8u && i < avail; i++) v |= (uint64_t)p[i] << (8u * i);
-    return v;
-}
-
-/* Per-lane copy of len <= 32 bytes, regions must not overlap.  All (up to four) 8-byte loads are
- * issued before the first store, so a lane pays one memory round trip; the stores write exactly
- * len bytes.  `readable` = bytes that may be read starting at s (>= len). */
-__device__ __forceinline__ void lane_copy32(uint8_t *d, const uint8_t *s, uint32_t len, uint32_t readable)
-{
-    uint64_t v[4];
-#pragma unroll
-    for (uint32_t c = 0; c < 4u; c++) {
-        v[c] = 0;
-        if (8u * c < len) v[c] = (8u * c + 8u <= readable) ? ld64u(s + 8u * c) : load_tail(s + 8u * c, readable - 8u * c);
-    }
-#pragma unroll
-    for (uint32_t c = 0; c < 4u; c++) {
-        if (8u * c >= len) break;
-        uint32_t rem = len - 8u * c;
-        uint8_t *q = d + 8u * c;
-        uint64_t x = v[c];
-        if (rem >= 8u) {
-            ((U64u *)q)->v = x;
-        } else {
-            if (rem & 4u) { ((U32u *)q)->v = (uint32_t)x; x >>= 32; q += 4; }
-            if (rem & 2u) { ((U16u *)q)->v = (uint16_t)x; x >>= 16; q += 2; }
-            if (rem & 1u) { *q = (uint8_t)x; }
         }
     }
 }

@@ -82,62 +82,15 @@ __device__ __forceinline__ uint32_t wave_count(const uint8_t *a, const uint8_t *
     }
 }
 
-constexpr int ENCODE_STAGE_BYTES = 2048;
-constexpr int ENCODE_LDS_DWORDS = 4096 + ENCODE_STAGE_BYTES / 4;   /* hash table + output stage */
-
-/* Output staging: the compressed stream is assembled in LDS and written to HBM in 16 B per lane
- * bursts.  Besides coalescing the byte-granular token/offset/length stores, this keeps the wave's
- * in-order memory queue free of stores, so the probe loads of the next sequence are not held up
- * behind write acknowledgements. */
-struct OutStage {
-    uint8_t *lds;      /* ENCODE_STAGE_BYTES, 16-byte aligned */
-    uint8_t *dst;      /* block output in global memory */
-    uint32_t base;     /* output position held by lds[0] */
-    bool dry;          /* cost estimation run: nothing leaves the stage */
-
-    __device__ __forceinline__ void flush_to(uint32_t op, int lane)
-    {
-        const uint32_t n = op - base;
-        if (dry) { base = uni(op); return; }
-        wave_sync();
-        for (uint32_t k = 16u * (uint32_t)lane; k < n; k += 1024u) {
-            if (k + 16u <= n) {
-                const uint4 v = *(const uint4 *)(lds + k);
-                U128u o;
-                o.v[0] = v.x; o.v[1] = v.y; o.v[2] = v.z; o.v[3] = v.w;
-                st128u(dst + base + k, o);
-            } else {
-                for (uint32_t t = k; t < n; t++) dst[base + t] = lds[t];
-            }
-        }
-        wave_sync();
-        base = uni(op);
-    }
-    /* make room for `need` more staged bytes at output position op */
-    __device__ __forceinline__ void reserve(uint32_t op, uint32_t need, int lane)
-    {
-        if (op - base + need > (uint32_t)ENCODE_STAGE_BYTES) flush_to(op, lane);
-    }
-    __device__ __forceinline__ uint8_t *at(uint32_t op) const { return lds + (op - base); }
-};
+constexpr int ENCODE_SCRATCH_BYTES = 2048;     /* same-hash detection: one byte per slot */
+constexpr int ENCODE_LDS_DWORDS = 4096 + ENCODE_SCRATCH_BYTES / 4;   /* hash table + detection slots */
 
 /* length field tail: `rem` encoded as 255-run + final byte (LL64.fast.cs:262-272,:365-381,:484-495) */
-__device__ __forceinline__ uint32_t emit_length_run(OutStage &st, uint32_t op, uint32_t rem, int lane)
+__device__ __forceinline__ void emit_length_run(uint8_t *dst, uint32_t op, uint32_t rem, int lane)
 {
     const uint32_t nb = rem / 255u;
-    if (nb > 256u) {                       /* multi-KiB run: straight to global memory */
-        st.flush_to(op, lane);
-        if (!st.dry) {
-            wave_fill(st.dst + op, 255, nb, lane);
-            if (lane == 0) st.dst[op + nb] = (uint8_t)(rem - nb * 255u);
-        }
-        st.base = uni(op + nb + 1u);
-        return uni(op + nb + 1u);
-    }
-    st.reserve(op, nb + 1u, lane);
-    wave_fill(st.at(op), 255, nb, lane);
-    if (lane == 0) *st.at(op + nb) = (uint8_t)(rem - nb * 255u);
-    return uni(op + nb + 1u);
+    wave_fill(dst + op, 255, nb, lane);
+    if (lane == 0) dst[op + nb] = (uint8_t)(rem - nb * 255u);
 }
 
 /* the 16 source bytes around position p: 4 before, the 4 compared ones, 8 after */
@@ -159,18 +112,47 @@ __device__ __forceinline__ Around load_around(const uint8_t *src, uint32_t p)
     return a;
 }
 
+/* What the 16+16 bytes around a position and its candidate say about the match extension:
+ * bits 0-3 forward bytes beyond MINMATCH (0..8, capped at fwd_max), bits 4-6 equal bytes backwards
+ * (0..4), 0x100 forward run continues past the 8 known bytes, 0x200 the 4 bytes before both are known */
+__device__ __forceinline__ uint32_t extension_info(uint32_t a_pre, uint64_t a_next, bool a_ok, uint32_t b_pre, uint64_t b_next,
+                                                   bool b_ok, uint32_t fwd_max)
+{
+    const uint64_t x = a_next ^ b_next;
+    const uint32_t e = x ? (uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3 : 8u;
+    const uint32_t c8 = e < fwd_max ? e : fwd_max;
+    const bool ok = a_ok && b_ok;
+    const uint32_t y = a_pre ^ b_pre;
+    const uint32_t nb = ok ? (y ? (uint32_t)__clz(y) >> 3 : 4u) : 0u;
+    return c8 | (nb << 4) | ((e == 8u && fwd_max > 8u) ? 0x100u : 0u) | (ok ? 0x200u : 0u);
+}
+
 /*
  * LL64.LZ4_compress_generic for one block.  `ldsw`: ENCODE_LDS_DWORDS dwords of LDS owned by this
- * wave (16 KiB hash table, zeroed here = LZ4_initStream, LL.tools.cs:235-239; then the output
- * stage).  Returns bytes written, 0 when the output does not fit.
+ * wave (16 KiB hash table, zeroed here = LZ4_initStream, LL.tools.cs:235-239; then the detection
+ * slots).  Returns bytes written, 0 when the output does not fit.
  *
- * One iteration of the main loop produces one sequence with two dependent memory round trips:
- *   (1) 16 source bytes around each of up to 64 probe positions (4 before, the 4 hashed ones, 8
- *       after) and the pending literal bytes                      -> hashes -> LDS table lookups
- *   (2) the 16 bytes around the 64 candidates                     -> first hit, and from the hit
- *       lane's registers the backward extension (up to 4) and the match length (up to 12)
- * Longer extensions take a third round trip (wave_count).  The reference's "test the position
- * right after a match" step (LL64.fast.cs:393-463) rides in lane 0 of the next probe round.
+ * One round looks at 64 probe positions -- normally the 64 consecutive positions from the cursor --
+ * and resolves EVERY sequence that starts inside that window, not just the first:
+ *   load     16 source bytes around each position (4 before, the 4 hashed ones, 8 after); hash; look
+ *            the hashes up in the table as it stood at the start of the round; load the 16 bytes
+ *            around the 64 candidates; per lane: would this position hit, how far does the match
+ *            extend (up to 4 back / 12 forward from registers).
+ *   groups   lanes whose hashes collide inside the window are found through one byte-wide LDS slot
+ *            per hash; each such lane keeps the bit mask of its group.  The serial semantics "a
+ *            probe sees the puts of every earlier visited position" then become: the candidate of a
+ *            lane is the highest *visited* lane of its group below it, else the table entry.
+ *   resolve  wave-uniform walk over the window: first hit at or after the cursor (a scalar bit scan
+ *            when no colliding lane is ahead), extension from the hit lane's precomputed info,
+ *            cursor to the match end, visited set += probes up to the hit and the `ip-2` position
+ *            (LL64.fast.cs:394); sequence k of the round is parked in lane k.  The test of the
+ *            position right after a match (LL64.fast.cs:393-463) is simply the probe of that lane.
+ *   commit   visited lanes write the table, one writer per hash (the highest visited of a group).
+ *   emit     lane k writes sequence k: output positions from a DPP prefix sum, token / offset /
+ *            length bytes and up to 32 literals per lane; longer literal runs and multi-byte
+ *            length fields by the whole wave.
+ * After 64 misses the schedule's step grows (LL64.fast.cs:156-172); those rounds probe the strided
+ * positions and stop at their first sequence.
  */
 template <bool BYU16, bool PROF = false>
 __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
@@ -184,173 +166,145 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
     const unsigned long long t_begin = prof_now<PROF>();
     if ((uint32_t)src_len > (uint32_t)MAX_INPUT_SIZE) return 0;     /* LL64.fast.cs:90 */
     const bool limited = dst_cap < compress_bound(src_len);         /* :524 */
-    const int64_t olimit = dst_cap;
+    const uint64_t olimit = (uint64_t)(dst_cap < 0 ? 0 : dst_cap);
     const uint32_t U = (uint32_t)src_len;
     FastTable<BYU16> tab;
     /* the table normally lives in LDS; `gtab` (16 KiB of global memory) lets more blocks run per CU */
     uint32_t *const tabmem = gtab ? gtab : ldsw;
     tab.t = (decltype(tab.t))tabmem;
-    OutStage st;
-    st.lds = (uint8_t *)(gtab ? ldsw : ldsw + 4096);
-    st.dst = dst;
-    st.base = 0;
-    st.dry = dry;
+    uint8_t *const scr = (uint8_t *)(gtab ? ldsw : ldsw + 4096);
+    const unsigned long long me = 1ull << lane, below_me = me - 1ull;
 
     for (int k = lane; k < 1024; k += 64) ((uint4 *)tabmem)[k] = make_uint4(0u, 0u, 0u, 0u);
     wave_sync();
 
     uint32_t anchor = 0;
-    int64_t op = 0;
+    uint32_t op = 0;
 
     if (src_len >= MFLIMIT + 1) {                                   /* :117 */
         const uint32_t mflimit_plus_one = U - MFLIMIT + 1;
         const uint32_t matchlimit = U - LASTLITERALS;
 
         if (lane == 0) tab.put(FastTable<BYU16>::hash(src), 0);     /* :119-122 */
-        uint32_t ip = 1;
-        bool test = false;   /* true: `ip` is the position right after a match (:393-463) */
+        uint32_t ip = 1;       /* cursor of a fresh round */
+        uint32_t sbase = 1;    /* where the current search loop started (:466) */
+        uint32_t jbase = 0;    /* probes of the current search already done (0: fresh round) */
+        bool test = false;     /* fresh round only: `ip` is the position right after a match (:393-463) */
 
         for (;;) {
-            /* ---------------- probe rounds ---------------- */
+            /* ---------------- load: positions, hashes, candidates ---------------- */
             const unsigned long long t0 = prof_now<PROF>();
-            const uint32_t sbase = test ? ip + 1u : ip;             /* where the search loop starts (:466) */
-            uint32_t shift = test ? 1u : 0u;                        /* lane 0 of the first round = the test probe */
-            /* first round: positions do not depend on the table, so their source bytes (and the
-             * bytes hashed for the ip-2 put) are requested before the table is touched */
+            const bool fresh = jbase == 0u;
+            if (fresh) sbase = test ? ip + 1u : ip;
+            const bool contig = fresh && accel == 1u;               /* lane l probes position ip + l */
+            const uint32_t shift = (fresh && test) ? 1u : 0u;       /* lane 0 = the test probe */
+            const bool is_test0 = shift != 0u && lane == 0;
+            const uint32_t ip0 = ip;
             uint32_t pos, npos;
             {
-                const bool is_test0 = shift != 0u && lane == 0;
-                const uint32_t j0 = (uint32_t)lane - (is_test0 ? 0u : shift);
-                if (accel == 1u) {                                  /* first 64 probes of the schedule: step 1 */
-                    pos = is_test0 ? ip : sbase + j0;
-                    npos = sbase + j0 + 1u;
+                const uint32_t j = jbase + (uint32_t)lane - (is_test0 ? 0u : shift);
+                if (contig) {
+                    pos = is_test0 ? ip : sbase + j;
+                    npos = sbase + j + 1u;
                 } else {
-                    pos = is_test0 ? ip : sbase + probe_offset(j0, accel);
-                    npos = sbase + probe_offset(j0 + 1u, accel);
+                    pos = is_test0 ? ip : sbase + probe_offset(j, accel);
+                    npos = sbase + probe_offset(j + 1u, accel);
                 }
             }
-            bool valid = (shift != 0u && lane == 0) || (npos <= mflimit_plus_one && npos >= sbase);   /* :172 */
-            Around pa, ca;
+            const bool valid = is_test0 || (npos <= mflimit_plus_one && npos >= sbase);   /* :172 */
+            Around pa;
             pa.pre = 0; pa.seq = 0; pa.next = 0; pa.pre_ok = false;
             if (valid) pa = load_around(src, pos);
-            const uint8_t litbyte = anchor + (uint32_t)lane < U ? src[anchor + (uint32_t)lane] : (uint8_t)0;
-            if (test) {
+            if (shift) {
                 const uint32_t h2 = FastTable<BYU16>::hash(src + ip - 2);
                 if (lane == 0) tab.put(h2, ip - 2u);                /* :394 */
             }
             wave_sync();
             unsigned long long ts = prof_now<PROF>();
-            if (PROF) c_s1 += ts - t0;
-            uint32_t jbase = 0;
-            uint32_t match = 0;
-            bool found = false, test_hit = false;
-            int f = 0;
-            for (bool first = true;; first = false) {
-                if (!first) {
-                    const uint32_t j = jbase + (uint32_t)lane;
-                    pos = sbase + probe_offset(j, accel);
-                    npos = sbase + probe_offset(j + 1u, accel);
-                    valid = npos <= mflimit_plus_one && npos >= sbase;
-                    pa.pre = 0; pa.seq = 0; pa.next = 0; pa.pre_ok = false;
-                    if (valid) pa = load_around(src, pos);
-                }
-                uint32_t h = 0, cand = 0;
-                if (valid) {
-                    h = FastTable<BYU16>::hash_of(pa.seq, pa.next);
-                    cand = tab.get(h);
-                }
-                if (PROF) { const unsigned long long tn = prof_now<PROF>(); c_s2 += tn - ts; ts = tn; }
-                ca = load_around(src, cand);
-                bool hit = valid && (BYU16 || cand + (uint32_t)DISTANCE_MAX >= pos) && ca.seq == pa.seq;
-                const unsigned long long vmask = __ballot(valid);
-                const unsigned long long stop0 = __ballot(hit || !valid);
-                if (PROF) { const unsigned long long tn = prof_now<PROF>(); c_s3 += tn - ts; ts = tn; }
-                const int W = stop0 ? ctz64(stop0) + 1 : 64;
-                if (PROF) n_round++;
-
-                /* in-window duplicates: a later lane must see the earlier lane's put */
-                uint32_t pk = 0, rank = 0;
-                for (int d = 1; d < W; d++) {
-                    const uint32_t hk = __shfl_up(h, (unsigned)d);
-                    if (valid && lane >= d && lane < W && hk == h) {
-                        rank++;
-                        if (pk == 0) pk = (uint32_t)d;
-                    }
-                }
-                const unsigned long long dupmask = __ballot(pk != 0);
-                if (dupmask) {
-                    if (PROF) n_dup++;
-                    const uint32_t ppos = __shfl(pos, lane - (int)pk);
-                    if (pk != 0) {
-                        cand = ppos;
-                        ca = load_around(src, cand);
-                        hit = (BYU16 || cand + (uint32_t)DISTANCE_MAX >= pos) && ca.seq == pa.seq;
-                    }
-                }
-                const unsigned long long stop = __ballot(lane < W && (hit || !valid));
-                f = stop ? ctz64(stop) : W;
-                const bool fvalid = stop ? ((vmask >> f) & 1ull) != 0 : false;
-                const int ncommit = stop ? f + (fvalid ? 1 : 0) : W;
-
-                /* commit puts of lanes < ncommit in lane order (:213, :420) */
-                if ((dupmask & ((ncommit >= 64 ? 0ull : (1ull << ncommit)) - 1ull)) == 0) {
-                    if (lane < ncommit) tab.put(h, pos);
-                    wave_sync();
-                } else {
-                    for (uint32_t r = 0;; r++) {
-                        if (!__ballot(lane < ncommit && rank >= r)) break;
-                        if (lane < ncommit && rank == r) tab.put(h, pos);
-                        wave_sync();
-                    }
-                }
-                if (PROF) { const unsigned long long tn = prof_now<PROF>(); c_s4 += tn - ts; ts = tn; }
-                if (!stop) {
-                    jbase += (uint32_t)W - shift;
-                    shift = 0;
-                    continue;
-                }
-                if (!fvalid) break;                                 /* -> _last_literals */
-                test_hit = shift != 0u && f == 0;
-                ip = __builtin_amdgcn_readlane(pos, f);
-                match = __builtin_amdgcn_readlane(cand, f);
-                found = true;
-                break;
+            if (PROF) { c_s1 += ts - t0; n_round++; }
+            uint32_t h = 0, cand = 0;
+            if (valid) {
+                h = FastTable<BYU16>::hash_of(pa.seq, pa.next);
+                cand = tab.get(h);
+                scr[h & (uint32_t)(ENCODE_SCRATCH_BYTES - 1)] = (uint8_t)lane;
             }
-            if (!found) break;
+            if (PROF) { const unsigned long long tn = prof_now<PROF>(); c_s2 += tn - ts; ts = tn; }
+            const Around ca = load_around(src, cand);
+            wave_sync();
+            const bool flagged = valid && scr[h & (uint32_t)(ENCODE_SCRATCH_BYTES - 1)] != (uint8_t)lane;
+            const bool hit_tab = valid && (BYU16 || cand + (uint32_t)DISTANCE_MAX >= pos) && ca.seq == pa.seq;
+            const uint32_t info = extension_info(pa.pre, pa.next, pa.pre_ok, ca.pre, ca.next, ca.pre_ok, matchlimit - (pos + MINMATCH));
+            if (PROF) { const unsigned long long tn = prof_now<PROF>(); c_s3 += tn - ts; ts = tn; }
 
-            /* ---------------- extension from the hit lane's registers ---------------- */
-            const unsigned long long t1 = prof_now<PROF>();
-            const uint32_t lit0 = test_hit ? 0u : ip - anchor;
-            const uint32_t maxback = test_hit ? 0u : (lit0 < match ? lit0 : match);
-            const uint32_t fwd_max = matchlimit - (ip + MINMATCH);
-            uint32_t back = 0, code;
+            /* ---------------- groups: lanes of the window with equal hashes ---------------- */
+            unsigned long long G = me;
             {
-                const uint32_t a_pre = __builtin_amdgcn_readlane(pa.pre, f), b_pre = __builtin_amdgcn_readlane(ca.pre, f);
-                const uint32_t a_lo = __builtin_amdgcn_readlane((uint32_t)pa.next, f), a_hi = __builtin_amdgcn_readlane((uint32_t)(pa.next >> 32), f);
-                const uint32_t b_lo = __builtin_amdgcn_readlane((uint32_t)ca.next, f), b_hi = __builtin_amdgcn_readlane((uint32_t)(ca.next >> 32), f);
-                const bool pre_ok = (__ballot(pa.pre_ok && ca.pre_ok) >> f) & 1ull;
-                /* forward (:326-329): bytes ip+4.. vs match+4.. */
-                const uint64_t x = (((uint64_t)a_hi << 32) | a_lo) ^ (((uint64_t)b_hi << 32) | b_lo);
-                const uint32_t e = x ? (uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3 : 8u;
-                if (e == 8u && fwd_max > 8u) {
-                    if (PROF) n_rt3++;
-                    code = 8u + wave_count(src + ip + MINMATCH + 8u, src + match + MINMATCH + 8u, fwd_max - 8u, lane);
-                } else {
-                    code = e < fwd_max ? e : fwd_max;
+                unsigned long long fl = __ballot(flagged);
+                while (fl) {
+                    const int j = ctz64(fl);
+                    const uint32_t hj = __builtin_amdgcn_readlane(h, j);
+                    const bool same = valid && h == hj;
+                    const unsigned long long m = __ballot(same);
+                    if (same) G = m;
+                    fl &= ~m;
                 }
-                /* backward (:237-242): bytes ip-1, ip-2, .. vs match-1, .. */
+            }
+            const unsigned long long dirty = __ballot(G != me);
+            if (PROF) { const unsigned long long tn = prof_now<PROF>(); c_s4 += tn - ts; ts = tn; if (dirty) n_dup++; }
+
+            /* ---------------- resolve: every sequence that starts in the window ---------------- */
+            const unsigned long long t1 = prof_now<PROF>();
+            const unsigned long long hit_tab_m = __ballot(hit_tab), inv_m = __ballot(!valid), preok_m = __ballot(pa.pre_ok);
+            unsigned long long I = 0;          /* lanes whose position has been put into the table this round */
+            uint32_t q = 0;                    /* lane of the cursor */
+            bool q_test = shift != 0u;         /* the cursor is a position right after a match */
+            uint32_t k = 0;                    /* sequences found this round; sequence i sits in lane i */
+            int jl = -1;                       /* per lane: group lane that supplies the candidate, -1 = table */
+            uint32_t r_ls = 0, r_ll = 0, r_off = 0, r_mc = 0;
+            int outcome;                       /* 0 window exhausted, 1 next round starts after a match, 2 block ends */
+            for (;;) {
+                const unsigned long long geq = ~0ull << q;
+                unsigned long long hm = hit_tab_m;
+                if (dirty & geq) {
+                    const unsigned long long eff = G & below_me & (I | geq);
+                    jl = eff ? 63 - (int)__clzll((long long)eff) : -1;
+                    const uint32_t vj = (uint32_t)__shfl((int)pa.seq, jl & 63);
+                    hm = __ballot(valid && (jl >= 0 ? vj == pa.seq : hit_tab));
+                }
+                const unsigned long long stop = (hm | inv_m) & geq;
+                if (!stop) { I |= geq; outcome = 0; break; }
+                const int f = ctz64(stop);
+                if ((inv_m >> f) & 1ull) { outcome = 2; break; }    /* -> _last_literals (:172) */
+                I |= geq & ((2ull << f) - 1ull);
+                const uint32_t p = __builtin_amdgcn_readlane(pos, f);
+                const int jf = ((dirty >> f) & 1ull) ? (int)__builtin_amdgcn_readlane((uint32_t)jl, f) : -1;
+                uint32_t match, inf;
+                if (jf >= 0) {                                      /* candidate is a position of this window */
+                    match = __builtin_amdgcn_readlane(pos, jf);
+                    const uint64_t a_next = ((uint64_t)readlane_u32((uint32_t)(pa.next >> 32), f) << 32) | readlane_u32((uint32_t)pa.next, f);
+                    const uint64_t b_next = ((uint64_t)readlane_u32((uint32_t)(pa.next >> 32), jf) << 32) | readlane_u32((uint32_t)pa.next, jf);
+                    inf = extension_info(readlane_u32(pa.pre, f), a_next, ((preok_m >> f) & 1ull) != 0,
+                                         readlane_u32(pa.pre, jf), b_next, ((preok_m >> jf) & 1ull) != 0,
+                                         matchlimit - (p + MINMATCH));
+                } else {
+                    match = __builtin_amdgcn_readlane(cand, f);
+                    inf = __builtin_amdgcn_readlane(info, f);
+                }
+                const uint32_t lit0 = p - anchor;
+                const uint32_t maxback = lit0 < match ? lit0 : match;   /* :237-242 (0 right after a match) */
+                uint32_t code = inf & 15u, back = 0;
+                if (inf & 0x100u) {                                 /* :326-329 beyond the 12 known bytes */
+                    if (PROF) n_rt3++;
+                    code = 8u + wave_count(src + p + MINMATCH + 8u, src + match + MINMATCH + 8u, matchlimit - (p + MINMATCH) - 8u, lane);
+                }
                 if (maxback) {
-                    uint32_t nb = 0;
-                    if (pre_ok) {
-                        const uint32_t y = a_pre ^ b_pre;
-                        nb = y ? (uint32_t)__clz(y) >> 3 : 4u;
-                        back = nb < maxback ? nb : maxback;
-                    }
-                    if ((!pre_ok || nb == 4u) && back < maxback) {
+                    const uint32_t nb = (inf >> 4) & 7u;
+                    back = nb < maxback ? nb : maxback;
+                    if ((!(inf & 0x200u) || nb == 4u) && back < maxback) {
                         if (PROF) n_rt3++;
                         while (back < maxback) {
                             const uint32_t i = back + (uint32_t)lane;
-                            const bool eq = i < maxback && src[ip - 1u - i] == src[match - 1u - i];
+                            const bool eq = i < maxback && src[p - 1u - i] == src[match - 1u - i];
                             const unsigned long long ne2 = ~__ballot(eq);
                             const int run = ne2 ? ctz64(ne2) : 64;
                             back += (uint32_t)run;
@@ -358,81 +312,111 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                         }
                     }
                 }
+                const uint32_t e_end = p + MINMATCH + code;
+#ifdef K4_DEBUG_ENC
+                if (sequences + k < 8u) {
+                    uint32_t *dbg = (uint32_t *)(dst + 40000) + 32u * (sequences + k);
+                    if (lane == 0) {
+                        dbg[0] = ip0; dbg[1] = q; dbg[2] = (uint32_t)f; dbg[3] = p; dbg[4] = (uint32_t)jf; dbg[5] = match; dbg[6] = inf;
+                        dbg[7] = lit0; dbg[8] = back; dbg[9] = code; dbg[10] = (uint32_t)dirty; dbg[11] = (uint32_t)(dirty >> 32);
+                        dbg[12] = (uint32_t)hm; dbg[13] = (uint32_t)(hm >> 32); dbg[14] = (uint32_t)I; dbg[15] = (uint32_t)(I >> 32);
+                    }
+                    if (lane == f) { dbg[16] = (uint32_t)G; dbg[17] = (uint32_t)(G >> 32); dbg[18] = (uint32_t)jl; dbg[19] = info; dbg[20] = h; dbg[21] = cand; dbg[22] = pos;
+                                     dbg[23] = (uint32_t)pa.next; dbg[24] = (uint32_t)(pa.next >> 32); dbg[25] = pa.pre; }
+                }
+#endif
+                if ((uint32_t)lane == k) { r_ls = anchor; r_ll = lit0 - back; r_off = p - match; r_mc = code + back; }
+                k++;
+                anchor = e_end;
+                if (e_end >= mflimit_plus_one) { outcome = 2; break; }   /* :391 */
+                if (!contig || e_end - ip0 >= 64u) { outcome = 1; break; }
+                q = e_end - ip0;
+                I |= 1ull << (q - 2u);                              /* :394 */
+                q_test = true;
             }
-            const uint32_t ip_end = ip + MINMATCH + code;
-            ip -= back;
-            match -= back;
-            code += back;
+            sequences += k;
+            if (PROF) n_seq += k;
 
-            /* ---------------- emit into the LDS stage (:244-382) ---------------- */
+            /* ---------------- commit the visited positions, one writer per hash ---------------- */
             const unsigned long long t2 = prof_now<PROF>();
-            st.reserve((uint32_t)op, 1u + 64u + 2u, lane);
-            uint32_t token_pos = (uint32_t)op;
-            uint32_t token = 0;
-            op++;
-            if (!test_hit) {
-                const uint32_t lit = ip - anchor;
-                if (limited && op + lit + (2 + 1 + LASTLITERALS) + lit / 255u > olimit) return 0;
-                if (lit >= (uint32_t)RUN_MASK) {
-                    token = (uint32_t)RUN_MASK << ML_BITS;
-                    op = emit_length_run(st, (uint32_t)op, lit - RUN_MASK, lane);
-                } else {
-                    token = lit << ML_BITS;
+            if (outcome != 2) {
+                if (((I >> lane) & 1ull) && (G & I & ~(below_me | me)) == 0ull) tab.put(h, pos);
+            }
+
+            /* ---------------- emit the k sequences (:244-382) ---------------- */
+            if (k) {
+                const bool mine = (uint32_t)lane < k;
+                const uint32_t ll = mine ? r_ll : 0u, mc = mine ? r_mc : 0u;
+                const uint32_t lx = ll >= (uint32_t)RUN_MASK ? (ll - RUN_MASK) / 255u + 1u : 0u;
+                const uint32_t mx = mc >= (uint32_t)ML_MASK ? (mc - ML_MASK) / 255u + 1u : 0u;
+                const uint32_t sz = mine ? 1u + lx + ll + 2u + mx : 0u;
+                const uint32_t incl = wave_inclusive_scan(sz);
+                const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+                const uint32_t o_tok = op + incl - sz;
+                const uint32_t o_lit = o_tok + 1u + lx, o_off = o_lit + ll, o_mx = o_off + 2u;
+                if (limited) {                                      /* :251-255, :346-350 */
+                    const bool fail = mine && ((uint64_t)o_tok + 1u + ll + (2 + 1 + LASTLITERALS) + ll / 255u > olimit ||
+                                               (uint64_t)o_mx + (1 + LASTLITERALS) + (mc + 240u) / 255u > olimit);
+                    if (__ballot(fail)) return 0;
                 }
-                if (lit <= 64u) {
-                    st.reserve((uint32_t)op, 64u + 2u, lane);
-                    if ((uint32_t)lane < lit) *st.at((uint32_t)op + (uint32_t)lane) = litbyte;
-                } else {
-                    st.flush_to((uint32_t)op, lane);
-                    if (!dry) wave_copy(dst + op, src + anchor, lit, lane);
-                    st.base = (uint32_t)op + lit;
+                if (!dry) {
+                    if (mine) {
+                        dst[o_tok] = (uint8_t)(((ll < (uint32_t)RUN_MASK ? ll : (uint32_t)RUN_MASK) << ML_BITS) |
+                                               (mc < (uint32_t)ML_MASK ? mc : (uint32_t)ML_MASK));
+                        if (lx == 1u) dst[o_tok + 1u] = (uint8_t)(ll - RUN_MASK);
+                        if (ll != 0u && ll <= LANE_COPY_MAX) lane_copy32(dst + o_lit, src + r_ls, ll, U - r_ls);
+                        ((U16u *)(dst + o_off))->v = (uint16_t)r_off;   /* :299-304 */
+                        if (mx == 1u) dst[o_mx] = (uint8_t)(mc - ML_MASK);
+                    }
+                    unsigned long long big = __ballot(mine && (ll > LANE_COPY_MAX || lx > 1u || mx > 1u));
+                    while (big) {
+                        const int g = ctz64(big);
+                        big &= big - 1ull;
+                        const uint32_t g_ll = __builtin_amdgcn_readlane(ll, g), g_mc = __builtin_amdgcn_readlane(mc, g);
+                        const uint32_t g_tok = __builtin_amdgcn_readlane(o_tok, g);
+                        if (g_ll >= (uint32_t)RUN_MASK + 255u) emit_length_run(dst, g_tok + 1u, g_ll - RUN_MASK, lane);
+                        if (g_ll > LANE_COPY_MAX)
+                            wave_copy(dst + __builtin_amdgcn_readlane(o_lit, g), src + __builtin_amdgcn_readlane(r_ls, g), g_ll, lane);
+                        if (g_mc >= (uint32_t)ML_MASK + 255u) emit_length_run(dst, __builtin_amdgcn_readlane(o_mx, g), g_mc - ML_MASK, lane);
+                    }
                 }
-                op += lit;
+                op += total;
             }
-            if (token_pos < st.base) {                              /* token already left the stage */
-                st.flush_to((uint32_t)op, lane);
-            }
-            st.reserve((uint32_t)op, 2u, lane);
-            if (lane == 0) {                                        /* offset (:299-304) */
-                const uint32_t off = ip - match;
-                uint8_t *o = st.at((uint32_t)op);
-                o[0] = (uint8_t)off;
-                o[1] = (uint8_t)(off >> 8);
-            }
-            op += 2;
-            if (limited && op + (1 + LASTLITERALS) + (code + 240u) / 255u > olimit) return 0;
-            if (code >= (uint32_t)ML_MASK) {
-                token += ML_MASK;
-                op = emit_length_run(st, (uint32_t)op, code - ML_MASK, lane);
+            if (PROF) { const unsigned long long t3 = prof_now<PROF>(); c_probe += t1 - t0; c_ext += t2 - t1; c_emit += t3 - t2; }
+
+            /* ---------------- where the next round starts ---------------- */
+            if (outcome == 2) break;
+            if (outcome == 1) {
+                ip = anchor;
+                test = true;
+                jbase = 0;
+            } else if (contig) {
+                const uint32_t qs = q + (q_test ? 1u : 0u);         /* lane where the running search started */
+                sbase = ip0 + qs;
+                jbase = 64u - qs;
+                test = false;
+                ip = sbase;
             } else {
-                token += code;
+                jbase += 64u - shift;
+                test = false;
             }
-            if (lane == 0) {
-                if (token_pos >= st.base) *st.at(token_pos) = (uint8_t)token;
-                else if (!dry) dst[token_pos] = (uint8_t)token;
-            }
-            ip = ip_end;
-            anchor = ip;
-            sequences++;
-            if (PROF) { const unsigned long long t3 = prof_now<PROF>(); c_probe += t1 - t0; c_ext += t2 - t1; c_emit += t3 - t2; n_seq++; }
-            if (ip >= mflimit_plus_one) break;                      /* :391 */
-            test = true;
         }
     }
 
     /* ---- _last_literals (:469-503) ---- */
     {
         const uint32_t last_run = U - anchor;
-        if (limited && op + last_run + 1 + (last_run + 255u - RUN_MASK) / 255u > olimit) return 0;
-        st.reserve((uint32_t)op, 1u, lane);
+        if (limited && (uint64_t)op + last_run + 1u + (last_run + 255u - RUN_MASK) / 255u > olimit) return 0;
         if (last_run >= (uint32_t)RUN_MASK) {
-            if (lane == 0) *st.at((uint32_t)op) = (uint8_t)(RUN_MASK << ML_BITS);
-            op = emit_length_run(st, (uint32_t)op + 1u, last_run - RUN_MASK, lane);
+            if (!dry) {
+                if (lane == 0) dst[op] = (uint8_t)(RUN_MASK << ML_BITS);
+                emit_length_run(dst, op + 1u, last_run - RUN_MASK, lane);
+            }
+            op += 2u + (last_run - RUN_MASK) / 255u;
         } else {
-            if (lane == 0) *st.at((uint32_t)op) = (uint8_t)(last_run << ML_BITS);
+            if (!dry && lane == 0) dst[op] = (uint8_t)(last_run << ML_BITS);
             op++;
         }
-        st.flush_to((uint32_t)op, lane);
         if (!dry) wave_copy(dst + op, src + anchor, last_run, lane);
         op += last_run;
     }
@@ -536,7 +520,7 @@ __global__ __launch_bounds__(64) void k4_encode_fast_kernel(BatchArgs a)
  * only the output stage in LDS: twice as many blocks resident per CU, each a little slower */
 __global__ __launch_bounds__(64) void k4_encode_fast_gtab_kernel(BatchArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t stage[ENCODE_STAGE_BYTES / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[ENCODE_SCRATCH_BYTES / 4];
     const int lane = lane_id();
     const long long b = a.order ? (long long)uni(a.order[blockIdx.x]) : (long long)blockIdx.x;
     const int src_len = a.srcLen[b];

@@ -107,7 +107,7 @@ static inline int __ffs(unsigned x) { return __builtin_ffs((int)x); }
 static inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 static inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
 
-static inline uint32_t __builtin_amdgcn_readlane(uint32_t v, int lane) { return k4emu_shfl_idx(v, lane); }
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return (int)k4emu_shfl_idx((uint32_t)v, lane); }   /* int, as the real builtin: widening sign-extends */
 static inline int __builtin_amdgcn_ds_bpermute(int addr, int data) { return (int)k4emu_shfl_idx((uint32_t)data, (addr >> 2) & 63); }
 static inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t v) { return k4emu_shfl_idx(v, 0); }
 static inline uint32_t __builtin_amdgcn_mbcnt_lo(uint32_t mask, uint32_t add) {
