@@ -26,6 +26,9 @@
 #pragma once
 #include "k4lz4_common.hpp"
 
+#ifdef K4_EMU_COUNTERS
+extern "C" unsigned long long k4emu_cnt[8];
+#endif
 namespace k4 {
 
 template <bool BYU16> struct FastTable;
@@ -111,6 +114,8 @@ __device__ __forceinline__ Around load_around(const uint8_t *src, uint32_t p)
     }
     return a;
 }
+
+__device__ __forceinline__ unsigned long long geq_of(uint32_t q) { return ~0ull << q; }
 
 /* What the 16+16 bytes around a position and its candidate say about the match extension:
  * bits 0-3 forward bytes beyond MINMATCH (0..8, capped at fwd_max), bits 4-6 equal bytes backwards
@@ -221,20 +226,20 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             }
             wave_sync();
             unsigned long long ts = prof_now<PROF>();
-            if (PROF) { c_s1 += ts - t0; n_round++; }
+            if (PROF) { n_round++; }
             uint32_t h = 0, cand = 0;
             if (valid) {
                 h = FastTable<BYU16>::hash_of(pa.seq, pa.next);
                 cand = tab.get(h);
                 scr[h & (uint32_t)(ENCODE_SCRATCH_BYTES - 1)] = (uint8_t)lane;
             }
-            if (PROF) { const unsigned long long tn = prof_now<PROF>(); c_s2 += tn - ts; ts = tn; }
+            if (PROF) { ts = prof_now<PROF>(); }
             const Around ca = load_around(src, cand);
             wave_sync();
             const bool flagged = valid && scr[h & (uint32_t)(ENCODE_SCRATCH_BYTES - 1)] != (uint8_t)lane;
             const bool hit_tab = valid && (BYU16 || cand + (uint32_t)DISTANCE_MAX >= pos) && ca.seq == pa.seq;
             const uint32_t info = extension_info(pa.pre, pa.next, pa.pre_ok, ca.pre, ca.next, ca.pre_ok, matchlimit - (pos + MINMATCH));
-            if (PROF) { const unsigned long long tn = prof_now<PROF>(); c_s3 += tn - ts; ts = tn; }
+            if (PROF) { ts = prof_now<PROF>(); }
 
             /* ---------------- groups: lanes of the window with equal hashes ---------------- */
             unsigned long long G = me;
@@ -250,102 +255,161 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 }
             }
             const unsigned long long dirty = __ballot(G != me);
-            if (PROF) { const unsigned long long tn = prof_now<PROF>(); c_s4 += tn - ts; ts = tn; if (dirty) n_dup++; }
+            if (PROF) { ts = prof_now<PROF>(); }
 
             /* ---------------- resolve: every sequence that starts in the window ---------------- */
             const unsigned long long t1 = prof_now<PROF>();
-            const unsigned long long hit_tab_m = __ballot(hit_tab), inv_m = __ballot(!valid), preok_m = __ballot(pa.pre_ok);
+            const unsigned long long inv_m = __ballot(!valid), preok_m = __ballot(pa.pre_ok);
+            const uint32_t fwd_max = matchlimit - (pos + MINMATCH);
+            const uint32_t anchor_in = anchor;
+            /* per lane: the candidate as the table and the visited positions of this round define it */
+            uint32_t cpos = cand, cinfo = info;
+            bool chit = hit_tab;
+            unsigned long long skipped = 0;    /* lanes inside matches: never put into the table */
+            unsigned long long hm, long_m, cand_m;   /* hits; hits whose match runs past the known bytes; lanes that are candidates */
+            uint32_t epos;                     /* per lane: where its match would end */
+            auto candidates = [&]() {          /* general form: highest visited-or-future lane of the group below this one */
+                const unsigned long long eff = G & below_me & ~skipped;
+                const int j = eff ? 63 - (int)__clzll((long long)eff) : -1;
+                const int sj = j & 63;
+                const uint32_t vj = (uint32_t)__shfl((int)pa.seq, sj), pj = (uint32_t)__shfl((int)pa.pre, sj);
+                const uint32_t nlo = (uint32_t)__shfl((int)(uint32_t)pa.next, sj), nhi = (uint32_t)__shfl((int)(uint32_t)(pa.next >> 32), sj);
+                const uint32_t posj = (uint32_t)__shfl((int)pos, sj);
+                const bool okj = ((preok_m >> sj) & 1ull) != 0;
+                if (j >= 0) {
+                    chit = valid && vj == pa.seq;
+                    cpos = posj;
+                    cinfo = extension_info(pa.pre, pa.next, pa.pre_ok, pj, ((uint64_t)nhi << 32) | nlo, okj, fwd_max);
+                } else {
+                    chit = hit_tab;
+                    cpos = cand;
+                    cinfo = info;
+                }
+            };
+            auto publish = [&]() {
+                hm = __ballot(chit);
+                long_m = __ballot((cinfo & 0x100u) != 0u);
+                epos = pos + MINMATCH + (cinfo & 15u);
+                /* a visited-or-future lane with a later lane in its group may be that lane's candidate */
+                cand_m = __ballot(((skipped >> lane) & 1ull) == 0ull && (G & ~(below_me | me)) != 0ull);
+            };
+            /* the common group is a pair: the later lane's candidate is the earlier lane while that one counts
+             * as visited, else the table entry -- both known up front, so losing a candidate is a select */
+            const unsigned long long gb = G & below_me;
+            const int j1 = gb ? 63 - (int)__clzll((long long)gb) : -1;
+            const unsigned long long multi_m = __ballot((gb & (gb - 1ull)) != 0ull);
+            bool hit1 = hit_tab, general = false;
+            uint32_t pos1 = cand, info1 = info;
+            if (dirty) {
+                candidates();
+                hit1 = chit; pos1 = cpos; info1 = cinfo;
+            }
+            publish();
+            const unsigned long long ta = prof_now<PROF>();
+            if (PROF) c_s1 += ta - t1;
+            unsigned long long t_rec = 0;
             unsigned long long I = 0;          /* lanes whose position has been put into the table this round */
+            unsigned long long hits = 0;       /* lanes where a sequence's match starts (before backward extension) */
+            unsigned long long cursors = 1;    /* lanes where a search started: lane 0 and the lanes right after matches */
             uint32_t q = 0;                    /* lane of the cursor */
             bool q_test = shift != 0u;         /* the cursor is a position right after a match */
-            uint32_t k = 0;                    /* sequences found this round; sequence i sits in lane i */
-            int jl = -1;                       /* per lane: group lane that supplies the candidate, -1 = table */
-            uint32_t r_ls = 0, r_ll = 0, r_off = 0, r_mc = 0;
+            uint32_t xcode = 0xffffffffu;      /* per lane: match length found by the slow forward count */
             int outcome;                       /* 0 window exhausted, 1 next round starts after a match, 2 block ends */
-            for (;;) {
+            bool cont;
+            /* one hop per sequence; written with selects so that the loop keeps a single exit */
+            do {
                 const unsigned long long geq = ~0ull << q;
-                unsigned long long hm = hit_tab_m;
-                if (dirty & geq) {
-                    const unsigned long long eff = G & below_me & (I | geq);
-                    jl = eff ? 63 - (int)__clzll((long long)eff) : -1;
-                    const uint32_t vj = (uint32_t)__shfl((int)pa.seq, jl & 63);
-                    hm = __ballot(valid && (jl >= 0 ? vj == pa.seq : hit_tab));
-                }
                 const unsigned long long stop = (hm | inv_m) & geq;
-                if (!stop) { I |= geq; outcome = 0; break; }
-                const int f = ctz64(stop);
-                if ((inv_m >> f) & 1ull) { outcome = 2; break; }    /* -> _last_literals (:172) */
-                I |= geq & ((2ull << f) - 1ull);
-                const uint32_t p = __builtin_amdgcn_readlane(pos, f);
-                const int jf = ((dirty >> f) & 1ull) ? (int)__builtin_amdgcn_readlane((uint32_t)jl, f) : -1;
-                uint32_t match, inf;
-                if (jf >= 0) {                                      /* candidate is a position of this window */
-                    match = __builtin_amdgcn_readlane(pos, jf);
-                    const uint64_t a_next = ((uint64_t)readlane_u32((uint32_t)(pa.next >> 32), f) << 32) | readlane_u32((uint32_t)pa.next, f);
-                    const uint64_t b_next = ((uint64_t)readlane_u32((uint32_t)(pa.next >> 32), jf) << 32) | readlane_u32((uint32_t)pa.next, jf);
-                    inf = extension_info(readlane_u32(pa.pre, f), a_next, ((preok_m >> f) & 1ull) != 0,
-                                         readlane_u32(pa.pre, jf), b_next, ((preok_m >> jf) & 1ull) != 0,
-                                         matchlimit - (p + MINMATCH));
-                } else {
-                    match = __builtin_amdgcn_readlane(cand, f);
-                    inf = __builtin_amdgcn_readlane(info, f);
-                }
-                const uint32_t lit0 = p - anchor;
-                const uint32_t maxback = lit0 < match ? lit0 : match;   /* :237-242 (0 right after a match) */
-                uint32_t code = inf & 15u, back = 0;
-                if (inf & 0x100u) {                                 /* :326-329 beyond the 12 known bytes */
+                const bool any = stop != 0ull;
+                const int f = any ? ctz64(stop) : 63;
+                const unsigned long long fbit = 1ull << f;
+                const bool is_hit = any && (inv_m & fbit) == 0ull;  /* else: window exhausted, or -> _last_literals (:172) */
+                I |= any ? (geq & ((fbit << 1) - 1ull)) : geq;
+                hits |= is_hit ? fbit : 0ull;
+                uint32_t e_end = readlane_u32(epos, f);
+                if (is_hit && (long_m & fbit) != 0ull) {            /* :326-329 beyond the 12 known bytes */
                     if (PROF) n_rt3++;
-                    code = 8u + wave_count(src + p + MINMATCH + 8u, src + match + MINMATCH + 8u, matchlimit - (p + MINMATCH) - 8u, lane);
+                    const uint32_t p = readlane_u32(pos, f), match = readlane_u32(cpos, f);
+                    const uint32_t code = 8u + wave_count(src + p + MINMATCH + 8u, src + match + MINMATCH + 8u, matchlimit - (p + MINMATCH) - 8u, lane);
+                    if (lane == f) xcode = code;
+                    e_end = p + MINMATCH + code;
                 }
-                if (maxback) {
-                    const uint32_t nb = (inf >> 4) & 7u;
-                    back = nb < maxback ? nb : maxback;
-                    if ((!(inf & 0x200u) || nb == 4u) && back < maxback) {
-                        if (PROF) n_rt3++;
-                        while (back < maxback) {
-                            const uint32_t i = back + (uint32_t)lane;
-                            const bool eq = i < maxback && src[p - 1u - i] == src[match - 1u - i];
-                            const unsigned long long ne2 = ~__ballot(eq);
-                            const int run = ne2 ? ctz64(ne2) : 64;
-                            back += (uint32_t)run;
-                            if (run < 64) break;
-                        }
+                const uint32_t qn = e_end - ip0;
+                const bool fin = e_end >= mflimit_plus_one;         /* :391 */
+                cont = is_hit && !fin && contig && qn < 64u;
+                outcome = !any ? 0 : ((!is_hit || fin) ? 2 : 1);
+                anchor = is_hit ? e_end : anchor;
+                /* lanes f+1 .. qn-1 except qn-2 are never visited: a lane whose candidate is one of them falls
+                 * back to the next visited lane of its group (or to the table); qn-2 is the put of :394 */
+                const unsigned long long qbit = cont ? 1ull << (qn & 63u) : 0ull;
+                const unsigned long long sk = cont ? ((~1ull << f) & (qbit - 1ull) & ~(qbit >> 2)) : 0ull;
+                cursors |= qbit;
+                I |= qbit >> 2;
+                skipped |= sk;
+                q = cont ? qn : q;
+                q_test = q_test || cont;
+                if (sk & cand_m) {
+                    const unsigned long long tr0 = prof_now<PROF>();
+                    if (PROF) n_dup++;
+                    const bool lost = j1 >= 0 && ((skipped >> (j1 & 63)) & 1ull) != 0ull;
+                    if (!general && (__ballot(lost) & multi_m)) general = true;
+                    if (general) {
+                        candidates();
+                    } else {
+                        chit = lost ? hit_tab : hit1;
+                        cpos = lost ? cand : pos1;
+                        cinfo = lost ? info : info1;
                     }
+                    publish();
+                    if (PROF) t_rec += prof_now<PROF>() - tr0;
                 }
-                const uint32_t e_end = p + MINMATCH + code;
-#ifdef K4_DEBUG_ENC
-                if (sequences + k < 8u) {
-                    uint32_t *dbg = (uint32_t *)(dst + 40000) + 32u * (sequences + k);
-                    if (lane == 0) {
-                        dbg[0] = ip0; dbg[1] = q; dbg[2] = (uint32_t)f; dbg[3] = p; dbg[4] = (uint32_t)jf; dbg[5] = match; dbg[6] = inf;
-                        dbg[7] = lit0; dbg[8] = back; dbg[9] = code; dbg[10] = (uint32_t)dirty; dbg[11] = (uint32_t)(dirty >> 32);
-                        dbg[12] = (uint32_t)hm; dbg[13] = (uint32_t)(hm >> 32); dbg[14] = (uint32_t)I; dbg[15] = (uint32_t)(I >> 32);
-                    }
-                    if (lane == f) { dbg[16] = (uint32_t)G; dbg[17] = (uint32_t)(G >> 32); dbg[18] = (uint32_t)jl; dbg[19] = info; dbg[20] = h; dbg[21] = cand; dbg[22] = pos;
-                                     dbg[23] = (uint32_t)pa.next; dbg[24] = (uint32_t)(pa.next >> 32); dbg[25] = pa.pre; }
-                }
-#endif
-                if ((uint32_t)lane == k) { r_ls = anchor; r_ll = lit0 - back; r_off = p - match; r_mc = code + back; }
-                k++;
-                anchor = e_end;
-                if (e_end >= mflimit_plus_one) { outcome = 2; break; }   /* :391 */
-                if (!contig || e_end - ip0 >= 64u) { outcome = 1; break; }
-                q = e_end - ip0;
-                I |= 1ull << (q - 2u);                              /* :394 */
-                q_test = true;
-            }
+            } while (cont);
+            const unsigned long long tb = prof_now<PROF>();
+            if (PROF) { c_s2 += tb - ta - t_rec; c_s3 += t_rec; }
+            const uint32_t k = (uint32_t)__popcll(hits);
             sequences += k;
             if (PROF) n_seq += k;
 
+            /* per hit lane: literal run, backward extension (:237-242), the sequence's numbers */
+            const bool mine = ((hits >> lane) & 1ull) != 0ull;
+            uint32_t r_ls = 0, r_ll = 0, r_off = 0, r_mc = 0;
+            if (k) {
+                const unsigned long long cb = cursors & (below_me | me);                   /* bit 0 is always set */
+                const uint32_t cq = 63u - (uint32_t)__clzll((long long)cb);
+                const uint32_t anchor_l = cq == 0u ? anchor_in : ip0 + cq;
+                const uint32_t lit0 = pos - anchor_l;
+                const uint32_t maxback = lit0 < cpos ? lit0 : cpos;               /* 0 right after a match */
+                const uint32_t nb = (cinfo >> 4) & 7u;
+                uint32_t back = nb < maxback ? nb : maxback;
+                unsigned long long slow = __ballot(mine && (!(cinfo & 0x200u) || nb == 4u) && back < maxback);
+                while (slow) {
+                    const int g = ctz64(slow);
+                    slow &= slow - 1ull;
+                    if (PROF) n_rt3++;
+                    const uint32_t p = readlane_u32(pos, g), match = readlane_u32(cpos, g), mb = readlane_u32(maxback, g);
+                    uint32_t b = readlane_u32(back, g);
+                    while (b < mb) {
+                        const uint32_t i = b + (uint32_t)lane;
+                        const bool eq = i < mb && src[p - 1u - i] == src[match - 1u - i];
+                        const unsigned long long ne2 = ~__ballot(eq);
+                        const int run = ne2 ? ctz64(ne2) : 64;
+                        b += (uint32_t)run;
+                        if (run < 64) break;
+                    }
+                    if (lane == g) back = b;
+                }
+                const uint32_t code = xcode != 0xffffffffu ? xcode : (cinfo & 15u);
+                r_ls = anchor_l; r_ll = lit0 - back; r_off = pos - cpos; r_mc = code + back;
+            }
             /* ---------------- commit the visited positions, one writer per hash ---------------- */
             const unsigned long long t2 = prof_now<PROF>();
+            if (PROF) c_s4 += t2 - tb;
             if (outcome != 2) {
                 if (((I >> lane) & 1ull) && (G & I & ~(below_me | me)) == 0ull) tab.put(h, pos);
             }
 
             /* ---------------- emit the k sequences (:244-382) ---------------- */
             if (k) {
-                const bool mine = (uint32_t)lane < k;
                 const uint32_t ll = mine ? r_ll : 0u, mc = mine ? r_mc : 0u;
                 const uint32_t lx = ll >= (uint32_t)RUN_MASK ? (ll - RUN_MASK) / 255u + 1u : 0u;
                 const uint32_t mx = mc >= (uint32_t)ML_MASK ? (mc - ML_MASK) / 255u + 1u : 0u;

@@ -50,8 +50,8 @@ for decode in (False, True):
     print("%-8s " % "ALL" + " ".join("%10.0f" % v for v in m[:8]))
     if not decode:
         d = c[np.arange(0, n, 12)].mean(axis=0)
-        print("dickens probe stages per sequence: s1(src loads+put) %.0f  s2(hash+table) %.0f  s3(cand loads+cmp) %.0f  s4(dedup+commit) %.0f" % tuple(d[11:15] / d[4]))
-        print("ALL     probe stages per sequence: s1 %.0f s2 %.0f s3 %.0f s4 %.0f" % tuple(m[11:15] / m[4]))
+        print("dickens resolve split per round: initial candidates %.0f  hop loop %.0f  recompute %.0f  post %.0f ; recomputes/round %.2f" % (tuple(d[11:15] / d[5]) + (d[6] / d[5],)))
+        print("ALL     resolve split per round: initial %.0f hop %.0f recompute %.0f post %.0f" % tuple(m[11:15] / m[5]))
     st, en = c[:, 8], c[:, 9]
     ev = sorted([(t, 1) for t in st] + [(t, -1) for t in en])
     cur = mx = 0
