@@ -38,6 +38,7 @@ struct k4lz4_ctx {
     uint8_t *d_meta = nullptr; size_t d_meta_cap = 0;
     uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;
     uint8_t *d_sched = nullptr; size_t d_sched_cap = 0;   /* dispatch-order scratch: cost[n], order[n], counters */
+    int cu_count = 256;
     uint8_t *d_dict = nullptr; size_t d_dict_cap = 0;         /* host-pointer decode with dictionaries: staged dictionaries + their metadata */
     uint8_t *d_gtab = nullptr; size_t d_gtab_cap = 0;         /* fast encoder: hash tables of the blocks encoded without an LDS table */
     hipStream_t aux = nullptr;                                /* second queue: those blocks run beside the LDS-table kernel */
@@ -197,9 +198,12 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
                 /* Only 8 blocks per CU fit with their hash table in LDS.  The most expensive blocks
                  * (front of the dispatch order) take those slots; the others are encoded at the same
                  * time on a second queue by the global-memory-table variant of the kernel. */
+                /* measured on MI355X (profiles/r02_split_sweep.txt): best when the LDS-table kernel gets about 45% of
+                 * a large batch, and no more than ~7 blocks per CU when the batch is small */
                 const char *pct_env = getenv("K4LZ4_SPLIT_PCT");
-                const int64_t pct = pct_env ? atoi(pct_env) : 45;
-                const int64_t n_lds = pct_env ? std::max<int64_t>(1, cnt * pct / 100) : std::max<int64_t>(std::min<int64_t>(cnt, 2048), cnt * 45 / 100);
+                const int64_t lds_slots = 7 * (int64_t)ctx->cu_count;
+                const int64_t n_lds = pct_env ? std::max<int64_t>(1, cnt * atoi(pct_env) / 100)
+                                              : std::min<int64_t>(cnt, std::max<int64_t>(lds_slots, cnt * 45 / 100));
                 const int64_t n_g = cnt - n_lds;
                 const int64_t gchunk = 8192;
                 if ((size_t)std::min(n_g, gchunk) * 16384 > ctx->d_gtab_cap) {
@@ -437,6 +441,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     k4lz4_ctx *ctx = new (std::nothrow) k4lz4_ctx();
     if (!ctx) return fail(nullptr, K4LZ4_E_NOMEM, "out of host memory");
     ctx->device = device;
+    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking);

@@ -196,6 +196,31 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
         uint32_t jbase = 0;    /* probes of the current search already done (0: fresh round) */
         bool test = false;     /* fresh round only: `ip` is the position right after a match (:393-463) */
 
+        /* the 64 probe positions of a round and their source bytes; issued for the NEXT round before the
+         * current one commits and emits, so that the loads fly during that work */
+        uint32_t pos_n;
+        bool valid_n;
+        Around pa_n;
+        auto prepare = [&]() {
+            const bool fresh_n = jbase == 0u;
+            const uint32_t sbase_n = fresh_n ? (test ? ip + 1u : ip) : sbase;
+            const uint32_t shift_n = (fresh_n && test) ? 1u : 0u;
+            const bool t0 = shift_n != 0u && lane == 0;
+            const uint32_t j = jbase + (uint32_t)lane - (t0 ? 0u : shift_n);
+            uint32_t npos;
+            if (fresh_n && accel == 1u) {
+                pos_n = t0 ? ip : sbase_n + j;
+                npos = sbase_n + j + 1u;
+            } else {
+                pos_n = t0 ? ip : sbase_n + probe_offset(j, accel);
+                npos = sbase_n + probe_offset(j + 1u, accel);
+            }
+            valid_n = t0 || (npos <= mflimit_plus_one && npos >= sbase_n);   /* :172 */
+            pa_n.pre = 0; pa_n.seq = 0; pa_n.next = 0; pa_n.pre_ok = false;
+            if (valid_n) pa_n = load_around(src, pos_n);
+        };
+        prepare();
+
         for (;;) {
             /* ---------------- load: positions, hashes, candidates ---------------- */
             const unsigned long long t0 = prof_now<PROF>();
@@ -203,23 +228,10 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             if (fresh) sbase = test ? ip + 1u : ip;
             const bool contig = fresh && accel == 1u;               /* lane l probes position ip + l */
             const uint32_t shift = (fresh && test) ? 1u : 0u;       /* lane 0 = the test probe */
-            const bool is_test0 = shift != 0u && lane == 0;
             const uint32_t ip0 = ip;
-            uint32_t pos, npos;
-            {
-                const uint32_t j = jbase + (uint32_t)lane - (is_test0 ? 0u : shift);
-                if (contig) {
-                    pos = is_test0 ? ip : sbase + j;
-                    npos = sbase + j + 1u;
-                } else {
-                    pos = is_test0 ? ip : sbase + probe_offset(j, accel);
-                    npos = sbase + probe_offset(j + 1u, accel);
-                }
-            }
-            const bool valid = is_test0 || (npos <= mflimit_plus_one && npos >= sbase);   /* :172 */
-            Around pa;
-            pa.pre = 0; pa.seq = 0; pa.next = 0; pa.pre_ok = false;
-            if (valid) pa = load_around(src, pos);
+            const uint32_t pos = pos_n;
+            const bool valid = valid_n;
+            const Around pa = pa_n;
             if (shift) {
                 const uint32_t h2 = FastTable<BYU16>::hash(src + ip - 2);
                 if (lane == 0) tab.put(h2, ip - 2u);                /* :394 */
@@ -372,7 +384,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
 
             /* per hit lane: literal run, backward extension (:237-242), the sequence's numbers */
             const bool mine = ((hits >> lane) & 1ull) != 0ull;
-            uint32_t r_ls = 0, r_ll = 0, r_off = 0, r_mc = 0;
+            uint32_t r_ls = 0, r_ll = 0, r_off = 0, r_mc = 0, r_cq = 0, r_back = 0;
             if (k) {
                 const unsigned long long cb = cursors & (below_me | me);                   /* bit 0 is always set */
                 const uint32_t cq = 63u - (uint32_t)__clzll((long long)cb);
@@ -399,8 +411,27 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                     if (lane == g) back = b;
                 }
                 const uint32_t code = xcode != 0xffffffffu ? xcode : (cinfo & 15u);
-                r_ls = anchor_l; r_ll = lit0 - back; r_off = pos - cpos; r_mc = code + back;
+                r_ls = anchor_l; r_ll = lit0 - back; r_off = pos - cpos; r_mc = code + back; r_cq = cq; r_back = back;
             }
+            /* ---------------- where the next round starts; its source loads go out now ---------------- */
+            if (outcome == 1) {
+                ip = anchor;
+                test = true;
+                jbase = 0;
+            } else if (outcome == 0) {
+                if (contig) {
+                    const uint32_t qs = q + (q_test ? 1u : 0u);     /* lane where the running search started */
+                    sbase = ip0 + qs;
+                    jbase = 64u - qs;
+                    test = false;
+                    ip = sbase;
+                } else {
+                    jbase += 64u - shift;
+                    test = false;
+                }
+            }
+            if (outcome != 2) prepare();
+
             /* ---------------- commit the visited positions, one writer per hash ---------------- */
             const unsigned long long t2 = prof_now<PROF>();
             if (PROF) c_s4 += t2 - tb;
@@ -428,42 +459,47 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                         dst[o_tok] = (uint8_t)(((ll < (uint32_t)RUN_MASK ? ll : (uint32_t)RUN_MASK) << ML_BITS) |
                                                (mc < (uint32_t)ML_MASK ? mc : (uint32_t)ML_MASK));
                         if (lx == 1u) dst[o_tok + 1u] = (uint8_t)(ll - RUN_MASK);
-                        if (ll != 0u && ll <= LANE_COPY_MAX) lane_copy32(dst + o_lit, src + r_ls, ll, U - r_ls);
                         ((U16u *)(dst + o_off))->v = (uint16_t)r_off;   /* :299-304 */
                         if (mx == 1u) dst[o_mx] = (uint8_t)(mc - ML_MASK);
                     }
-                    unsigned long long big = __ballot(mine && (ll > LANE_COPY_MAX || lx > 1u || mx > 1u));
+                    unsigned long long big;
+                    if (contig) {
+                        /* literals: lane l holds source byte ip0 + l, so every literal position of the window
+                         * stores its own byte; it belongs to the first sequence that hits at or above l */
+                        const unsigned long long hg = hits & ~below_me;
+                        const int nh = hg ? ctz64(hg) : 0;
+                        const uint32_t pk = (uint32_t)__shfl((int)(r_cq | ((r_back < 64u ? r_back : 64u) << 8)), nh);
+                        const uint32_t ol = (uint32_t)__shfl((int)o_lit, nh);
+                        const int c = (int)(pk & 0xffu), b = (int)(pk >> 8);
+                        const uint32_t n_pre = ip0 - anchor_in;     /* literals pending from before the window */
+                        if (hg != 0ull && lane >= c && lane < nh - b)
+                            dst[ol + (uint32_t)(lane - c) + (c == 0 ? n_pre : 0u)] = (uint8_t)pa.seq;
+                        if (n_pre) {
+                            const int f0 = ctz64(hits);
+                            const uint32_t l0 = readlane_u32(ll, f0);
+                            wave_copy(dst + readlane_u32(o_lit, f0), src + anchor_in, l0 < n_pre ? l0 : n_pre, lane);
+                        }
+                        big = __ballot(mine && (lx > 1u || mx > 1u));
+                    } else {
+                        if (mine && ll != 0u && ll <= LANE_COPY_MAX) lane_copy32(dst + o_lit, src + r_ls, ll, U - r_ls);
+                        big = __ballot(mine && (ll > LANE_COPY_MAX || lx > 1u || mx > 1u));
+                    }
                     while (big) {
                         const int g = ctz64(big);
                         big &= big - 1ull;
-                        const uint32_t g_ll = __builtin_amdgcn_readlane(ll, g), g_mc = __builtin_amdgcn_readlane(mc, g);
-                        const uint32_t g_tok = __builtin_amdgcn_readlane(o_tok, g);
+                        const uint32_t g_ll = readlane_u32(ll, g), g_mc = readlane_u32(mc, g);
+                        const uint32_t g_tok = readlane_u32(o_tok, g);
                         if (g_ll >= (uint32_t)RUN_MASK + 255u) emit_length_run(dst, g_tok + 1u, g_ll - RUN_MASK, lane);
-                        if (g_ll > LANE_COPY_MAX)
-                            wave_copy(dst + __builtin_amdgcn_readlane(o_lit, g), src + __builtin_amdgcn_readlane(r_ls, g), g_ll, lane);
-                        if (g_mc >= (uint32_t)ML_MASK + 255u) emit_length_run(dst, __builtin_amdgcn_readlane(o_mx, g), g_mc - ML_MASK, lane);
+                        if (!contig && g_ll > LANE_COPY_MAX)
+                            wave_copy(dst + readlane_u32(o_lit, g), src + readlane_u32(r_ls, g), g_ll, lane);
+                        if (g_mc >= (uint32_t)ML_MASK + 255u) emit_length_run(dst, readlane_u32(o_mx, g), g_mc - ML_MASK, lane);
                     }
                 }
                 op += total;
             }
             if (PROF) { const unsigned long long t3 = prof_now<PROF>(); c_probe += t1 - t0; c_ext += t2 - t1; c_emit += t3 - t2; }
 
-            /* ---------------- where the next round starts ---------------- */
             if (outcome == 2) break;
-            if (outcome == 1) {
-                ip = anchor;
-                test = true;
-                jbase = 0;
-            } else if (contig) {
-                const uint32_t qs = q + (q_test ? 1u : 0u);         /* lane where the running search started */
-                sbase = ip0 + qs;
-                jbase = 64u - qs;
-                test = false;
-                ip = sbase;
-            } else {
-                jbase += 64u - shift;
-                test = false;
-            }
         }
     }
 
