@@ -10,25 +10,18 @@
  *   hash / table helpers               Engine/LL.tools.cs:46-148, x64/LL64.tools.cs:86-153
  * and produces byte-identical blocks.  The reference is a serial greedy state machine whose hash
  * table is mutated by every visited position; bit-exactness therefore forbids "hash everything in
- * parallel".  What the wavefront parallelises instead:
- *
- *   search   the next 64 probe positions of the skip schedule (LL64.fast.cs:156-234) are hashed,
- *            looked up (16 KiB table in LDS) and compared at once, one per lane.  The serial
- *            semantics "a probe sees the puts of every earlier probe" are restored inside the
- *            wave: a lane whose hash equals that of an earlier lane takes that lane's position as
- *            its candidate (found with shuffles over the window that can still matter), and only
- *            the puts of lanes up to the first hit are committed, in lane order.
- *   extend   backward extension and LZ4_count compare 64 / 256 bytes per step with a ballot.
- *   emit     literal runs move 1 KiB per wave instruction; 255-runs are wave fills.
+ * parallel".  What the wavefront does instead: one ROUND handles the 64 consecutive probe
+ * positions from the cursor, one per lane, and resolves every sequence that starts among them
+ * (about 8 per round on text), see encode_fast_block.  The serial semantics "a probe sees the
+ * puts of every earlier visited position, and positions inside a match are never put" are kept
+ * exactly: lanes with equal hashes form groups, a lane's candidate is the highest VISITED lane of
+ * its group below it, else the table entry as it stood at the start of the round.
  *
  * Table slots hold positions relative to the block start (currentOffset == 0, empty slot == 0).
  */
 #pragma once
 #include "k4lz4_common.hpp"
 
-#ifdef K4_EMU_COUNTERS
-extern "C" unsigned long long k4emu_cnt[8];
-#endif
 namespace k4 {
 
 template <bool BYU16> struct FastTable;
@@ -139,23 +132,31 @@ __device__ __forceinline__ uint32_t extension_info(uint32_t a_pre, uint64_t a_ne
  *
  * One round looks at 64 probe positions -- normally the 64 consecutive positions from the cursor --
  * and resolves EVERY sequence that starts inside that window, not just the first:
- *   load     16 source bytes around each position (4 before, the 4 hashed ones, 8 after); hash; look
+ *   load     16 source bytes around each position (4 before, the 4 hashed ones, 8 after; issued at
+ *            the end of the previous round, before its table commit and output stores); hash; look
  *            the hashes up in the table as it stood at the start of the round; load the 16 bytes
  *            around the 64 candidates; per lane: would this position hit, how far does the match
  *            extend (up to 4 back / 12 forward from registers).
  *   groups   lanes whose hashes collide inside the window are found through one byte-wide LDS slot
- *            per hash; each such lane keeps the bit mask of its group.  The serial semantics "a
- *            probe sees the puts of every earlier visited position" then become: the candidate of a
- *            lane is the highest *visited* lane of its group below it, else the table entry.
- *   resolve  wave-uniform walk over the window: first hit at or after the cursor (a scalar bit scan
- *            when no colliding lane is ahead), extension from the hit lane's precomputed info,
- *            cursor to the match end, visited set += probes up to the hit and the `ip-2` position
- *            (LL64.fast.cs:394); sequence k of the round is parked in lane k.  The test of the
- *            position right after a match (LL64.fast.cs:393-463) is simply the probe of that lane.
+ *            per hash; each such lane keeps the bit mask of its group.  A lane's candidate is the
+ *            highest visited-or-future lane of its group below it (its bytes come from that lane's
+ *            registers), else the table entry.
+ *   hops     wave-uniform chain over the window, one v_readlane per sequence: first stop at or
+ *            after the cursor -> the lane after that match (precomputed per lane) -> next cursor.
+ *            A hop leaves the tight loop only when the match runs past the known bytes (wave-wide
+ *            count in memory), ends the window or the block, or covers a lane that may be a later
+ *            lane's candidate (then the lanes inside matches are derived from the hits so far and
+ *            the affected lanes fall back to their next candidate -- for the usual pair groups a
+ *            select between two precomputed alternatives).  The test of the position right after
+ *            a match (LL64.fast.cs:393-463) is simply the probe of that lane.
+ *   derive   from the hit lanes alone: lanes inside matches (never put, except the `ip-2` position
+ *            of LL64.fast.cs:394), the cursor each hit was found from (-> literal run, backward
+ *            extension LL64.fast.cs:237-242), the sequences' numbers -- all lane-parallel.
  *   commit   visited lanes write the table, one writer per hash (the highest visited of a group).
- *   emit     lane k writes sequence k: output positions from a DPP prefix sum, token / offset /
- *            length bytes and up to 32 literals per lane; longer literal runs and multi-byte
- *            length fields by the whole wave.
+ *   emit     output positions from a DPP prefix sum over the hit lanes; each hit lane writes its
+ *            token / offset / length bytes, every literal position of the window stores its own
+ *            byte (the lane holds it already); literals pending from before the window, and
+ *            multi-byte length fields, are moved by the whole wave.
  * After 64 misses the schedule's step grows (LL64.fast.cs:156-172); those rounds probe the strided
  * positions and stop at their first sequence.
  */
@@ -278,7 +279,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             uint32_t cpos = cand, cinfo = info;
             bool chit = hit_tab;
             unsigned long long skipped = 0;    /* lanes inside matches: never put into the table */
-            unsigned long long hm, long_m, cand_m;   /* hits; hits whose match runs past the known bytes; lanes that are candidates */
+            unsigned long long hmx, cand_m;    /* lanes that stop the chain (hits, invalid lanes); lanes that may be a later lane's candidate */
             uint32_t epos;                     /* per lane: where its match would end */
             auto candidates = [&]() {          /* general form: highest visited-or-future lane of the group below this one */
                 const unsigned long long eff = G & below_me & ~skipped;
@@ -298,12 +299,33 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                     cinfo = info;
                 }
             };
+            uint32_t xcode = 0xffffffffu;      /* per lane: match length found by the slow forward count */
+            uint32_t hopv;                     /* per lane, as a hit: bits 0-6 lane after its match (>= 64: outside the window),
+                                                * 0x100 match runs past the known bytes, 0x200 block ends after it (:391),
+                                                * 0x400 its match covers a lane that may be a later lane's candidate */
             auto publish = [&]() {
-                hm = __ballot(chit);
-                long_m = __ballot((cinfo & 0x100u) != 0u);
-                epos = pos + MINMATCH + (cinfo & 15u);
+                hmx = __ballot(chit) | inv_m;
+                const bool counted = xcode != 0xffffffffu;          /* this lane's long match has been measured already */
+                const uint32_t c8 = counted ? xcode : (cinfo & 15u);
+                epos = pos + MINMATCH + c8;
                 /* a visited-or-future lane with a later lane in its group may be that lane's candidate */
                 cand_m = __ballot(((skipped >> lane) & 1ull) == 0ull && (G & ~(below_me | me)) != 0ull);
+                const uint32_t qn_full = (uint32_t)lane + MINMATCH + c8;
+                const uint32_t qn = contig && qn_full < 127u ? qn_full : 127u;
+                /* lanes lane+1 .. qn-1 except qn-2 are never visited if this lane is a hit */
+                const unsigned long long inside = ~(below_me | me) & ((1ull << (qn & 63u)) - 1ull) & ~(1ull << ((qn - 2u) & 63u));
+                const bool trig = qn < 64u && (inside & cand_m) != 0ull;
+                hopv = (valid ? 0u : 0x800u) | qn | (counted ? 0u : (cinfo & 0x100u)) | (epos >= mflimit_plus_one ? 0x200u : 0u) | (trig ? 0x400u : 0u);
+            };
+            /* from the hits so far: the lanes inside their matches (never visited) and the lanes right after them */
+            unsigned long long cursors = 1;
+            auto derive = [&](unsigned long long hits_now) {
+                const unsigned long long hb = hits_now & below_me;
+                const int ph = hb ? 63 - (int)__clzll((long long)hb) : 0;
+                const uint32_t qp = (uint32_t)__shfl((int)hopv, ph) & 127u;       /* lane after the match of the hit below */
+                const bool in = hb != 0ull && (uint32_t)lane < qp;
+                skipped = __ballot(in && (uint32_t)lane + 2u != qp);
+                cursors = 1ull | __ballot(hb != 0ull && (uint32_t)lane == qp);
             };
             /* the common group is a pair: the later lane's candidate is the earlier lane while that one counts
              * as visited, else the table entry -- both known up front, so losing a candidate is a select */
@@ -320,49 +342,51 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             const unsigned long long ta = prof_now<PROF>();
             if (PROF) c_s1 += ta - t1;
             unsigned long long t_rec = 0;
-            unsigned long long I = 0;          /* lanes whose position has been put into the table this round */
             unsigned long long hits = 0;       /* lanes where a sequence's match starts (before backward extension) */
-            unsigned long long cursors = 1;    /* lanes where a search started: lane 0 and the lanes right after matches */
             uint32_t q = 0;                    /* lane of the cursor */
-            bool q_test = shift != 0u;         /* the cursor is a position right after a match */
-            uint32_t xcode = 0xffffffffu;      /* per lane: match length found by the slow forward count */
             int outcome;                       /* 0 window exhausted, 1 next round starts after a match, 2 block ends */
-            bool cont;
-            /* one hop per sequence; written with selects so that the loop keeps a single exit */
-            do {
-                const unsigned long long geq = ~0ull << q;
-                const unsigned long long stop = (hm | inv_m) & geq;
-                const bool any = stop != 0ull;
-                const int f = any ? ctz64(stop) : 63;
-                const unsigned long long fbit = 1ull << f;
-                const bool is_hit = any && (inv_m & fbit) == 0ull;  /* else: window exhausted, or -> _last_literals (:172) */
-                I |= any ? (geq & ((fbit << 1) - 1ull)) : geq;
-                hits |= is_hit ? fbit : 0ull;
+            for (;;) {
+                /* plain hops: one readlane per sequence; everything else about the chain is derived afterwards.
+                 * Lanes past the last probe position (:172) stop the chain like hits and carry flag 0x800. */
+                uint32_t hv = 0;
+                int f = 0;
+                unsigned long long stop;
+                for (;;) {
+                    stop = hmx & (~0ull << q);
+                    if (!stop) break;
+                    f = ctz64(stop);
+                    hv = readlane_u32(hopv, f);
+                    hits |= 1ull << f;
+                    if (hv & 0xf40u) break;
+                    q = hv & 63u;
+                }
+                if (!stop || (hv & 0x800u)) {
+                    hits &= ~inv_m;
+                    if (hits) anchor = ip0 + q;
+                    outcome = stop ? 2 : 0;
+                    break;
+                }
+                /* hit f needs attention before the chain can go on */
                 uint32_t e_end = readlane_u32(epos, f);
-                if (is_hit && (long_m & fbit) != 0ull) {            /* :326-329 beyond the 12 known bytes */
+                if (hv & 0x100u) {                                  /* :326-329 beyond the 12 known bytes */
                     if (PROF) n_rt3++;
                     const uint32_t p = readlane_u32(pos, f), match = readlane_u32(cpos, f);
                     const uint32_t code = 8u + wave_count(src + p + MINMATCH + 8u, src + match + MINMATCH + 8u, matchlimit - (p + MINMATCH) - 8u, lane);
-                    if (lane == f) xcode = code;
                     e_end = p + MINMATCH + code;
+                    const uint32_t qf = e_end - ip0;
+                    if (lane == f) { xcode = code; hopv = (hopv & ~127u) | (contig && qf < 127u ? qf : 127u); }
                 }
-                const uint32_t qn = e_end - ip0;
-                const bool fin = e_end >= mflimit_plus_one;         /* :391 */
-                cont = is_hit && !fin && contig && qn < 64u;
-                outcome = !any ? 0 : ((!is_hit || fin) ? 2 : 1);
-                anchor = is_hit ? e_end : anchor;
-                /* lanes f+1 .. qn-1 except qn-2 are never visited: a lane whose candidate is one of them falls
-                 * back to the next visited lane of its group (or to the table); qn-2 is the put of :394 */
-                const unsigned long long qbit = cont ? 1ull << (qn & 63u) : 0ull;
-                const unsigned long long sk = cont ? ((~1ull << f) & (qbit - 1ull) & ~(qbit >> 2)) : 0ull;
-                cursors |= qbit;
-                I |= qbit >> 2;
-                skipped |= sk;
-                q = cont ? qn : q;
-                q_test = q_test || cont;
+                anchor = e_end;
+                if (e_end >= mflimit_plus_one) { outcome = 2; break; }   /* :391 */
+                if (!contig || e_end - ip0 >= 64u) { outcome = 1; break; }
+                q = e_end - ip0;
+                /* lanes f+1 .. q-1 except q-2 were never visited: a lane whose candidate is one of them falls back
+                 * to the next visited lane of its group (or to the table); q-2 is the put of :394 */
+                const unsigned long long sk = (~1ull << f) & ((1ull << q) - 1ull) & ~(1ull << (q - 2u));
                 if (sk & cand_m) {
                     const unsigned long long tr0 = prof_now<PROF>();
                     if (PROF) n_dup++;
+                    derive(hits);
                     const bool lost = j1 >= 0 && ((skipped >> (j1 & 63)) & 1ull) != 0ull;
                     if (!general && (__ballot(lost) & multi_m)) general = true;
                     if (general) {
@@ -375,7 +399,10 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                     publish();
                     if (PROF) t_rec += prof_now<PROF>() - tr0;
                 }
-            } while (cont);
+            }
+            if (hits) derive(hits);
+            const unsigned long long I = ~skipped; /* lanes whose position has been put into the table this round */
+            const bool q_test = shift != 0u || hits != 0ull;       /* the cursor is a position right after a match */
             const unsigned long long tb = prof_now<PROF>();
             if (PROF) { c_s2 += tb - ta - t_rec; c_s3 += t_rec; }
             const uint32_t k = (uint32_t)__popcll(hits);

@@ -48,8 +48,11 @@ def gen(rng, n):
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    run(rounds, seed, Oracle(), Emu())
+
+
+def run(rounds, seed, oracle, emu, verbose=True):
     rng = np.random.default_rng(seed)
-    oracle, emu = Oracle(), Emu()
     for r in range(rounds):
         blocks = []
         for _ in range(48):
@@ -80,7 +83,8 @@ def main():
                 a = d1[int(o1[i]):int(o1[i]) + want[i]]; b = d2[int(o2[i]):int(o2[i]) + want[i]]
                 assert np.array_equal(a, b), (r, i, blocks[i].size, int(np.argmax(a != b)))
             assert (d1[int(o1[i]) + caps[i]:int(o1[i]) + caps[i] + 16] == 0xCD).all(), (r, i, 'guard')
-        print("round", r, "ok", len(blocks), "blocks accel", accel, flush=True)
+        if verbose:
+            print("round", r, "ok", len(blocks), "blocks accel", accel, flush=True)
 
 if __name__ == "__main__":
     main()

@@ -3,6 +3,8 @@ host wave emulator (tests/emu), compared with the oracle.  This checks the kerne
 (speculative probe rounds, in-window duplicate resolution, token parse, accept/reject rules,
 envelope arithmetic) on the CPU; the same comparisons run against the real gfx950 build in the
 `-m gpu` tests.  Nothing here is a product path."""
+import os
+
 import numpy as np
 import pytest
 
@@ -449,3 +451,14 @@ def test_decode_with_dictionary_issue64_and_synthetic(emu, oracle):
         if n > 0:
             assert buf[d.size:d.size + n].tobytes() == ref[:n].tobytes(), i
         assert (buf[d.size + cap:] == 0xCD).all() and buf[:d.size].tobytes() == d.tobytes()
+
+
+def test_encode_random_stress(emu, oracle):
+    """scripts/emu_stress_encode.py (two rounds of it): inputs built to provoke equal hashes inside one
+    64-position window, matches ending at window edges, long literal runs, limited output, accel > 1"""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "emu_stress_encode.py")
+    spec = importlib.util.spec_from_file_location("emu_stress_encode", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run(2, 5, oracle, emu, verbose=False)
