@@ -60,6 +60,8 @@ enum k4lz4_flags {
     K4LZ4_FLAG_NO_REORDER = 4,    /* encode/pickle: dispatch blocks in index order instead of most-expensive-first */
     K4LZ4_FLAG_REORDER = 8,       /* decode/unpickle: dispatch longest inputs first (useful for ragged batches) */
     K4LZ4_FLAG_NO_SPLIT = 16,     /* encode: do not run part of the batch on the global-memory-table kernel */
+    K4LZ4_FLAG_ALLOW_COPY = 64,   /* encode: LZ4EncoderBase.Encode(allowCopy) -- a block that does not shrink is stored raw, outLen = -srcLen;
+                                     outLen = 0 where the reference throws "target buffer too small" (Encoders/LZ4EncoderBase.cs:66-88) */
     K4LZ4_FLAG_PARTIAL = 32       /* decode: LZ4Codec.PartialDecode -- stop once dstCap[i] bytes are produced (LZ4Codec.cs:123-173) */
 };
 
@@ -171,6 +173,30 @@ K4LZ4_API int k4lz4_profile_batch_device(k4lz4_ctx *ctx, int decode, const uint8
                                          const int32_t *srcLen, uint8_t *dst, const uint64_t *dstOff,
                                          const int32_t *dstCap, int32_t *outLen, int64_t n, uint64_t *counters,
                                          void *stream);
+
+/* ---- frame layer (K4os.Compression.LZ4.Streams: Frames/LZ4FrameWriter.cs, LZ4FrameReader.async.cs) ----------- */
+
+/* XXH32.DigestOf for n buffers (K4os.Hash.xxHash 1.0.8, NuGet; call sites Frames/LZ4FrameWriter.cs:100,:162-182,
+ * Internal/Stash.cs:149-150): out[i] = xxHash32(data[off[i] .. off[i]+len[i]), seed). */
+K4LZ4_API int k4lz4_xxh32_batch(k4lz4_ctx *ctx, const uint8_t *data, const uint64_t *off, const uint64_t *len,
+                                uint32_t *out, int64_t n, uint32_t seed);
+K4LZ4_API int k4lz4_xxh32_batch_device(k4lz4_ctx *ctx, const uint8_t *data, const uint64_t *off, const uint64_t *len,
+                                       uint32_t *out, int64_t n, uint32_t seed, void *stream);
+
+/* Block streams decoded in order, one stream per wavefront: ILZ4Decoder.Decode / Inject over the blocks of a frame
+ * (Frames/LZ4FrameReader.async.cs:108-136; Encoders/LZ4BlockDecoder.cs:39-71 for independent blocks,
+ * Encoders/LZ4ChainDecoder.cs -> LL64.LZ4_decompress_safe_continue for chained ones).  Stream s owns blocks
+ * firstBlk[s] .. firstBlk[s]+nBlk[s]-1; blkLen has bit 31 set for blocks stored raw (LZ4FrameWriter.cs:159-160).
+ * outLen[s] = bytes produced, -6 when a block does not decode, -9 when dstCap[s] is too small. */
+K4LZ4_API int k4lz4_decode_chain_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *blkOff, const uint32_t *blkLen,
+                                       int64_t nBlocks, const uint64_t *firstBlk, const uint32_t *nBlk,
+                                       const int32_t *blockSize, const uint8_t *chained, uint8_t *dst,
+                                       const uint64_t *dstOff, const uint64_t *dstCap, int64_t *outLen, int64_t nStreams);
+K4LZ4_API int k4lz4_decode_chain_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *blkOff,
+                                              const uint32_t *blkLen, const uint64_t *firstBlk, const uint32_t *nBlk,
+                                              const int32_t *blockSize, const uint8_t *chained, uint8_t *dst,
+                                              const uint64_t *dstOff, const uint64_t *dstCap, int64_t *outLen,
+                                              int64_t nStreams, void *stream);
 
 #ifdef __cplusplus
 }

@@ -4,7 +4,12 @@ All compute runs in hand-written HIP kernels (csrc/) reached through the C ABI o
 (include/k4lz4.h).  There is no CPU fallback."""
 from .codec import LZ4Codec, LZ4Level, pack_blocks, make_arena
 from .pickler import LZ4Pickler, InvalidDataException
+from .encoders import (LZ4BlockEncoder, LZ4BlockDecoder, EncoderAction, InvalidOperationException, TopupAndEncode,
+                       FlushAndEncode, DecodeAndDrain)
+from .frames import LZ4Frame, LZ4EncoderSettings, LZ4Descriptor, parse_frame, xxh32_many
 from ._native import NativeLibraryError, Context, load_library, default_context
 
 __all__ = ["LZ4Codec", "LZ4Level", "LZ4Pickler", "InvalidDataException", "NativeLibraryError", "Context",
-           "load_library", "default_context", "pack_blocks", "make_arena"]
+           "load_library", "default_context", "pack_blocks", "make_arena", "LZ4BlockEncoder", "LZ4BlockDecoder",
+           "EncoderAction", "InvalidOperationException", "TopupAndEncode", "FlushAndEncode", "DecodeAndDrain", "LZ4Frame",
+           "LZ4EncoderSettings", "LZ4Descriptor", "parse_frame", "xxh32_many"]

@@ -18,6 +18,7 @@ FLAG_NO_REORDER = 4
 FLAG_REORDER = 8
 FLAG_NO_SPLIT = 16
 FLAG_PARTIAL = 32
+FLAG_ALLOW_COPY = 64
 
 _u8p = C.c_void_p
 _BATCH = [C.c_void_p, _u8p, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
@@ -51,6 +52,12 @@ SYMBOLS = {
     "k4lz4_pickle_batch_device": (C.c_int, _BATCH + [C.c_int, C.c_int, C.c_void_p]),
     "k4lz4_unpickle_batch_device": (C.c_int, _BATCH + [C.c_int, C.c_void_p]),
     "k4lz4_profile_batch_device": (C.c_int, [C.c_void_p, C.c_int] + _BATCH[1:] + [C.c_void_p, C.c_void_p]),
+    "k4lz4_xxh32_batch": (C.c_int, [C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32]),
+    "k4lz4_xxh32_batch_device": (C.c_int, [C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p]),
+    "k4lz4_decode_chain_batch": (C.c_int, [C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "k4lz4_decode_chain_batch_device": (C.c_int, [C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "k4lz4_unpickle_sizes_device": (C.c_int, [C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
 }
 

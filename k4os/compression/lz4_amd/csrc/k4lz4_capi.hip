@@ -25,6 +25,8 @@
 #include "k4lz4_encode_fast.hpp"
 #include "k4lz4_pickle.hpp"
 #include "k4lz4_encode_hc.hpp"
+#include "k4lz4_frame.hpp"
+#include "k4lz4_xxh32.hpp"
 
 struct k4lz4_ctx {
     int device = -1;
@@ -156,8 +158,19 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
     if (n == 0) return K4LZ4_OK;
     const int64_t chunk_max = 1 << 24;   /* blocks per launch (grid.x * blockDim.x must stay < 2^32) */
     const bool encode_like = kind == KIND_ENCODE || kind == KIND_PICKLE;
-    if (encode_like && level >= K4LZ4_L03_HC)
-        return launch_hc(ctx, kind == KIND_PICKLE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, stream);
+    if (encode_like && level >= K4LZ4_L03_HC) {
+        const int rc = launch_hc(ctx, kind == KIND_PICKLE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, stream);
+        if (rc != K4LZ4_OK || kind != KIND_ENCODE || !(flags & K4LZ4_FLAG_ALLOW_COPY)) return rc;
+        for (int64_t first = 0; first < n; first += chunk_max) {
+            const int64_t cnt = std::min<int64_t>(chunk_max, n - first);
+            k4::BatchArgs a{};
+            a.src = src; a.srcOff = srcOff + first; a.srcLen = srcLen + first;
+            a.dst = dst; a.dstOff = dstOff + first; a.dstCap = dstCap + first; a.outLen = outLen + first; a.n = cnt;
+            hipLaunchKernelGGL(k4::k4_allow_copy_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, stream, a);
+        }
+        K4_HIP(ctx, hipGetLastError());
+        return K4LZ4_OK;
+    }
     /* cost-ordered dispatch (most expensive blocks first): encoders by default, decoders on request */
     const bool reorder = n > 1 &&
                          (encode_like ? !(flags & K4LZ4_FLAG_NO_REORDER) : (flags & K4LZ4_FLAG_REORDER) != 0);
@@ -236,6 +249,8 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
             hipLaunchKernelGGL(k4::k4_unpickle_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
             break;
         }
+        if (kind == KIND_ENCODE && (flags & K4LZ4_FLAG_ALLOW_COPY))
+            hipLaunchKernelGGL(k4::k4_allow_copy_kernel, dim3(wg4), dim3(256), 0, stream, a);
         K4_HIP(ctx, hipGetLastError());
     }
     return K4LZ4_OK;
@@ -354,7 +369,8 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
     K4_HIP(ctx, hipStreamSynchronize(st));
     for (int64_t i = 0; i < n; i++) {
         const int32_t got = outLen[i];
-        if (got > 0 && got <= h_cap[(size_t)i]) memcpy(dst + dstOff[i], ctx->h_stage + h_doff[(size_t)i], (size_t)got);
+        const int32_t stored = (got < 0 && (flags & K4LZ4_FLAG_ALLOW_COPY) && kind == KIND_ENCODE) ? -got : got;   /* raw blocks come back as -length */
+        if (stored > 0 && stored <= h_cap[(size_t)i]) memcpy(dst + dstOff[i], ctx->h_stage + h_doff[(size_t)i], (size_t)stored);
     }
     return K4LZ4_OK;
 }
@@ -613,6 +629,139 @@ int k4lz4_profile_batch_device(k4lz4_ctx *ctx, int decode, const uint8_t *src, c
                               K4LZ4_L00_FAST, 0, stream);
     ctx->prof = nullptr;
     return rc;
+}
+
+/* ---- frame layer -------------------------------------------------------------------------------- */
+int k4lz4_xxh32_batch_device(k4lz4_ctx *ctx, const uint8_t *data, const uint64_t *off, const uint64_t *len,
+                             uint32_t *out, int64_t n, uint32_t seed, void *stream)
+{
+    if (!ctx) return fail(nullptr, K4LZ4_E_ARG, "ctx is NULL");
+    if (n < 0 || (n > 0 && (!data || !off || !len || !out))) return fail(ctx, K4LZ4_E_ARG, "bad argument");
+    if (n == 0) return K4LZ4_OK;
+    K4_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t per_launch = (int64_t)1 << 24;
+    for (int64_t first = 0; first < n; first += per_launch) {
+        const int64_t cnt = std::min<int64_t>(per_launch, n - first);
+        k4::HashArgs a{data, off + first, len + first, out + first, cnt, seed};
+        hipLaunchKernelGGL(k4::k4_xxh32_kernel, dim3((unsigned)((cnt * 4 + k4::XXH_THREADS - 1) / k4::XXH_THREADS)),
+                           dim3(k4::XXH_THREADS), 0, (hipStream_t)stream, a);
+    }
+    K4_HIP(ctx, hipGetLastError());
+    return K4LZ4_OK;
+}
+
+int k4lz4_xxh32_batch(k4lz4_ctx *ctx, const uint8_t *data, const uint64_t *off, const uint64_t *len, uint32_t *out,
+                      int64_t n, uint32_t seed)
+{
+    if (!ctx) return fail(nullptr, K4LZ4_E_ARG, "ctx is NULL");
+    if (n < 0 || (n > 0 && (!data || !off || !len || !out))) return fail(ctx, K4LZ4_E_ARG, "bad argument");
+    if (n == 0) return K4LZ4_OK;
+    K4_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t lo = UINT64_MAX, hi = 0;
+    for (int64_t i = 0; i < n; i++)
+        if (len[i]) { lo = std::min(lo, off[i]); hi = std::max(hi, off[i] + len[i]); }
+    if (lo == UINT64_MAX) { lo = 0; hi = 0; }
+    std::vector<uint64_t> h_off((size_t)n);
+    for (int64_t i = 0; i < n; i++) h_off[(size_t)i] = len[i] ? off[i] - lo : 0;
+    const size_t span = (size_t)(hi - lo);
+    int rc;
+    if ((rc = grow(ctx, &ctx->d_src, &ctx->d_src_cap, span + 64, false)) != K4LZ4_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_meta, &ctx->d_meta_cap, (size_t)n * 20 + 64, false)) != K4LZ4_OK) return rc;
+    uint64_t *d_off = (uint64_t *)ctx->d_meta, *d_len = d_off + n;
+    uint32_t *d_out = (uint32_t *)(d_len + n);
+    hipStream_t st = ctx->stream;
+    if (span) K4_HIP(ctx, hipMemcpyAsync(ctx->d_src, data + lo, span, hipMemcpyHostToDevice, st));
+    K4_HIP(ctx, hipMemcpyAsync(d_off, h_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    K4_HIP(ctx, hipMemcpyAsync(d_len, len, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    rc = k4lz4_xxh32_batch_device(ctx, ctx->d_src, d_off, d_len, d_out, n, seed, st);
+    if (rc != K4LZ4_OK) return rc;
+    K4_HIP(ctx, hipMemcpyAsync(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    K4_HIP(ctx, hipStreamSynchronize(st));
+    return K4LZ4_OK;
+}
+
+int k4lz4_decode_chain_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *blkOff, const uint32_t *blkLen,
+                                    const uint64_t *firstBlk, const uint32_t *nBlk, const int32_t *blockSize,
+                                    const uint8_t *chained, uint8_t *dst, const uint64_t *dstOff, const uint64_t *dstCap,
+                                    int64_t *outLen, int64_t nStreams, void *stream)
+{
+    if (!ctx) return fail(nullptr, K4LZ4_E_ARG, "ctx is NULL");
+    if (nStreams < 0 || (nStreams > 0 && (!src || !blkOff || !blkLen || !firstBlk || !nBlk || !blockSize || !chained || !dst ||
+                                          !dstOff || !dstCap || !outLen)))
+        return fail(ctx, K4LZ4_E_ARG, "bad argument");
+    if (nStreams == 0) return K4LZ4_OK;
+    K4_HIP(ctx, hipSetDevice(ctx->device));
+    k4::ChainArgs a{src, blkOff, blkLen, firstBlk, nBlk, blockSize, chained, dst, dstOff, dstCap, (long long *)outLen, nStreams};
+    const unsigned grid = (unsigned)((nStreams + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
+    hipLaunchKernelGGL(k4::k4_decode_chain_kernel, dim3(grid), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, (hipStream_t)stream, a);
+    K4_HIP(ctx, hipGetLastError());
+    return K4LZ4_OK;
+}
+
+int k4lz4_decode_chain_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *blkOff, const uint32_t *blkLen,
+                             int64_t nBlocks, const uint64_t *firstBlk, const uint32_t *nBlk, const int32_t *blockSize,
+                             const uint8_t *chained, uint8_t *dst, const uint64_t *dstOff, const uint64_t *dstCap,
+                             int64_t *outLen, int64_t nStreams)
+{
+    if (!ctx) return fail(nullptr, K4LZ4_E_ARG, "ctx is NULL");
+    if (nStreams < 0 || nBlocks < 0 ||
+        (nStreams > 0 && (!src || !firstBlk || !nBlk || !blockSize || !chained || !dst || !dstOff || !dstCap || !outLen)) ||
+        (nBlocks > 0 && (!blkOff || !blkLen)))
+        return fail(ctx, K4LZ4_E_ARG, "bad argument");
+    if (nStreams == 0) return K4LZ4_OK;
+    K4_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t lo = UINT64_MAX, hi = 0;
+    for (int64_t i = 0; i < nBlocks; i++) {
+        const uint64_t l = blkLen[i] & 0x7fffffffu;
+        if (l) { lo = std::min(lo, blkOff[i]); hi = std::max(hi, blkOff[i] + l); }
+    }
+    if (lo == UINT64_MAX) { lo = 0; hi = 0; }
+    std::vector<uint64_t> h_boff((size_t)std::max<int64_t>(nBlocks, 1)), h_doff((size_t)nStreams);
+    for (int64_t i = 0; i < nBlocks; i++) h_boff[(size_t)i] = (blkLen[i] & 0x7fffffffu) ? blkOff[i] - lo : 0;
+    uint64_t dtotal = 0;
+    for (int64_t i = 0; i < nStreams; i++) {
+        if (firstBlk[i] + nBlk[i] > (uint64_t)nBlocks) return fail(ctx, K4LZ4_E_ARG, "stream refers to blocks outside the block table");
+        h_doff[(size_t)i] = dtotal;
+        dtotal += (dstCap[i] + 15u) & ~(uint64_t)15u;
+    }
+    const size_t span = (size_t)(hi - lo);
+    const size_t meta = (size_t)nBlocks * 12 + (size_t)nStreams * (8 + 4 + 4 + 1 + 8 + 8 + 8) + 256;
+    int rc;
+    if ((rc = grow(ctx, &ctx->d_src, &ctx->d_src_cap, span + 64, false)) != K4LZ4_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_dst, &ctx->d_dst_cap, (size_t)dtotal + 64, false)) != K4LZ4_OK) return rc;
+    if ((rc = grow(ctx, &ctx->d_meta, &ctx->d_meta_cap, meta, false)) != K4LZ4_OK) return rc;
+    if ((rc = grow(ctx, &ctx->h_stage, &ctx->h_stage_cap, (size_t)dtotal + 64, true)) != K4LZ4_OK) return rc;
+    uint8_t *m = ctx->d_meta;
+    uint64_t *d_boff = (uint64_t *)m;            m += (size_t)nBlocks * 8;
+    uint64_t *d_first = (uint64_t *)m;           m += (size_t)nStreams * 8;
+    uint64_t *d_doff = (uint64_t *)m;            m += (size_t)nStreams * 8;
+    uint64_t *d_dcap = (uint64_t *)m;            m += (size_t)nStreams * 8;
+    int64_t *d_out = (int64_t *)m;               m += (size_t)nStreams * 8;
+    uint32_t *d_blen = (uint32_t *)m;            m += (size_t)nBlocks * 4;
+    uint32_t *d_nblk = (uint32_t *)m;            m += (size_t)nStreams * 4;
+    int32_t *d_bsize = (int32_t *)m;             m += (size_t)nStreams * 4;
+    uint8_t *d_chained = m;
+    hipStream_t st = ctx->stream;
+    if (span) K4_HIP(ctx, hipMemcpyAsync(ctx->d_src, src + lo, span, hipMemcpyHostToDevice, st));
+    if (nBlocks) {
+        K4_HIP(ctx, hipMemcpyAsync(d_boff, h_boff.data(), (size_t)nBlocks * 8, hipMemcpyHostToDevice, st));
+        K4_HIP(ctx, hipMemcpyAsync(d_blen, blkLen, (size_t)nBlocks * 4, hipMemcpyHostToDevice, st));
+    }
+    K4_HIP(ctx, hipMemcpyAsync(d_first, firstBlk, (size_t)nStreams * 8, hipMemcpyHostToDevice, st));
+    K4_HIP(ctx, hipMemcpyAsync(d_doff, h_doff.data(), (size_t)nStreams * 8, hipMemcpyHostToDevice, st));
+    K4_HIP(ctx, hipMemcpyAsync(d_dcap, dstCap, (size_t)nStreams * 8, hipMemcpyHostToDevice, st));
+    K4_HIP(ctx, hipMemcpyAsync(d_nblk, nBlk, (size_t)nStreams * 4, hipMemcpyHostToDevice, st));
+    K4_HIP(ctx, hipMemcpyAsync(d_bsize, blockSize, (size_t)nStreams * 4, hipMemcpyHostToDevice, st));
+    K4_HIP(ctx, hipMemcpyAsync(d_chained, chained, (size_t)nStreams, hipMemcpyHostToDevice, st));
+    rc = k4lz4_decode_chain_batch_device(ctx, ctx->d_src, d_boff, d_blen, d_first, d_nblk, d_bsize, d_chained, ctx->d_dst, d_doff,
+                                         d_dcap, d_out, nStreams, st);
+    if (rc != K4LZ4_OK) return rc;
+    K4_HIP(ctx, hipMemcpyAsync(outLen, d_out, (size_t)nStreams * 8, hipMemcpyDeviceToHost, st));
+    if (dtotal) K4_HIP(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_dst, (size_t)dtotal, hipMemcpyDeviceToHost, st));
+    K4_HIP(ctx, hipStreamSynchronize(st));
+    for (int64_t i = 0; i < nStreams; i++)
+        if (outLen[i] > 0 && (uint64_t)outLen[i] <= dstCap[i]) memcpy(dst + dstOff[i], ctx->h_stage + h_doff[(size_t)i], (size_t)outLen[i]);
+    return K4LZ4_OK;
 }
 
 int k4lz4_unpickle_sizes_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,

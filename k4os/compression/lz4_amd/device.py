@@ -101,6 +101,28 @@ class DeviceCodec:
         self.ctx.check(rc)
         return out
 
+    def xxh32(self, data: torch.Tensor, off: torch.Tensor, length: torch.Tensor, seed: int = 0) -> torch.Tensor:
+        """XXH32 of n HBM-resident buffers (off, length: int64/uint64 tensors) -> uint32 digests as an int64 tensor's low half
+        (torch has no uint32 arithmetic; the tensor is int32 storage, view it as uint32 on the host)"""
+        n = off.numel()
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        rc = self.lib.k4lz4_xxh32_batch_device(self.ctx.handle, _dp(data), _dp(off), _dp(length), _dp(out), n, seed,
+                                               C.c_void_p(self._stream()))
+        self.ctx.check(rc)
+        return out
+
+    def decode_chain(self, src: torch.Tensor, blk_off: torch.Tensor, blk_len: torch.Tensor, first: torch.Tensor, nblk: torch.Tensor,
+                     block_size: torch.Tensor, chained: torch.Tensor, dst: torch.Tensor, dst_off: torch.Tensor,
+                     dst_cap: torch.Tensor) -> torch.Tensor:
+        """block streams decoded in order, one stream per wavefront (k4lz4_decode_chain_batch_device)"""
+        n = first.numel()
+        out = torch.empty(n, dtype=torch.int64, device=self.device)
+        rc = self.lib.k4lz4_decode_chain_batch_device(self.ctx.handle, _dp(src), _dp(blk_off), _dp(blk_len), _dp(first), _dp(nblk),
+                                                      _dp(block_size), _dp(chained), _dp(dst), _dp(dst_off), _dp(dst_cap), _dp(out), n,
+                                                      C.c_void_p(self._stream()))
+        self.ctx.check(rc)
+        return out
+
     def profile(self, decode: bool, src: DeviceBatch, dst: DeviceBatch, out_len: Optional[torch.Tensor] = None):
         """instrumented twin kernels: returns (out_len, counters[n, 16] int64 tensor)"""
         out_len = self.new_out_len(src.n) if out_len is None else out_len

@@ -5,6 +5,8 @@
 #include "k4lz4_encode_fast.hpp"
 #include "k4lz4_pickle.hpp"
 #include "k4lz4_encode_hc.hpp"
+#include "k4lz4_frame.hpp"
+#include "k4lz4_xxh32.hpp"
 #include <vector>
 
 extern "C" {
@@ -105,6 +107,37 @@ int k4emu_unpickle_sizes(const uint8_t *src, const uint64_t *srcOff, const int32
     k4::BatchArgs a{src, srcOff, srcLen, nullptr, nullptr, nullptr, outLen, n, 0, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n <= 0) return 0;
     k4emu::launch_fn(dim3((unsigned)((n + 255) / 256)), dim3(256), [=] { k4::k4_unpickle_sizes_kernel(a); }, threads);
+    return 0;
+}
+
+int k4emu_xxh32_batch(const uint8_t *data, const uint64_t *off, const uint64_t *len, uint32_t *out, long long n,
+                      uint32_t seed, int threads)
+{
+    if (n <= 0) return 0;
+    k4::HashArgs a{data, off, len, out, n, seed};
+    k4emu::launch_fn(dim3((unsigned)((n * 4 + k4::XXH_THREADS - 1) / k4::XXH_THREADS)), dim3(k4::XXH_THREADS),
+                     [=] { k4::k4_xxh32_kernel(a); }, threads);
+    return 0;
+}
+
+int k4emu_allow_copy(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                     const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int threads)
+{
+    if (n <= 0) return 0;
+    k4::BatchArgs a{};
+    a.src = src; a.srcOff = srcOff; a.srcLen = srcLen; a.dst = dst; a.dstOff = dstOff; a.dstCap = dstCap; a.outLen = outLen; a.n = n;
+    k4emu::launch_fn(dim3((unsigned)((n + 3) / 4)), dim3(256), [=] { k4::k4_allow_copy_kernel(a); }, threads);
+    return 0;
+}
+
+int k4emu_decode_chain_batch(const uint8_t *src, const uint64_t *blkOff, const uint32_t *blkLen, const uint64_t *firstBlk,
+                             const uint32_t *nBlk, const int32_t *blockSize, const uint8_t *chained, uint8_t *dst,
+                             const uint64_t *dstOff, const uint64_t *dstCap, long long *outLen, long long n, int threads)
+{
+    if (n <= 0) return 0;
+    k4::ChainArgs a{src, blkOff, blkLen, firstBlk, nBlk, blockSize, chained, dst, dstOff, dstCap, outLen, n};
+    unsigned grid = (unsigned)((n + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
+    k4emu::launch_fn(dim3(grid), dim3(64 * k4::DECODE_WAVES_PER_WG), [=] { k4::k4_decode_chain_kernel(a); }, threads);
     return 0;
 }
 }

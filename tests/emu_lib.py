@@ -52,6 +52,10 @@ class Emu:
         self.lib.k4emu_decode_batch.argtypes = b + [C.c_int, C.c_int]
         self.lib.k4emu_encode_batch.argtypes = b + [C.c_int, C.c_int, C.c_int, C.c_int]
         self.lib.k4emu_decode_dict_batch.argtypes = b + [C.c_int, _u8p, C.c_void_p, C.c_void_p, C.c_int]
+        self.lib.k4emu_xxh32_batch.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_uint32, C.c_int]
+        self.lib.k4emu_allow_copy.argtypes = b + [C.c_int]
+        self.lib.k4emu_decode_chain_batch.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u8p,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int]
         self.lib.k4emu_encode_hc_batch.argtypes = b + [C.c_int, C.c_int, C.c_int]
         self.lib.k4emu_order.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         self.lib.k4emu_pickle_batch.argtypes = b + [C.c_int, C.c_int, C.c_int]
@@ -122,5 +126,25 @@ class Emu:
         rc = self.lib.k4emu_decode_dict_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
                                               dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data, len(src_len),
                                               flags, self._p(dct), dict_off.ctypes.data, dict_len.ctypes.data, threads)
+        assert rc == 0
+        return out
+
+    def xxh32_batch(self, data, off, length, seed=0, threads=0):
+        out = np.zeros(len(off), dtype=np.uint32)
+        rc = self.lib.k4emu_xxh32_batch(self._p(data), off.ctypes.data, length.ctypes.data, out.ctypes.data, len(off), seed, threads)
+        assert rc == 0
+        return out
+
+    def allow_copy(self, src, src_off, src_len, dst, dst_off, dst_cap, out_len, threads=0):
+        rc = self.lib.k4emu_allow_copy(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst), dst_off.ctypes.data,
+                                       dst_cap.ctypes.data, out_len.ctypes.data, len(src_len), threads)
+        assert rc == 0
+        return out_len
+
+    def decode_chain_batch(self, src, blk_off, blk_len, first, nblk, block_size, chained, dst, dst_off, dst_cap, threads=0):
+        out = np.full(len(first), -12345, dtype=np.int64)
+        rc = self.lib.k4emu_decode_chain_batch(self._p(src), blk_off.ctypes.data, blk_len.ctypes.data, first.ctypes.data,
+                                               nblk.ctypes.data, block_size.ctypes.data, chained.ctypes.data, self._p(dst),
+                                               dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data, len(first), threads)
         assert rc == 0
         return out

@@ -234,3 +234,45 @@ class SystemLZ4:
         dst = np.full(max(cap, 1), 0xCD, dtype=np.uint8)
         ret = self.lib.LZ4_decompress_safe_usingDict(_ptr(src), _ptr(dst), src.size, cap, _ptr(dictionary), dictionary.size)
         return ret, dst[:cap]
+
+
+def _frame_api(lib):
+    lib.k4o_xxh32.restype = C.c_uint32
+    lib.k4o_xxh32.argtypes = [_u8p, C.c_int64, C.c_uint32]
+    lib.k4o_frame_bound.restype = C.c_int64
+    lib.k4o_frame_bound.argtypes = [C.c_int64, C.c_int]
+    lib.k4o_frame_encode.restype = C.c_int64
+    lib.k4o_frame_encode.argtypes = [_u8p, C.c_int64, _u8p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _u8p]
+    lib.k4o_frame_decode.restype = C.c_int64
+    lib.k4o_frame_decode.argtypes = [_u8p, C.c_int64, _u8p, C.c_int64, C.POINTER(C.c_int64)]
+
+
+class FrameOracle:
+    """frame layer of the oracle (oracle/k4lz4_oracle_frame.c): XXH32, frame writer for independent
+    blocks, frame reader (independent and chained blocks)"""
+
+    def __init__(self, oracle: "Oracle"):
+        self.o = oracle
+        self.lib = oracle.lib
+        _frame_api(self.lib)
+
+    def xxh32(self, data, seed: int = 0) -> int:
+        a = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+        return int(self.lib.k4o_xxh32(_ptr(a if a.size else np.zeros(1, np.uint8)), a.size, seed))
+
+    def frame_encode(self, data: np.ndarray, block_size=65536, level=0, block_checksum=False, content_checksum=False) -> bytes:
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        cap = int(self.lib.k4o_frame_bound(data.size, block_size))
+        dst = np.zeros(cap, np.uint8)
+        scratch = np.zeros(self.o.compress_bound(block_size), np.uint8)
+        n = self.lib.k4o_frame_encode(_ptr(data if data.size else np.zeros(1, np.uint8)), data.size, _ptr(dst), cap, block_size, level,
+                                      int(block_checksum), int(content_checksum), _ptr(scratch))
+        assert n > 0, n
+        return dst[:n].tobytes()
+
+    def frame_decode(self, frame, cap: int):
+        f = np.frombuffer(bytes(frame), np.uint8)
+        dst = np.full(max(cap, 1), 0xCD, np.uint8)
+        used = C.c_int64(0)
+        n = self.lib.k4o_frame_decode(_ptr(f), f.size, _ptr(dst), cap, C.byref(used))
+        return int(n), dst[:max(n, 0)].tobytes(), int(used.value)
