@@ -159,6 +159,47 @@ __device__ __forceinline__ uint64_t load_tail(const uint8_t *p, uint32_t avail)
     return v;
 }
 
+/* the load half / store half of lane_copy32, for copies whose loads are issued well before the stores
+ * and whose result goes to two places (global memory and an LDS stage) */
+__device__ __forceinline__ void lane_load32(uint64_t (&v)[4], const uint8_t *s, uint32_t len, uint32_t readable)
+{
+#pragma unroll
+    for (uint32_t c = 0; c < 4u; c++) {
+        v[c] = 0;
+        if (8u * c < len) v[c] = (8u * c + 8u <= readable) ? ld64u(s + 8u * c) : load_tail(s + 8u * c, readable - 8u * c);
+    }
+}
+__device__ __forceinline__ void lane_store32(uint8_t *d, const uint64_t (&v)[4], uint32_t len)
+{
+#pragma unroll
+    for (uint32_t c = 0; c < 4u; c++) {
+        if (8u * c >= len) break;
+        uint32_t rem = len - 8u * c;
+        uint8_t *q = d + 8u * c;
+        uint64_t x = v[c];
+        if (rem >= 8u) {
+            ((U64u *)q)->v = x;
+        } else {
+            if (rem & 4u) { ((U32u *)q)->v = (uint32_t)x; x >>= 32; q += 4; }
+            if (rem & 2u) { ((U16u *)q)->v = (uint16_t)x; x >>= 16; q += 2; }
+            if (rem & 1u) { *q = (uint8_t)x; }
+        }
+    }
+}
+
+/* Orders this wave's LDS accesses only (LDS executes a wave's accesses in order; this pins the
+ * compiler) -- unlike wave_sync() it never waits for global stores to be acknowledged. */
+__device__ __forceinline__ void lds_sync()
+{
+#ifndef K4_HOST_EMU
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+#else
+    wave_sync();
+#endif
+}
+
 /* Per-lane copy of len <= 32 bytes, regions must not overlap.  All (up to four) 8-byte loads are
  * issued before the first store, so a lane pays one memory round trip; the stores write exactly
  * len bytes.  `readable` = bytes that may be read starting at s (>= len). */

@@ -40,7 +40,8 @@
 
 namespace k4 {
 
-constexpr int DECODE_LDS_DWORDS = RING_DWORDS + 5 * 64;   /* ring + 5 descriptor arrays */
+constexpr int DECODE_STAGE_BYTES = 2048;          /* a batch's output, kept in LDS while its matches resolve */
+constexpr int DECODE_LDS_DWORDS = RING_DWORDS + 5 * 64 + (DECODE_STAGE_BYTES + 64) / 4;   /* ring + 5 descriptor arrays + stage */
 constexpr int MAX_SEQ_PER_ROUND = 22;            /* 64 hypotheses, >= 3 stream bytes per sequence */
 
 /* Match copy inside the output block: out[op + i] = out[op - offset + i] with the byte-serial
@@ -127,6 +128,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     for (;;) {
         /* ======================= PARSE ======================= */
         const unsigned long long t0 = prof_now<PROF>();
+        const int64_t op_batch = op;
         int nseq = 0;
         int err = 0;
         bool done = false;
@@ -343,6 +345,72 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
         const uint32_t v_mlen = mine ? d_mlen[lane] : 0u;
         const unsigned long long t1 = prof_now<PROF>();
 
+        const uint32_t o0 = (uint32_t)op_batch, T = (uint32_t)(op - op_batch);
+        const bool has_m = mine && v_mlen != 0u;
+        const unsigned long long complex_m = __ballot((mine && v_llen > LANE_COPY_MAX) ||
+                                                      (has_m && (v_mlen > LANE_COPY_MAX || v_moff < v_mlen || v_moff > v_out + v_llen)));
+        unsigned long long t2 = t1;
+        if (T <= (uint32_t)DECODE_STAGE_BYTES && complex_m == 0ull) {
+            /* ======================= STAGED: the batch's output lives in LDS while it is assembled ==========
+             * All global loads of the batch go out first -- literals from the compressed stream, and the
+             * match sources that lie before the batch's output (they are final).  Matches that read this
+             * batch's own output take it from the LDS stage, so the dependency rounds never wait for global
+             * memory; the finished batch is then written out in one coalesced pass. */
+            uint8_t *stg = (uint8_t *)(d_mlen + 64);
+            const uint32_t mdst = v_out + v_llen, mend = mdst + v_mlen, msrc = mdst - v_moff;
+            const uint32_t before = has_m && msrc < o0 ? (o0 - msrc < v_mlen ? o0 - msrc : v_mlen) : 0u;   /* source bytes before the batch */
+            uint64_t L[4], M[4];
+            lane_load32(L, in + v_lpos, mine ? v_llen : 0u, (uint32_t)src_size - v_lpos);
+            lane_load32(M, out + msrc, before, (uint32_t)out_size - msrc);
+            /* dependencies among the matches of the batch, as below */
+            const uint32_t send = msrc + v_mlen < mdst ? msrc + v_mlen : mdst;
+            lds_sync();
+            d_out[lane] = mine ? mdst : 0xffffffffu;
+            d_llen[lane] = mine ? mend : 0xffffffffu;
+            lds_sync();
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (uint32_t step = 32; step != 0; step >>= 1) {
+                if (d_llen[lo + step - 1u] <= msrc) lo += step;
+                if (d_out[hi + step - 1u] < send) hi += step;
+            }
+            const uint32_t hi_c = hi < (uint32_t)lane ? hi : (uint32_t)lane;
+            unsigned long long deps = 0;
+            const bool later = has_m && before < v_mlen;            /* some source bytes are this batch's output */
+            if (later && lo < hi_c) deps = ((hi_c >= 64u ? 0ull : (1ull << hi_c)) - 1ull) & ~((1ull << lo) - 1ull);
+            if (mine && v_llen != 0u) lane_store32(stg + (v_out - o0), L, v_llen);
+            if (before) lane_store32(stg + (mdst - o0), M, before);
+            if (PROF) t2 = prof_now<PROF>();
+            /* the part of every match that comes out of the stage: stage[src_s ..) -> stage[dst_s ..), `n` bytes */
+            const uint32_t n = later ? v_mlen - before : 0u;
+            const uint32_t dst_s = mdst + before - o0, src_s = msrc + before - o0;
+            unsigned long long pend = __ballot(later);
+            while (pend) {
+                if (PROF) n_round++;
+                const bool ready = ((pend >> lane) & 1ull) != 0 && (deps & pend) == 0;
+                const unsigned long long rmask = __ballot(ready);
+                lds_sync();
+                if (ready) {
+                    uint64_t R[4];
+#pragma unroll
+                    for (uint32_t c = 0; c < 4u; c++) R[c] = 8u * c < n ? ld64u(stg + src_s + 8u * c) : 0ull;
+                    lane_store32(stg + dst_s, R, n);
+                }
+                pend &= ~rmask;
+            }
+            lds_sync();
+            /* the finished batch leaves the stage in one pass, 16 bytes per lane */
+            for (uint32_t k = 16u * (uint32_t)lane; k < T; k += 1024u) {
+                if (k + 16u <= T) {
+                    const uint4 v = *(const uint4 *)(stg + k);
+                    U128u o;
+                    o.v[0] = v.x; o.v[1] = v.y; o.v[2] = v.z; o.v[3] = v.w;
+                    st128u(out + o0 + k, o);
+                } else {
+                    for (uint32_t t = k; t < T; t++) out[o0 + t] = stg[t];
+                }
+            }
+        } else {
         /* ======================= LITERALS ======================= */
         {
             if (mine && v_llen != 0u && v_llen <= LANE_COPY_MAX)
@@ -355,7 +423,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                           __builtin_amdgcn_readlane(v_llen, f), lane);
             }
         }
-        const unsigned long long t2 = prof_now<PROF>();
+        if (PROF) t2 = prof_now<PROF>();
 
         /* ======================= MATCHES ======================= */
         {
@@ -405,6 +473,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 pend &= ~rmask;
             }
             wave_sync();
+        }
         }
         if (PROF) {
             const unsigned long long t3 = prof_now<PROF>();
