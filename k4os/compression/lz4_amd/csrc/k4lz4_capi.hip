@@ -80,9 +80,8 @@ enum Kind { KIND_ENCODE, KIND_DECODE, KIND_PICKLE, KIND_UNPICKLE };
 
 int check_level(k4lz4_ctx *ctx, int level)
 {
-    if (level <= K4LZ4_L08_HC) return K4LZ4_OK;   /* < L03_HC -> fast (LZ4Codec.cs:48); L03..L08 -> hash chain */
-    return fail(ctx, K4LZ4_E_UNSUPPORTED,
-                "LZ4Level L09_HC (pattern analysis) and L10..L12 (optimal parser) are not implemented by the device path");
+    if (level <= K4LZ4_L09_HC) return K4LZ4_OK;   /* < L03_HC -> fast (LZ4Codec.cs:48); L03..L09 -> hash chain (L09 with pattern analysis) */
+    return fail(ctx, K4LZ4_E_UNSUPPORTED, "LZ4Level L10_OPT..L12_MAX (optimal parser) are not implemented by the device path");
 }
 
 int grow(k4lz4_ctx *ctx, uint8_t **p, size_t *cap, size_t need, bool pinned);

@@ -1,5 +1,5 @@
 /*
- * k4lz4_encode_hc.hpp -- batched LZ4 HC (hash-chain) block encoder for gfx950, levels L03..L08.
+ * k4lz4_encode_hc.hpp -- batched LZ4 HC (hash-chain) block encoder for gfx950, levels L03..L09.
  *
  * Replaces (for batches of independent blocks) the reference's
  *   LZ4Codec.Encode (level >= L03_HC)        src/K4os.Compression.LZ4/LZ4Codec.cs:48-51
@@ -8,8 +8,9 @@
  *   LZ4HC_init_internal / clearTables        Engine/LL.high.cs:142-166
  *   LZ4HC_compress_generic / clTable         Engine/x64/LL64.high.cs:1124-1189
  *   LZ4HC_compress_hashChain                 Engine/x64/LL64.high.cs:512-800
- *   LZ4HC_InsertAndGetWiderMatch             Engine/x64/LL64.high.cs:70-383 (noDictCtx, no chainSwap,
- *                                            no pattern analysis: nbSearches <= 128, i.e. levels 3..8)
+ *   LZ4HC_InsertAndGetWiderMatch             Engine/x64/LL64.high.cs:70-383 (noDictCtx, no chainSwap;
+ *                                            pattern analysis, :208-337, at level 9 = 256 attempts)
+ *   LZ4HC_countPattern / reverseCountPattern Engine/x64/LL64.high.cs:37-68, Engine/LL.high.cs:232-254
  *   LZ4HC_Insert / LZ4HC_countBack           Engine/LL.high.cs:102-122,:216-230
  *   LZ4HC_encodeSequence                     Engine/x64/LL64.high.cs:435-510
  * with byte-identical output.
@@ -209,7 +210,115 @@ __global__ __launch_bounds__(256) void k4_hc_cand_kernel(HcArgs a)
 
 /* ---- kernel 2: parse -------------------------------------------------------------------- */
 
+/* ---- level 9: pattern analysis (LL64.high.cs:208-337) ------------------------------------------
+ * A candidate whose chain step is 1 sits inside a run of a repeating 1/2/4-byte pattern.  The reference
+ * then measures the run around the candidate and jumps along it instead of walking it position by
+ * position.  The walk becomes data dependent, so from the first such candidate on the search goes one
+ * candidate at a time (wave-wide counts), exactly in the reference's order. */
+
+/* bytes at src[from .. limit) that continue the 4-periodic `pattern` (phase 0 at `from`): LL64.high.cs:37-68 */
+__device__ __forceinline__ uint32_t hc_count_pattern(const uint8_t *src, uint32_t from, uint32_t limit, uint32_t pattern, int lane)
+{
+    uint32_t done = 0;
+    for (;;) {
+        const uint32_t i = done + (uint32_t)lane;
+        const bool eq = from + i < limit && src[from + i] == (uint8_t)(pattern >> (8u * (i & 3u)));
+        const unsigned long long ne = ~__ballot(eq);
+        const int run = ne ? ctz64(ne) : 64;
+        done += (uint32_t)run;
+        if (run < 64) return done;
+    }
+}
+
+/* bytes before src[at] (down to position 0) that continue the pattern backwards: LL.high.cs:232-254 */
+__device__ __forceinline__ uint32_t hc_reverse_count_pattern(const uint8_t *src, uint32_t at, uint32_t pattern, int lane)
+{
+    uint32_t done = 0;
+    for (;;) {
+        const uint32_t i = done + (uint32_t)lane;
+        const bool eq = i < at && src[at - 1u - i] == (uint8_t)(pattern >> (8u * (3u - (i & 3u))));
+        const unsigned long long ne = ~__ballot(eq);
+        const int run = ne ? ctz64(ne) : 64;
+        done += (uint32_t)run;
+        if (run < 64) return done;
+    }
+}
+
 struct HcMatch { int len; uint32_t mpos, spos; };          /* longest, *matchpos, *startpos */
+
+/* the rest of a search, one candidate per step; entered right after candidate `mi` has been evaluated */
+__device__ __forceinline__ void hc_search_serial(const uint8_t *src, const uint32_t *prev, uint32_t ip, uint32_t ilow, uint32_t matchlimit,
+                                                 HcMatch &r, uint32_t mi, int attempts, int lane)
+{
+    const uint32_t pattern = uni(ld32u(src + ip));
+    const uint32_t lowest = ip > (uint32_t)DISTANCE_MAX ? ip - (uint32_t)DISTANCE_MAX : 0u;
+    const uint32_t look_back = ip - ilow;
+    int repeat = 0;                                          /* 0 untested, 1 not a repeating pattern, 2 confirmed */
+    uint32_t src_pattern_length = 0;
+    for (;;) {
+        /* chain step of candidate mi (LL.high.cs:114 caps it at 65535; such a step ends the walk) */
+        uint32_t pv = uni(prev[mi]);
+        uint32_t delta = pv == HC_NONE || mi - pv >= (uint32_t)DISTANCE_MAX ? 0u : mi - pv;   /* 0: the chain ends */
+        bool jumped = false;
+        if (delta == 1u) {                                   /* :208 (matchChainPos == 0) */
+            const uint32_t cidx = mi - 1u;
+            if (repeat == 0) {
+                if (((pattern & 0xFFFFu) == (pattern >> 16)) && ((pattern & 0xFFu) == (pattern >> 24))) {
+                    repeat = 2;
+                    src_pattern_length = hc_count_pattern(src, ip + MINMATCH, matchlimit, pattern, lane) + MINMATCH;
+                } else {
+                    repeat = 1;
+                }
+            }
+            if (repeat == 2 && cidx >= lowest && uni(ld32u(src + cidx)) == pattern) {
+                const uint32_t fwd = hc_count_pattern(src, cidx + MINMATCH, matchlimit, pattern, lane) + MINMATCH;
+                uint32_t back_len = hc_reverse_count_pattern(src, cidx, pattern, lane);
+                {
+                    const uint32_t a = cidx - back_len;
+                    back_len = cidx - (a > lowest ? a : lowest);
+                }
+                const uint32_t cur_seg = back_len + fwd;
+                jumped = true;
+                if (cur_seg >= src_pattern_length && fwd <= src_pattern_length) {
+                    mi = cidx + fwd - src_pattern_length;    /* the spot in the run with exactly the source's run ahead */
+                } else {
+                    mi = cidx - back_len;                    /* start of the run */
+                    if (look_back == 0u) {
+                        const uint32_t max_ml = cur_seg < src_pattern_length ? cur_seg : src_pattern_length;
+                        if ((uint32_t)r.len < max_ml) {
+                            if (ip - mi > (uint32_t)DISTANCE_MAX) return;
+                            r.len = (int)max_ml; r.mpos = mi; r.spos = ip;
+                        }
+                        pv = uni(prev[mi]);
+                        if (pv == HC_NONE || mi - pv >= (uint32_t)DISTANCE_MAX) return;
+                        mi = pv;
+                    }
+                }
+            }
+        }
+        if (!jumped) {
+            if (delta == 0u) return;
+            mi -= delta;
+        }
+        if (mi < lowest || attempts == 0) return;
+        attempts--;
+        if (uni(ld32u(src + mi)) == pattern) {               /* :120-133 */
+            const uint32_t fwd = wave_count(src + ip + MINMATCH, src + mi + MINMATCH, matchlimit - (ip + MINMATCH), lane);
+            uint32_t back = 0;
+            const uint32_t maxb = look_back < mi ? look_back : mi;
+            while (back < maxb) {
+                const uint32_t i = back + (uint32_t)lane;
+                const bool eq = i < maxb && src[ip - 1u - i] == src[mi - 1u - i];
+                const unsigned long long ne = ~__ballot(eq);
+                const int run = ne ? ctz64(ne) : 64;
+                back += (uint32_t)run;
+                if (run < 64) break;
+            }
+            const int ml = (int)(MINMATCH + fwd + back);
+            if (ml > r.len) { r.len = ml; r.mpos = mi - back; r.spos = ip - back; }
+        }
+    }
+}
 
 /*
  * LZ4HC_InsertAndGetWiderMatch (LL64.high.cs:70-383) at position ip with low limit ilow, best
@@ -218,7 +327,7 @@ struct HcMatch { int len; uint32_t mpos, spos; };          /* longest, *matchpos
  */
 __device__ __forceinline__ HcMatch hc_search(const uint8_t *src, const uint32_t *cand, uint32_t ip, uint32_t ilow,
                                              uint32_t matchlimit, int longest, uint32_t mpos, uint32_t spos,
-                                             int max_attempts, int lane)
+                                             int max_attempts, int lane, const uint32_t *prev = nullptr, bool pa = false)
 {
     HcMatch r;
     r.len = longest; r.mpos = mpos; r.spos = spos;
@@ -240,8 +349,20 @@ __device__ __forceinline__ HcMatch hc_search(const uint8_t *src, const uint32_t 
         const bool ok0 = (okm & 1ull) != 0, ok1 = ok0 && ((okm >> 16) & 1ull) != 0, ok2 = ok1 && ((okm >> 32) & 1ull) != 0,
                    ok3 = ok2 && ((okm >> 48) & 1ull) != 0;
         ok = grp == 0 ? ok0 : grp == 1 ? ok1 : grp == 2 ? ok2 : ok3;
-        const int nvalid = (ok0 ? 1 : 0) + (ok1 ? 1 : 0) + (ok2 ? 1 : 0) + (ok3 ? 1 : 0);
+        int nvalid = (ok0 ? 1 : 0) + (ok1 ? 1 : 0) + (ok2 ? 1 : 0) + (ok3 ? 1 : 0);
         if (nvalid == 0) break;
+        /* level 9: the first candidate whose chain step is 1 ends the four-at-a-time walk */
+        int pa_at = -1;
+        if (pa) {
+            uint32_t nx = grp == 0 ? rec.y : grp == 1 ? rec.z : grp == 2 ? rec.w : HC_NONE;
+            if (grp == 3 && ok) nx = prev[c];
+            const unsigned long long pm = __ballot(ok && sub == 0 && nx != HC_NONE && c - nx == 1u);
+            if (pm) {
+                pa_at = ctz64(pm) >> 4;
+                if (nvalid > pa_at + 1) nvalid = pa_at + 1;
+                ok = ok && grp <= pa_at;
+            }
+        }
         if (!ok) c = 0;
         const bool seq_ok = ok && ld32u(src + c) == pattern;                      /* :120 */
         /* forward: bytes ip+4.. vs c+4.., 64 per step and group */
@@ -304,6 +425,10 @@ __device__ __forceinline__ HcMatch hc_search(const uint8_t *src, const uint32_t 
         if (nvalid > 2 && ml2 > r.len) { r.len = ml2; r.mpos = c2 - b2; r.spos = ip - b2; }
         if (nvalid > 3 && ml3 > r.len) { r.len = ml3; r.mpos = c3 - b3; r.spos = ip - b3; }
         attempts -= nvalid;
+        if (pa_at >= 0) {
+            hc_search_serial(src, prev, ip, ilow, matchlimit, r, pa_at == 0 ? c0 : pa_at == 1 ? c1 : pa_at == 2 ? c2 : c3, attempts, lane);
+            break;
+        }
         if (nvalid < 4) break;
         rec_at = c3;                                        /* the chain continues behind the last candidate */
         first_record = false;
@@ -437,11 +562,13 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
 {
 #define K4_HC_SEARCH(P, LOW, LONGEST, MPOS, SPOS) \
     (L3 ? hc_search_l3(src, cand, hc_get_rec(win, cand, flen, blen, (P)), (P), (LOW), matchlimit, (LONGEST), (MPOS), (SPOS), lane) \
-        : hc_search(src, cand, (P), (LOW), matchlimit, (LONGEST), (MPOS), (SPOS), max_attempts, lane))
+        : hc_search(src, cand, (P), (LOW), matchlimit, (LONGEST), (MPOS), (SPOS), max_attempts, lane, prev, pattern_analysis))
     if ((uint32_t)src_len > (uint32_t)MAX_INPUT_SIZE) return 0;      /* :1153 */
     const bool limited = dst_cap < compress_bound(src_len);         /* :1348 */
     const int64_t oend = dst_cap;
     const int max_attempts = hc_nb_searches(level);
+    const bool pattern_analysis = max_attempts > 128;               /* LZ4HC_compress_hashChain: patternAnalysis = (maxNbAttempts > 128), level 9 */
+    const uint32_t *prev = cand - (((uint32_t)(src_len > 0 ? src_len : 0) + 3u) & ~3u);
     const uint32_t U = (uint32_t)src_len;
     uint32_t ip = 0, anchor = 0;
     int64_t op = 0;
@@ -476,7 +603,7 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
                 const HcRec rec = hc_get_rec(win, cand, flen, blen, ip);
                 m = hc_search_l3(src, cand, rec, ip, ip, matchlimit, MINMATCH - 1, 0u, ip, lane);
             } else {
-                m = hc_search(src, cand, ip, ip, matchlimit, MINMATCH - 1, 0u, ip, max_attempts, lane);
+                m = hc_search(src, cand, ip, ip, matchlimit, MINMATCH - 1, 0u, ip, max_attempts, lane, prev, pattern_analysis);
             }
             int ml = m.len;
             uint32_t ref = m.mpos;

@@ -293,10 +293,19 @@ def test_dispatch_order_is_a_permutation_by_cost(emu):
     assert (np.diff(slen[order_l].astype(np.int64) // 1) <= 0).all() or (np.diff(cost_l[order_l].astype(np.int64)) <= 0).all()
 
 
-@pytest.mark.parametrize("level", [3, 4, 6, 8])
+@pytest.mark.parametrize("level", [3, 4, 6, 8, 9])
 def test_encode_hc_matches_oracle(emu, oracle, level):
-    """HC chain + parse kernels (levels 3..8) against the oracle's LL64.high.cs restatement"""
+    """HC chain + parse kernels (levels 3..9; 9 adds pattern analysis) against the oracle's LL64.high.cs restatement"""
     blocks = [np.frombuffer(corpus.QUICK_FOX, np.uint8), np.zeros(0, np.uint8)]
+    if level == 9:      # runs of 1/2/4-byte patterns of many lengths, next to each other and far apart
+        rng = np.random.default_rng(9)
+        for unit in (b"a", b"ab", b"abcd", b"aaab", b"abc"):
+            parts = []
+            for _ in range(60):
+                parts.append(np.frombuffer(unit * int(rng.integers(1, 400)), np.uint8))
+                parts.append(rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8))
+            blocks.append(np.concatenate(parts))
+        blocks.append(np.concatenate([np.zeros(70000, np.uint8), np.frombuffer(b"xyz", np.uint8), np.zeros(70000, np.uint8)]))
     blocks += [corpus.lorem(n) for n in (1, 12, 13, 14, 1000, 65536)]
     blocks += [corpus.repeated(0xAA, n) for n in (13, 33, 1000, 70000)]
     blocks += [corpus.random_bytes(5000, 5), np.tile(np.frombuffer(b"abcdabcdabcdabcd" * 4 + b"xyz", np.uint8), 300)]

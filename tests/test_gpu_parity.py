@@ -276,7 +276,7 @@ def test_full_size_config2_properties(oracle):
 
 
 # ---- HC levels (BASELINE.json configs[4]) -----------------------------------
-@pytest.mark.parametrize("level", [LZ4Level.L03_HC, LZ4Level.L04_HC, LZ4Level.L06_HC, LZ4Level.L08_HC])
+@pytest.mark.parametrize("level", [LZ4Level.L03_HC, LZ4Level.L04_HC, LZ4Level.L06_HC, LZ4Level.L08_HC, LZ4Level.L09_HC])
 def test_hc_single_block_roundtrip(oracle, level):
     for data in (corpus.lorem(0x172a5), corpus.class_bytes("webster", 65536, 3), corpus.repeated(7, 1000)):
         target = np.full(LZ4Codec.MaximumOutputSize(data.size), 0xCD, np.uint8)
@@ -328,9 +328,30 @@ def test_hc_pickle_levels(oracle):
     assert [LZ4Pickler.Unpickle(p) for p in ps] == [m.tobytes() for m in msgs]
 
 
+def test_hc_level9_pattern_analysis_batch(oracle):
+    """L09_HC = 256 attempts + pattern analysis (LL64.high.cs:208-337): runs of 1/2/4-byte patterns, and the
+    12 classes, byte-compared with the oracle (itself byte-equal to liblz4's level 9)"""
+    rng = np.random.default_rng(9)
+    blocks = []
+    for unit in (b"a", b"ab", b"abcd", b"aaab", b"abc"):
+        parts = []
+        for _ in range(60):
+            parts.append(np.frombuffer(unit * int(rng.integers(1, 400)), np.uint8))
+            parts.append(rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8))
+        blocks.append(np.concatenate(parts))
+    blocks.append(np.concatenate([np.zeros(70000, np.uint8), np.frombuffer(b"xyz", np.uint8), np.zeros(70000, np.uint8)]))
+    blocks += [corpus.class_bytes(name, 40000, 11) for name in corpus.SILESIA_NAMES]
+    enc = LZ4Codec.EncodeBatch(blocks, LZ4Level.L09_HC)
+    for i, b in enumerate(blocks):
+        r, w = oracle.compress_hc(b, 9)
+        assert enc[i] == w[:r].tobytes(), i
+    dec = LZ4Codec.DecodeBatch(enc, [b.size for b in blocks])
+    assert all(d == b.tobytes() for d, b in zip(dec, blocks))
+
+
 def test_unsupported_levels_fail_loudly():
     data = corpus.lorem(5000)
-    for level in (LZ4Level.L09_HC, LZ4Level.L10_OPT, LZ4Level.L12_MAX):
+    for level in (LZ4Level.L10_OPT, LZ4Level.L11_OPT, LZ4Level.L12_MAX):
         with pytest.raises(NotImplementedError):
             LZ4Codec.Encode(data, np.zeros(6000, np.uint8), level)
 
