@@ -645,7 +645,9 @@ __global__ __launch_bounds__(64) void k4_encode_fast_kernel(BatchArgs a)
 
 /* the same encoder with its hash table in global memory (a.gtab: 16 KiB per workgroup slot) and
  * only the output stage in LDS: twice as many blocks resident per CU, each a little slower */
-__global__ __launch_bounds__(64) void k4_encode_fast_gtab_kernel(BatchArgs a)
+/* waves_per_eu(6): at most 80 VGPRs.  Two LDS-table waves and four of these fit one SIMD's register file only
+ * below that line; one register more costs 20 % of the batch rate (measured). */
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k4_encode_fast_gtab_kernel(BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t stage[ENCODE_SCRATCH_BYTES / 4];
     const int lane = lane_id();
