@@ -210,12 +210,13 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
                 /* Only 8 blocks per CU fit with their hash table in LDS.  The most expensive blocks
                  * (front of the dispatch order) take those slots; the others are encoded at the same
                  * time on a second queue by the global-memory-table variant of the kernel. */
-                /* measured on MI355X (profiles/r02_split_sweep.txt): best when the LDS-table kernel gets about 45% of
-                 * a large batch, and no more than ~7 blocks per CU when the batch is small */
+                /* measured on MI355X (profiles/r02_split_sweep.txt): best when the LDS-table kernel gets one full
+                 * residency of the chip (8 blocks of 18 KiB per CU) or about 48 % of a larger batch; one block more
+                 * than a residency starts a second pass and costs 20 % */
                 const char *pct_env = getenv("K4LZ4_SPLIT_PCT");
-                const int64_t lds_slots = 7 * (int64_t)ctx->cu_count;
+                const int64_t lds_slots = 8 * (int64_t)ctx->cu_count;
                 const int64_t n_lds = pct_env ? std::max<int64_t>(1, cnt * atoi(pct_env) / 100)
-                                              : std::min<int64_t>(cnt, std::max<int64_t>(lds_slots, cnt * 45 / 100));
+                                              : std::min<int64_t>(cnt, std::max<int64_t>(lds_slots, cnt * 48 / 100));
                 const int64_t n_g = cnt - n_lds;
                 const int64_t gchunk = 8192;
                 if ((size_t)std::min(n_g, gchunk) * 16384 > ctx->d_gtab_cap) {

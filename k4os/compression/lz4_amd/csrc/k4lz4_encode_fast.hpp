@@ -79,6 +79,7 @@ __device__ __forceinline__ uint32_t wave_count(const uint8_t *a, const uint8_t *
 }
 
 constexpr int ENCODE_SCRATCH_BYTES = 2048;     /* same-hash detection: one byte per slot */
+constexpr int ENCODE_SCRATCH_BYTES_GTAB = 512; /* global-table variant: fewer slots (more false alarms), so that LDS never limits it */
 constexpr int ENCODE_LDS_DWORDS = 4096 + ENCODE_SCRATCH_BYTES / 4;   /* hash table + detection slots */
 
 /* length field tail: `rem` encoded as 255-run + final byte (LL64.fast.cs:262-272,:365-381,:484-495) */
@@ -179,6 +180,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
     uint32_t *const tabmem = gtab ? gtab : ldsw;
     tab.t = (decltype(tab.t))tabmem;
     uint8_t *const scr = (uint8_t *)(gtab ? ldsw : ldsw + 4096);
+    const uint32_t scr_mask = gtab ? (uint32_t)(ENCODE_SCRATCH_BYTES_GTAB - 1) : (uint32_t)(ENCODE_SCRATCH_BYTES - 1);
     const unsigned long long me = 1ull << lane, below_me = me - 1ull;
 
     for (int k = lane; k < 1024; k += 64) ((uint4 *)tabmem)[k] = make_uint4(0u, 0u, 0u, 0u);
@@ -244,12 +246,12 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             if (valid) {
                 h = FastTable<BYU16>::hash_of(pa.seq, pa.next);
                 cand = tab.get(h);
-                scr[h & (uint32_t)(ENCODE_SCRATCH_BYTES - 1)] = (uint8_t)lane;
+                scr[h & scr_mask] = (uint8_t)lane;
             }
             if (PROF) { ts = prof_now<PROF>(); }
             const Around ca = load_around(src, cand);
             wave_sync();
-            const bool flagged = valid && scr[h & (uint32_t)(ENCODE_SCRATCH_BYTES - 1)] != (uint8_t)lane;
+            const bool flagged = valid && scr[h & scr_mask] != (uint8_t)lane;
             const bool hit_tab = valid && (BYU16 || cand + (uint32_t)DISTANCE_MAX >= pos) && ca.seq == pa.seq;
             const uint32_t info = extension_info(pa.pre, pa.next, pa.pre_ok, ca.pre, ca.next, ca.pre_ok, matchlimit - (pos + MINMATCH));
             if (PROF) { ts = prof_now<PROF>(); }
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(64) void k4_encode_fast_kernel(BatchArgs a)
  * below that line; one register more costs 20 % of the batch rate (measured). */
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k4_encode_fast_gtab_kernel(BatchArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t stage[ENCODE_SCRATCH_BYTES / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[ENCODE_SCRATCH_BYTES_GTAB / 4];
     const int lane = lane_id();
     const long long b = a.order ? (long long)uni(a.order[blockIdx.x]) : (long long)blockIdx.x;
     const int src_len = a.srcLen[b];
