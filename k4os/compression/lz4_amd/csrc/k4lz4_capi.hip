@@ -240,6 +240,8 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
             break;
         case KIND_DECODE:
             if (a.prof) hipLaunchKernelGGL(k4::k4_decode_prof_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
+            else if (cnt > 24 * (int64_t)ctx->cu_count)   /* more blocks than can be resident (6 waves x 4 SIMDs per CU) */
+                hipLaunchKernelGGL(k4::k4_decode_dense_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
             else hipLaunchKernelGGL(k4::k4_decode_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
             break;
         case KIND_PICKLE:
