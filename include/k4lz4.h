@@ -198,6 +198,17 @@ K4LZ4_API int k4lz4_decode_chain_batch_device(k4lz4_ctx *ctx, const uint8_t *src
                                               const uint64_t *dstOff, const uint64_t *dstCap, int64_t *outLen,
                                               int64_t nStreams, void *stream);
 
+/* Frame writer on device-resident data: after k4lz4_encode_batch_device(..., K4LZ4_FLAG_ALLOW_COPY) and
+ * k4lz4_xxh32_batch_device, lays the frames out (Frames/LZ4FrameWriter.cs:57-108 header, LZ4FrameWriter.async.cs:15-27
+ * block records, :75-90 EndMark + content checksum).  The caller computes the positions (recOff, frameOff, tailOff) from
+ * the block split and the encoded lengths; hdr holds 16 bytes per frame of which hdrLen[f] (FLG, BD [, content size]) are
+ * used, hdrSum[f] their XXH32.  frameLen[f] receives each frame's length. */
+K4LZ4_API int k4lz4_frame_assemble_device(k4lz4_ctx *ctx, const uint8_t *arena, const uint64_t *slotOff, const int32_t *outLen,
+                                          const uint32_t *blkSum, const uint64_t *recOff, int64_t nBlocks, const uint8_t *hdr,
+                                          const uint32_t *hdrLen, const uint32_t *hdrSum, const uint64_t *frameOff,
+                                          const uint64_t *tailOff, const uint32_t *contentSum, uint8_t *frames,
+                                          uint64_t *frameLen, int64_t nFrames, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

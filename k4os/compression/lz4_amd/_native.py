@@ -58,6 +58,8 @@ SYMBOLS = {
                                            C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "k4lz4_decode_chain_batch_device": (C.c_int, [C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "k4lz4_frame_assemble_device": (C.c_int, [C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _u8p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_int64, C.c_void_p]),
     "k4lz4_unpickle_sizes_device": (C.c_int, [C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
 }
 

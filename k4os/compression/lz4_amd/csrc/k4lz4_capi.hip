@@ -766,6 +766,29 @@ int k4lz4_decode_chain_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t 
     return K4LZ4_OK;
 }
 
+int k4lz4_frame_assemble_device(k4lz4_ctx *ctx, const uint8_t *arena, const uint64_t *slotOff, const int32_t *outLen,
+                                const uint32_t *blkSum, const uint64_t *recOff, int64_t nBlocks, const uint8_t *hdr,
+                                const uint32_t *hdrLen, const uint32_t *hdrSum, const uint64_t *frameOff,
+                                const uint64_t *tailOff, const uint32_t *contentSum, uint8_t *frames, uint64_t *frameLen,
+                                int64_t nFrames, void *stream)
+{
+    if (!ctx) return fail(nullptr, K4LZ4_E_ARG, "ctx is NULL");
+    if (nBlocks < 0 || nFrames < 0 || (nBlocks > 0 && (!arena || !slotOff || !outLen || !recOff)) ||
+        (nFrames > 0 && (!hdr || !hdrLen || !hdrSum || !frameOff || !tailOff || !frames || !frameLen)))
+        return fail(ctx, K4LZ4_E_ARG, "bad argument");
+    K4_HIP(ctx, hipSetDevice(ctx->device));
+    if (nBlocks > 0) {
+        k4::FrameBlocksArgs a{arena, slotOff, outLen, blkSum, recOff, frames, nBlocks};
+        hipLaunchKernelGGL(k4::k4_frame_blocks_kernel, dim3((unsigned)((nBlocks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    if (nFrames > 0) {
+        k4::FrameEdgesArgs e{hdr, hdrLen, hdrSum, frameOff, tailOff, contentSum, frames, frameLen, nFrames};
+        hipLaunchKernelGGL(k4::k4_frame_edges_kernel, dim3((unsigned)((nFrames + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e);
+    }
+    K4_HIP(ctx, hipGetLastError());
+    return K4LZ4_OK;
+}
+
 int k4lz4_unpickle_sizes_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
                                 int32_t *outLen, int64_t n, void *stream)
 {

@@ -95,4 +95,60 @@ __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_decode_chain_kern
     if (lane == 0) a.outLen[s] = result < 0 ? result : (long long)op;
 }
 
+
+/* ---- frame writer on the device (Frames/LZ4FrameWriter.async.cs:15-27 per block, :75-90 tail; LZ4FrameWriter.cs:57-108
+ * header).  The host lays out WHERE things go (it knows the block split); the bytes are moved here. ----------------- */
+struct FrameBlocksArgs {
+    const uint8_t *arena;        /* encoder output slots */
+    const uint64_t *slotOff;     /* per block: its slot in the arena */
+    const int32_t *outLen;       /* per block: k4lz4_encode_batch result with FLAG_ALLOW_COPY (< 0: stored raw) */
+    const uint32_t *blkSum;      /* per block: XXH32 of the stored payload, or nullptr */
+    const uint64_t *recOff;      /* per block: where its record (length word, payload, checksum) starts in `frames` */
+    uint8_t *frames;
+    long long n;
+};
+
+/* one wavefront per block: BlockLengthCode, payload, optional block checksum */
+__global__ __launch_bounds__(256) void k4_frame_blocks_kernel(FrameBlocksArgs a)
+{
+    const int lane = lane_id();
+    const long long b = (long long)blockIdx.x * 4 + (long long)uni(threadIdx.x >> 6);
+    if (b >= a.n) return;
+    const int32_t got = a.outLen[b];
+    const uint32_t stored = (uint32_t)(got < 0 ? -got : got);
+    uint8_t *rec = a.frames + a.recOff[b];
+    if (lane == 0) ((U32u *)rec)->v = stored | (got < 0 ? 0x80000000u : 0u);       /* LZ4FrameWriter.cs:159-160 */
+    wave_copy(rec + 4, a.arena + a.slotOff[b], stored, lane);
+    if (a.blkSum && lane == 0) ((U32u *)(rec + 4 + stored))->v = a.blkSum[b];
+}
+
+struct FrameEdgesArgs {
+    const uint8_t *hdr;          /* per frame: 16 bytes, the header bytes FLG.. (hdrLen of them used) */
+    const uint32_t *hdrLen;
+    const uint32_t *hdrSum;      /* XXH32 of those bytes */
+    const uint64_t *frameOff;    /* per frame: where it starts in `frames` */
+    const uint64_t *tailOff;     /* per frame: where its EndMark goes */
+    const uint32_t *contentSum;  /* per frame, or nullptr */
+    uint8_t *frames;
+    uint64_t *frameLen;          /* per frame: total length, written here */
+    long long n;
+};
+
+/* one thread per frame: magic, header, header checksum byte; EndMark and content checksum */
+__global__ __launch_bounds__(256) void k4_frame_edges_kernel(FrameEdgesArgs a)
+{
+    const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (f >= a.n) return;
+    uint8_t *p = a.frames + a.frameOff[f];
+    ((U32u *)p)->v = 0x184D2204u;
+    const uint32_t hl = a.hdrLen[f];
+    for (uint32_t i = 0; i < hl; i++) p[4 + i] = a.hdr[16 * f + i];
+    p[4 + hl] = (uint8_t)(a.hdrSum[f] >> 8);
+    uint8_t *t = a.frames + a.tailOff[f];
+    ((U32u *)t)->v = 0u;
+    uint64_t end = a.tailOff[f] + 4u;
+    if (a.contentSum) { ((U32u *)(t + 4))->v = a.contentSum[f]; end += 4u; }
+    a.frameLen[f] = end - a.frameOff[f];
+}
+
 }  // namespace k4

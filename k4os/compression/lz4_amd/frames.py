@@ -359,3 +359,72 @@ class LZ4Frame:
                                                else "Decoded frame does not fit its declared size")
                 res[f] = dst[int(doff[k]):int(doff[k]) + int(out[k])]
         return res
+
+
+def encode_frames_device(dc, data, off: np.ndarray, length: np.ndarray, settings: Optional[LZ4EncoderSettings] = None):
+    """LZ4Frame.EncodeBatch on HBM-resident contents, nothing leaves the device: `data` is a uint8 torch tensor holding
+    the contents, content f = data[off[f] : off[f]+length[f]] (off / length: host arrays -- the block split is host index
+    work).  Returns (frames, frame_off, frame_len): frame f = frames[frame_off[f] : frame_off[f] + frame_len[f]], with
+    frame_off a host array of (worst-case spaced) positions and frame_len a device tensor.  Asynchronous on the current
+    torch stream; `dc` is a device.DeviceCodec."""
+    import ctypes as C
+    import torch
+    from ._native import FLAG_ALLOW_COPY
+    from .device import DeviceBatch, _dp
+    s = settings or LZ4EncoderSettings()
+    if s.ChainBlocks:
+        raise NotImplementedException("chained blocks are encoded serially: use ChainBlocks=False")
+    bs = int(s.BlockSize)
+    max_block_size_code(bs)
+    off = np.asarray(off, dtype=np.int64)
+    length = np.asarray(length, dtype=np.int64)
+    nf = len(off)
+    nblk = (length + bs - 1) // bs
+    first = np.concatenate(([0], np.cumsum(nblk)))[:-1]
+    nb = int(nblk.sum())
+    owner = np.repeat(np.arange(nf), nblk)
+    k_in = np.arange(nb) - first[owner]
+    boff = off[owner] + k_in * bs
+    blen = np.minimum(bs, length[owner] - k_in * bs).astype(np.int32)
+    bound = LZ4Codec.MaximumOutputSize(bs)
+    dev = dc.device
+    src = DeviceBatch(data, torch.from_numpy(boff).to(dev), torch.from_numpy(blen).to(dev))
+    arena = DeviceBatch.empty_slots(np.full(nb, bound, np.int64), dev)
+    out_len = dc.encode(src, arena, level=s.CompressionLevel, flags=FLAG_ALLOW_COPY) if nb else torch.zeros(0, dtype=torch.int32, device=dev)
+    stored = out_len.abs().to(torch.int64)
+    # header bytes (host: two to ten bytes per frame) and every XXH32 of the batch
+    hdrs = [frame_header(LZ4Descriptor(int(length[f]) if s.ContentLength is not None else None, s.ContentChecksum, False,
+                                       s.BlockChecksum, None, bs)) for f in range(nf)]
+    hl = len(hdrs[0]) if nf else 2
+    hdr_h = np.zeros((max(nf, 1), 16), np.uint8)
+    for f, h in enumerate(hdrs):
+        hdr_h[f, :hl] = np.frombuffer(h, np.uint8)
+    hdr_d = torch.from_numpy(hdr_h.reshape(-1)).to(dev)
+    hdr_len = torch.full((max(nf, 1),), hl, dtype=torch.int64, device=dev)
+    hdr_sum = dc.xxh32(hdr_d, torch.arange(max(nf, 1), dtype=torch.int64, device=dev) * 16, hdr_len)
+    blk_sum = dc.xxh32(arena.data, arena.off, stored) if (s.BlockChecksum and nb) else None
+    con_sum = dc.xxh32(data, torch.from_numpy(off).to(dev), torch.from_numpy(length).to(dev)) if (s.ContentChecksum and nf) else None
+    # layout: frames sit at worst-case spaced bases (known without a sync), records are packed inside each frame
+    head = 4 + hl + 1
+    per_block = 4 + bound + (4 if s.BlockChecksum else 0)
+    frame_cap = head + nblk * per_block + 8
+    frame_off = np.concatenate(([0], np.cumsum(frame_cap)))[:-1].astype(np.int64)
+    rec_size = stored + (8 if s.BlockChecksum else 4)
+    excl = torch.cumsum(rec_size, 0) - rec_size if nb else rec_size
+    owner_d = torch.from_numpy(owner).to(dev)
+    first_d = torch.from_numpy(np.minimum(first, max(nb - 1, 0))).to(dev)
+    base_d = torch.from_numpy(frame_off).to(dev)
+    start_of_frame = excl[first_d] if nb else torch.zeros(nf, dtype=torch.int64, device=dev)
+    rec_off = (base_d[owner_d] + head + excl - start_of_frame[owner_d]) if nb else torch.zeros(0, dtype=torch.int64, device=dev)
+    total = torch.zeros(nf, dtype=torch.int64, device=dev)
+    if nb:
+        total.index_add_(0, owner_d, rec_size)
+    tail_off = base_d + head + total
+    frames = torch.empty(int(frame_cap.sum()) + 64, dtype=torch.uint8, device=dev)
+    frame_len = torch.zeros(max(nf, 1), dtype=torch.int64, device=dev)
+    hdr_len32 = hdr_len.to(torch.int32)
+    rc = dc.lib.k4lz4_frame_assemble_device(dc.ctx.handle, _dp(arena.data), _dp(arena.off), _dp(out_len), _dp(blk_sum), _dp(rec_off), nb,
+                                            _dp(hdr_d), _dp(hdr_len32), _dp(hdr_sum), _dp(base_d), _dp(tail_off), _dp(con_sum), _dp(frames),
+                                            _dp(frame_len), nf, C.c_void_p(dc._stream()))
+    dc.ctx.check(rc)
+    return frames, frame_off, frame_len[:nf]

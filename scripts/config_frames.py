@@ -51,6 +51,17 @@ print(json.dumps({"config": "LZ4Frame host API, 64 x 4 MiB, block checksums", "e
                   "decode_GiBs": round(tot / td / 2**30, 2), "ratio": round(sum(len(f) for f in frames) / tot, 4),
                   "roundtrip_ok": all(b == c.tobytes() for b, c in zip(back, contents)), "note": "pageable host memory, PCIe and python assembly inclusive"}))
 
+# frame writer with everything in HBM
+from k4os.compression.lz4_amd.frames import encode_frames_device
+c_off = np.arange(64, dtype=np.int64) * (64 * bs); c_len = np.full(64, 64 * bs, np.int64)
+for st_d in (LZ4EncoderSettings(), LZ4EncoderSettings(BlockChecksum=True), LZ4EncoderSettings(BlockChecksum=True, ContentChecksum=True)):
+    tf = timed(lambda: encode_frames_device(dc, data, c_off, c_len, st_d), reps=5)
+    fr, fo_, fl_ = encode_frames_device(dc, data, c_off, c_len, st_d); torch.cuda.synchronize()
+    f0 = fr[int(fo_[0]):int(fo_[0]) + int(fl_[0])].cpu().numpy().tobytes()
+    print(json.dumps({"config": "encode_frames_device, 64 contents x 4 MiB, HBM-resident", "block_checksum": st_d.BlockChecksum,
+                      "content_checksum": st_d.ContentChecksum, "ms": round(tf * 1e3, 2), "GiBs": round(tot / tf / 2**30, 1),
+                      "first_frame_equals_host_api": f0 == LZ4Frame.Encode(contents[0], st_d)}))
+
 # chained decode, device resident
 from test_frame_layer import LZ4F
 lz = LZ4F()

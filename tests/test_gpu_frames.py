@@ -4,6 +4,7 @@ Reads like the reference's Streams tests: encode with one side, decode with the 
 liblz4's LZ4F_* and the oracle), checksum variants (ChecksumTests.cs), block encoders (Tests/EncoderTests)."""
 import numpy as np
 import pytest
+import torch   # noqa: F401  (before libk4lz4 is loaded: torch must initialise its HIP runtime first)
 
 from oracle_lib import FrameOracle
 from test_frame_layer import LZ4F, _contents
@@ -154,3 +155,28 @@ def test_block_decoder_decode_drain(oracle):
     small = LZ4BlockDecoder(1024)
     with pytest.raises(InvalidOperationException):
         small.Decode(np.frombuffer(comp, np.uint8))             # decoded block larger than the decoder's buffer
+
+
+def test_device_resident_frame_encoder_equals_host_api(fo, lz4f):
+    """encode_frames_device: contents stay in HBM, frames are laid out by k4_frame_blocks_kernel / k4_frame_edges_kernel;
+    byte-identical to LZ4Frame.EncodeBatch and to the oracle"""
+    import torch
+    from k4os.compression.lz4_amd.device import DeviceCodec
+    from k4os.compression.lz4_amd.frames import encode_frames_device
+    from k4os.compression.lz4_amd import pack_blocks
+    dc = DeviceCodec(0)
+    contents = _contents()
+    data_h, off, ln = pack_blocks(contents)
+    data = torch.from_numpy(data_h).to(dc.device)
+    for bsum, csum, bs, clen in ((False, False, 65536, False), (True, True, 65536, False), (True, False, 262144, True)):
+        s = LZ4EncoderSettings(BlockSize=bs, BlockChecksum=bsum, ContentChecksum=csum, ContentLength=0 if clen else None)
+        frames, foff, flen = encode_frames_device(dc, data, off.astype(np.int64), np.array([c.size for c in contents], np.int64), s)
+        torch.cuda.synchronize()
+        fh, fl = frames.cpu().numpy(), flen.cpu().numpy()
+        for f, c in enumerate(contents):
+            got = fh[int(foff[f]):int(foff[f]) + int(fl[f])].tobytes()
+            if not clen:
+                assert got == fo.frame_encode(c, bs, 0, bsum, csum), (f, bsum, csum)
+            r, out, used = lz4f.decompress(got, c.size + 16)
+            assert r == 0 and used == len(got) and out == c.tobytes()
+            assert LZ4Frame.Decode(got) == c.tobytes()
