@@ -129,9 +129,9 @@ static int protect_dict_end(uint32_t dict_limit, uint32_t match_index) { return 
  * dictLimit == lowLimit == START (every candidate lies in the current prefix).
  * ip / ilow / ihigh are pointers into src; returns `longest`, updates *matchpos / *startpos.
  */
-static int insert_and_get_wider_match(hc_t *c, const uint8_t *ip, const uint8_t *ilow, const uint8_t *ihigh,
-                                      int longest, const uint8_t **matchpos, const uint8_t **startpos,
-                                      int max_attempts, int pattern_analysis)
+static int insert_and_get_wider_match_x(hc_t *c, const uint8_t *ip, const uint8_t *ilow, const uint8_t *ihigh,
+                                        int longest, const uint8_t **matchpos, const uint8_t **startpos,
+                                        int max_attempts, int pattern_analysis, int chain_swap)
 {
     const uint8_t *base = c->base;
     const uint32_t dict_limit = START;
@@ -144,6 +144,7 @@ static int insert_and_get_wider_match(hc_t *c, const uint8_t *ip, const uint8_t 
     uint32_t match_index;
     int repeat = 0;  /* 0 untested, 1 not, 2 confirmed */
     uint32_t src_pattern_length = 0;
+    uint32_t match_chain_pos = 0;                                   /* LL64.high.cs:95 */
 
     hc_insert(c, ip_index);
     match_index = c->hash[hash_ptr(ip)];
@@ -166,9 +167,31 @@ static int insert_and_get_wider_match(hc_t *c, const uint8_t *ip, const uint8_t 
                 }
             }
         }
+        if (chain_swap && match_length == longest) {           /* :172-206 better match => select a better chain */
+            if (match_index + (uint32_t)longest <= ip_index) {
+                const int k_trigger = 4;
+                uint32_t distance_to_next = 1;
+                const int end = longest - MINMATCH + 1;
+                int step = 1, accel = 1 << k_trigger, pos;
+                for (pos = 0; pos < end; pos += step) {
+                    uint32_t cd = c->chain[(uint16_t)(match_index + (uint32_t)pos)];
+                    step = (accel++ >> k_trigger);
+                    if (cd > distance_to_next) {
+                        distance_to_next = cd;
+                        match_chain_pos = (uint32_t)pos;
+                        accel = 1 << k_trigger;
+                    }
+                }
+                if (distance_to_next > 1) {
+                    if (distance_to_next > match_index) break;
+                    match_index -= distance_to_next;
+                    continue;
+                }
+            }
+        }
         {
             uint32_t dist_next = c->chain[(uint16_t)match_index];
-            if (pattern_analysis && dist_next == 1) {          /* :208-337 (matchChainPos == 0) */
+            if (pattern_analysis && dist_next == 1 && match_chain_pos == 0) {   /* :208-337 */
                 uint32_t cand_idx = match_index - 1;
                 if (repeat == 0) {
                     if (((pattern & 0xFFFF) == (pattern >> 16)) & ((pattern & 0xFF) == (pattern >> 24))) {
@@ -221,9 +244,16 @@ static int insert_and_get_wider_match(hc_t *c, const uint8_t *ip, const uint8_t 
                 }
             }
         }
-        match_index -= c->chain[(uint16_t)match_index];
+        match_index -= c->chain[(uint16_t)(match_index + match_chain_pos)];   /* :340 follow current chain */
     }
     return longest;
+}
+
+static int insert_and_get_wider_match(hc_t *c, const uint8_t *ip, const uint8_t *ilow, const uint8_t *ihigh,
+                                      int longest, const uint8_t **matchpos, const uint8_t **startpos,
+                                      int max_attempts, int pattern_analysis)
+{
+    return insert_and_get_wider_match_x(c, ip, ilow, ihigh, longest, matchpos, startpos, max_attempts, pattern_analysis, 0);
 }
 
 /* LL64.high.cs:435-510; returns 1 on output overflow */
@@ -387,13 +417,168 @@ static int nb_searches(int level)
     return t[level];
 }
 
-/* LL64.LZ4_compress_HC (LL64.high.cs:1367-1381) for levels <= 9 */
+/* ---- optimal parser, levels 10..12 (LL64.high.cs:802-1122; LL.high.cs:267-287 prices; :404-445 FindLongerMatch) ---- */
+#define OPT_NUM (1 << 12)
+#define TRAILING_LITERALS 3
+typedef struct { int price, off, mlen, litlen; } opt_t;
+
+static int literals_price(int litlen)
+{
+    int price = litlen;
+    if (litlen >= (int)RUN_MASK) price += 1 + ((litlen - (int)RUN_MASK) / 255);
+    return price;
+}
+static int sequence_price(int litlen, int mlen)
+{
+    int price = 1 + 2;
+    price += literals_price(litlen);
+    if (mlen >= (int)(ML_MASK + MINMATCH)) price += 1 + ((mlen - (int)(ML_MASK + MINMATCH)) / 255);
+    return price;
+}
+
+/* LZ4HC_FindLongerMatch with favorCompressionRatio: pattern analysis and chain swap on, no look-back */
+static void find_longer_match(hc_t *c, const uint8_t *ip, const uint8_t *ihigh, int min_len, int nb_searches, int *len, int *off)
+{
+    const uint8_t *mp = NULL, *sp = ip;
+    int ml = insert_and_get_wider_match_x(c, ip, ip, ihigh, min_len, &mp, &sp, nb_searches, 1, 1);
+    *len = 0; *off = 0;
+    if (ml <= min_len) return;
+    *len = ml;
+    *off = (int)(ip - mp);
+}
+
+static int compress_optimal(hc_t *ctx, const uint8_t *source, uint8_t *dst, int src_size, int dst_capacity, int nb_searches,
+                            size_t sufficient_len, int limited, int full_update)
+{
+    opt_t *opt = (opt_t *)malloc(sizeof(opt_t) * (OPT_NUM + TRAILING_LITERALS));
+    const uint8_t *ip = source, *anchor = ip;
+    const uint8_t *iend = ip + src_size, *mflimit = iend - MFLIMIT, *matchlimit = iend - LASTLITERALS;
+    uint8_t *op = dst, *oend = op + dst_capacity;
+    int result = 0;
+    if (!opt) return 0;
+    if (sufficient_len >= OPT_NUM) sufficient_len = OPT_NUM - 1;
+
+    while (ip <= mflimit) {
+        int llen = (int)(ip - anchor);
+        int best_mlen, best_off, cur, last_match_pos = 0;
+        int first_len, first_off;
+        find_longer_match(ctx, ip, matchlimit, MINMATCH - 1, nb_searches, &first_len, &first_off);
+        if (first_len == 0) { ip++; continue; }
+        if ((size_t)first_len > sufficient_len) {
+            if (encode_sequence(&ip, &op, &anchor, first_len, ip - first_off, limited, oend)) goto overflow;
+            continue;
+        }
+        for (int r = 0; r < MINMATCH; r++) {
+            opt[r].mlen = 1; opt[r].off = 0; opt[r].litlen = llen + r; opt[r].price = literals_price(llen + r);
+        }
+        for (int mlen = MINMATCH; mlen <= first_len; mlen++) {
+            opt[mlen].mlen = mlen; opt[mlen].off = first_off; opt[mlen].litlen = llen; opt[mlen].price = sequence_price(llen, mlen);
+        }
+        last_match_pos = first_len;
+        for (int a = 1; a <= TRAILING_LITERALS; a++) {
+            opt[last_match_pos + a].mlen = 1; opt[last_match_pos + a].off = 0; opt[last_match_pos + a].litlen = a;
+            opt[last_match_pos + a].price = opt[last_match_pos].price + literals_price(a);
+        }
+        for (cur = 1; cur < last_match_pos; cur++) {
+            const uint8_t *cur_ptr = ip + cur;
+            int new_len, new_off;
+            if (cur_ptr > mflimit) break;
+            if (full_update) {
+                if ((opt[cur + 1].price <= opt[cur].price) && (opt[cur + MINMATCH].price < opt[cur].price + 3)) continue;
+            } else {
+                if (opt[cur + 1].price <= opt[cur].price) continue;
+            }
+            if (full_update) find_longer_match(ctx, cur_ptr, matchlimit, MINMATCH - 1, nb_searches, &new_len, &new_off);
+            else find_longer_match(ctx, cur_ptr, matchlimit, last_match_pos - cur, nb_searches, &new_len, &new_off);
+            if (new_len == 0) continue;
+            if (((size_t)new_len > sufficient_len) || (new_len + cur >= OPT_NUM)) {
+                best_mlen = new_len; best_off = new_off; last_match_pos = cur + 1;
+                goto encode;
+            }
+            {
+                int base_litlen = opt[cur].litlen;
+                for (int litlen = 1; litlen < MINMATCH; litlen++) {
+                    int price = opt[cur].price - literals_price(base_litlen) + literals_price(base_litlen + litlen);
+                    int pos = cur + litlen;
+                    if (price < opt[pos].price) {
+                        opt[pos].mlen = 1; opt[pos].off = 0; opt[pos].litlen = base_litlen + litlen; opt[pos].price = price;
+                    }
+                }
+            }
+            {
+                int match_ml = new_len;
+                for (int ml = MINMATCH; ml <= match_ml; ml++) {
+                    int pos = cur + ml, price, ll;
+                    if (opt[cur].mlen == 1) {
+                        ll = opt[cur].litlen;
+                        price = ((cur > ll) ? opt[cur - ll].price : 0) + sequence_price(ll, ml);
+                    } else {
+                        ll = 0;
+                        price = opt[cur].price + sequence_price(0, ml);
+                    }
+                    if (pos > last_match_pos + TRAILING_LITERALS || price <= opt[pos].price) {
+                        if ((ml == match_ml) && (last_match_pos < pos)) last_match_pos = pos;
+                        opt[pos].mlen = ml; opt[pos].off = new_off; opt[pos].litlen = ll; opt[pos].price = price;
+                    }
+                }
+            }
+            for (int a = 1; a <= TRAILING_LITERALS; a++) {
+                opt[last_match_pos + a].mlen = 1; opt[last_match_pos + a].off = 0; opt[last_match_pos + a].litlen = a;
+                opt[last_match_pos + a].price = opt[last_match_pos].price + literals_price(a);
+            }
+        }
+        best_mlen = opt[last_match_pos].mlen;
+        best_off = opt[last_match_pos].off;
+        cur = last_match_pos - best_mlen;
+    encode:
+        {
+            int candidate_pos = cur, sel_ml = best_mlen, sel_off = best_off;
+            for (;;) {
+                int next_ml = opt[candidate_pos].mlen, next_off = opt[candidate_pos].off;
+                opt[candidate_pos].mlen = sel_ml; opt[candidate_pos].off = sel_off;
+                sel_ml = next_ml; sel_off = next_off;
+                if (next_ml > candidate_pos) break;
+                candidate_pos -= next_ml;
+            }
+        }
+        {
+            int r = 0;
+            while (r < last_match_pos) {
+                int ml = opt[r].mlen, offset = opt[r].off;
+                if (ml == 1) { ip++; r++; continue; }
+                r += ml;
+                if (encode_sequence(&ip, &op, &anchor, ml, ip - offset, limited, oend)) goto overflow;
+            }
+        }
+    }
+    {   /* _last_literals (:1062-1098), limitedOutput / notLimited only */
+        size_t last_run = (size_t)(iend - anchor);
+        size_t lit_length = (last_run + 255 - RUN_MASK) / 255;
+        size_t total = 1 + lit_length + last_run;
+        if (limited && (op + total > oend)) goto overflow;
+        if (last_run >= RUN_MASK) {
+            size_t acc = last_run - RUN_MASK;
+            *op++ = (uint8_t)(RUN_MASK << ML_BITS);
+            for (; acc >= 255; acc -= 255) *op++ = 255;
+            *op++ = (uint8_t)acc;
+        } else {
+            *op++ = (uint8_t)(last_run << ML_BITS);
+        }
+        memcpy(op, anchor, last_run);
+        op += last_run;
+    }
+    result = (int)(op - dst);
+overflow:
+    free(opt);
+    return result;
+}
+
+/* LL64.LZ4_compress_HC (LL64.high.cs:1367-1381): clTable (:1124-1138) picks hash chain (3..9) or the optimal parser (10..12) */
 K4O_API int k4o_compress_hc(const uint8_t *src, uint8_t *dst, int src_len, int dst_cap, int level)
 {
     if ((uint32_t)src_len > (uint32_t)MAX_INPUT_SIZE) return 0;          /* :1153 */
     if (level < 1) level = 9;                                           /* LZ4HC_CLEVEL_DEFAULT */
     if (level > 12) level = 12;
-    if (level >= 10) return 0;                                          /* optimal parser: not restated */
     hc_t *ctx = (hc_t *)malloc(sizeof(hc_t));
     if (!ctx) return 0;
     memset(ctx->hash, 0, sizeof ctx->hash);                             /* LZ4HC_clearTables */
@@ -403,7 +588,14 @@ K4O_API int k4o_compress_hc(const uint8_t *src, uint8_t *dst, int src_len, int d
     ctx->src = src;
     int bound = src_len > MAX_INPUT_SIZE ? 0 : src_len + src_len / 255 + 16;
     int limited = dst_cap < bound;
-    int r = compress_hash_chain(ctx, src, dst, src_len, dst_cap, nb_searches(level), limited);
+    int r;
+    if (level >= 10) {
+        static const int nbs[3] = {96, 512, 16384};
+        static const size_t tgt[3] = {64, 128, OPT_NUM};
+        r = compress_optimal(ctx, src, dst, src_len, dst_cap, nbs[level - 10], tgt[level - 10], limited, level == 12);
+    } else {
+        r = compress_hash_chain(ctx, src, dst, src_len, dst_cap, nb_searches(level), limited);
+    }
     free(ctx);
     return r;
 }
