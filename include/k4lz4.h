@@ -44,7 +44,7 @@ enum k4lz4_status {
     K4LZ4_E_ARG = -2,         /* NULL pointer / negative count (the C# shim raises ArgumentException) */
     K4LZ4_E_NOMEM = -3,
     K4LZ4_E_NO_DEVICE = -4,   /* no gfx950 device visible */
-    K4LZ4_E_UNSUPPORTED = -5  /* level outside what the device path implements: L10_OPT..L12_MAX, the optimal parser */
+    K4LZ4_E_UNSUPPORTED = -5  /* reserved: every LZ4Level is implemented (levels above L12_MAX behave as L12_MAX, LL64.high.cs:1160) */
 };
 
 /* LZ4Level.cs:6-39 -- the numeric value is part of the ABI */

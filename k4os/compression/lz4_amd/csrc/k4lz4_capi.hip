@@ -80,8 +80,8 @@ enum Kind { KIND_ENCODE, KIND_DECODE, KIND_PICKLE, KIND_UNPICKLE };
 
 int check_level(k4lz4_ctx *ctx, int level)
 {
-    if (level <= K4LZ4_L09_HC) return K4LZ4_OK;   /* < L03_HC -> fast (LZ4Codec.cs:48); L03..L09 -> hash chain (L09 with pattern analysis) */
-    return fail(ctx, K4LZ4_E_UNSUPPORTED, "LZ4Level L10_OPT..L12_MAX (optimal parser) are not implemented by the device path");
+    (void)ctx; (void)level;   /* < L03_HC -> fast (LZ4Codec.cs:48); L03..L09 hash chain; L10..L12 optimal parser; above: as L12 (LL64.high.cs:1160) */
+    return K4LZ4_OK;
 }
 
 int grow(k4lz4_ctx *ctx, uint8_t **p, size_t *cap, size_t need, bool pinned);
@@ -126,7 +126,8 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
         h.work = ctx->d_hc_work;
         K4_HIP(ctx, hipMemsetAsync(ctx->d_hc_hash, 0, (size_t)cnt << (k4::HC_HASH_LOG + 2), stream));
         hipLaunchKernelGGL(k4::k4_hc_chain_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
-        if (tail[1] >= 13) {
+        const bool optimal = level >= K4LZ4_L10_OPT;              /* clTable (LL64.high.cs:1124-1138): lz4opt strategy */
+        if (tail[1] >= 13 && !optimal) {
             const unsigned gy = (unsigned)((tail[1] + k4::HC_CAND_POS_PER_WG - 1) / k4::HC_CAND_POS_PER_WG);
             for (unsigned y0 = 0; y0 < gy; y0 += 65535u) {   /* grid.y limit */
                 k4::HcArgs hy = h;
@@ -134,7 +135,8 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
                 hipLaunchKernelGGL(k4::k4_hc_cand_kernel, dim3((unsigned)cnt, std::min(65535u, gy - y0)), dim3(256), 0, stream, hy);
             }
         }
-        hipLaunchKernelGGL(k4::k4_hc_parse_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
+        if (optimal) hipLaunchKernelGGL(k4::k4_hc_parse_opt_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
+        else hipLaunchKernelGGL(k4::k4_hc_parse_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
         if (pickle) hipLaunchKernelGGL(k4::k4_pickle_finish_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a, d_enclen);
         K4_HIP(ctx, hipGetLastError());
     }

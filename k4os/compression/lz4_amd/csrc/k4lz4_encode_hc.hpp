@@ -1,5 +1,6 @@
 /*
- * k4lz4_encode_hc.hpp -- batched LZ4 HC (hash-chain) block encoder for gfx950, levels L03..L09.
+ * k4lz4_encode_hc.hpp -- batched LZ4 HC block encoder for gfx950: hash chain (levels L03..L09) and the optimal
+ * parser (L10..L12, LL64.high.cs:802-1122, at the end of this file).
  *
  * Replaces (for batches of independent blocks) the reference's
  *   LZ4Codec.Encode (level >= L03_HC)        src/K4os.Compression.LZ4/LZ4Codec.cs:48-51
@@ -548,6 +549,265 @@ __device__ __forceinline__ bool hc_encode_sequence(const uint8_t *src, uint8_t *
     return true;
 }
 
+/* ---- levels 10..12: the optimal parser (LL64.high.cs:802-1122) ------------------------------------------
+ * LZ4HC_FindLongerMatch = InsertAndGetWiderMatch with pattern analysis AND chain swap, no look-back: the walk
+ * is data dependent from the first improvement on, so it goes one candidate at a time.  The price table of the
+ * dynamic program (4096 + 3 positions) lives in LDS; its inner loops over match lengths run one length per lane. */
+constexpr int HC_OPT_NUM = 1 << 12;                        /* LL.types.cs:75 */
+constexpr int HC_OPT_ENTRIES = HC_OPT_NUM + 3;             /* + TRAILING_LITERALS */
+constexpr int HC_OPT_LDS_DWORDS = HC_OPT_ENTRIES * 3 + 4;  /* price u32, litlen u32, (mlen | off << 16) u32 */
+
+__device__ __forceinline__ uint32_t hc_delta(const uint32_t *prev, uint32_t p)       /* DELTANEXTU16(chainTable, p) */
+{
+    const uint32_t pv = uni(prev[p]);
+    return pv == HC_NONE || p - pv >= (uint32_t)DISTANCE_MAX ? (uint32_t)DISTANCE_MAX : p - pv;
+}
+
+struct HcOptMatch { int len; int off; };
+
+__device__ __forceinline__ HcOptMatch hc_find_longer_match(const uint8_t *src, const uint32_t *prev, uint32_t ip, uint32_t matchlimit,
+                                                           int min_len, int nb_searches, int lane)
+{
+    HcOptMatch r; r.len = 0; r.off = 0;
+    const uint32_t pattern = uni(ld32u(src + ip));
+    const uint32_t lowest = ip > (uint32_t)DISTANCE_MAX ? ip - (uint32_t)DISTANCE_MAX : 0u;
+    int longest = min_len;
+    uint32_t mpos = 0;
+    int attempts = nb_searches;
+    int repeat = 0;
+    uint32_t src_pattern_length = 0, chain_pos = 0;        /* matchChainPos (:95) */
+    uint32_t mi = uni(prev[ip]);
+    if (mi == HC_NONE) return r;
+    while (mi >= lowest && attempts != 0) {
+        attempts--;
+        bool improved = false;
+        if (uni(ld32u(src + mi)) == pattern) {              /* :120-133; the 16-bit pre-test only filters non-improvements */
+            const int ml = (int)(MINMATCH + wave_count(src + ip + MINMATCH, src + mi + MINMATCH, matchlimit - (ip + MINMATCH), lane));
+            if (ml > longest) { longest = ml; mpos = mi; improved = true; }
+        }
+        if (improved && mi + (uint32_t)longest <= ip) {     /* :172-206 chain swap */
+            uint32_t dist_next = 1;
+            const int end = longest - MINMATCH + 1;
+            int step = 1, accel = 16;
+            for (int pos = 0; pos < end; pos += step) {
+                const uint32_t cd = hc_delta(prev, mi + (uint32_t)pos);
+                step = accel++ >> 4;
+                if (cd > dist_next) { dist_next = cd; chain_pos = (uint32_t)pos; accel = 16; }
+            }
+            if (dist_next > 1u) {
+                if (dist_next > mi) break;
+                mi -= dist_next;
+                continue;
+            }
+        }
+        {
+            const uint32_t d0 = hc_delta(prev, mi);
+            if (d0 == 1u && chain_pos == 0u) {              /* :208-337 pattern analysis */
+                const uint32_t cidx = mi - 1u;
+                if (repeat == 0) {
+                    if (((pattern & 0xFFFFu) == (pattern >> 16)) && ((pattern & 0xFFu) == (pattern >> 24))) {
+                        repeat = 2;
+                        src_pattern_length = hc_count_pattern(src, ip + MINMATCH, matchlimit, pattern, lane) + MINMATCH;
+                    } else {
+                        repeat = 1;
+                    }
+                }
+                if (repeat == 2 && cidx >= lowest && uni(ld32u(src + cidx)) == pattern) {
+                    const uint32_t fwd = hc_count_pattern(src, cidx + MINMATCH, matchlimit, pattern, lane) + MINMATCH;
+                    uint32_t back_len = hc_reverse_count_pattern(src, cidx, pattern, lane);
+                    {
+                        const uint32_t a = cidx - back_len;
+                        back_len = cidx - (a > lowest ? a : lowest);
+                    }
+                    const uint32_t cur_seg = back_len + fwd;
+                    if (cur_seg >= src_pattern_length && fwd <= src_pattern_length) {
+                        mi = cidx + fwd - src_pattern_length;
+                    } else {
+                        mi = cidx - back_len;
+                        const uint32_t max_ml = cur_seg < src_pattern_length ? cur_seg : src_pattern_length;
+                        if ((uint32_t)longest < max_ml) {
+                            if (ip - mi > (uint32_t)DISTANCE_MAX) break;
+                            longest = (int)max_ml; mpos = mi;
+                        }
+                        const uint32_t d = hc_delta(prev, mi);
+                        if (d > mi) break;
+                        mi -= d;
+                    }
+                    continue;
+                }
+            }
+        }
+        {
+            const uint32_t d = hc_delta(prev, mi + chain_pos);   /* :340 follow current chain */
+            if (d > mi) break;
+            mi -= d;
+        }
+    }
+    if (longest <= min_len) return r;
+    r.len = longest;
+    r.off = (int)(ip - mpos);
+    return r;
+}
+
+__device__ __forceinline__ int hc_literals_price(int litlen)                      /* LL.high.cs:267-274 */
+{
+    return litlen + (litlen >= (int)RUN_MASK ? 1 + (litlen - (int)RUN_MASK) / 255 : 0);
+}
+__device__ __forceinline__ int hc_sequence_price(int litlen, int mlen)            /* LL.high.cs:277-287 */
+{
+    return 3 + hc_literals_price(litlen) + (mlen >= (int)(ML_MASK + MINMATCH) ? 1 + (mlen - (int)(ML_MASK + MINMATCH)) / 255 : 0);
+}
+
+/* LZ4HC_compress_optimal for one block (limitedOutput / notLimited); returns bytes written, 0 = overflow */
+__device__ __forceinline__ int hc_parse_block_opt(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap, int level,
+                                                  const uint32_t *prev, uint32_t *lds, int lane)
+{
+    if ((uint32_t)src_len > (uint32_t)MAX_INPUT_SIZE) return 0;
+    const bool limited = dst_cap < compress_bound(src_len);
+    const int64_t oend = dst_cap;
+    const uint32_t U = (uint32_t)src_len;
+    const int nb_searches = level <= 10 ? 96 : level == 11 ? 512 : 16384;         /* clTable :1134-1136; above 12: as 12 (:1160) */
+    int sufficient_len = level <= 10 ? 64 : level == 11 ? 128 : HC_OPT_NUM;
+    if (sufficient_len >= HC_OPT_NUM) sufficient_len = HC_OPT_NUM - 1;
+    const bool full_update = level >= 12;
+    uint32_t *o_price = lds, *o_litlen = lds + HC_OPT_ENTRIES, *o_ml_off = lds + 2 * HC_OPT_ENTRIES;
+#define K4_OPT_SET(P, ML, OFF, LL, PR) do { o_price[(P)] = (uint32_t)(PR); o_litlen[(P)] = (uint32_t)(LL); o_ml_off[(P)] = (uint32_t)(ML) | ((uint32_t)(OFF) << 16); } while (0)
+    uint32_t ip = 0, anchor = 0;
+    int64_t op = 0;
+    if (src_len >= MFLIMIT + 1) {
+        const uint32_t mflimit = U - MFLIMIT, matchlimit = U - LASTLITERALS;
+        while (ip <= mflimit) {
+            const int llen = (int)(ip - anchor);
+            const HcOptMatch first = hc_find_longer_match(src, prev, ip, matchlimit, MINMATCH - 1, nb_searches, lane);
+            if (first.len == 0) { ip++; continue; }
+            if (first.len > sufficient_len) {                       /* good enough: immediate encoding */
+                if (!hc_encode_sequence(src, dst, ip, op, anchor, first.len, ip - (uint32_t)first.off, limited, oend, lane)) return 0;
+                continue;
+            }
+            wave_sync();
+            if (lane < MINMATCH) K4_OPT_SET(lane, 1, 0, llen + lane, hc_literals_price(llen + lane));
+            for (int m = MINMATCH + lane; m <= first.len; m += 64) K4_OPT_SET(m, m, first.off, llen, hc_sequence_price(llen, m));
+            int last_match_pos = first.len;
+            wave_sync();
+            {
+                const uint32_t base_price = uni(o_price[last_match_pos]);
+                if (lane >= 1 && lane <= 3) K4_OPT_SET(last_match_pos + lane, 1, 0, lane, base_price + (uint32_t)hc_literals_price(lane));
+            }
+            wave_sync();
+            int best_mlen = 0, best_off = 0, cur;
+            bool direct = false;
+            for (cur = 1; cur < last_match_pos; cur++) {
+                const uint32_t cur_ptr = ip + (uint32_t)cur;
+                if (cur_ptr > mflimit) break;
+                const int p_cur = (int)uni(o_price[cur]), p_next = (int)uni(o_price[cur + 1]);
+                if (full_update) {
+                    if (p_next <= p_cur && (int)uni(o_price[cur + MINMATCH]) < p_cur + 3) continue;
+                } else {
+                    if (p_next <= p_cur) continue;
+                }
+                const HcOptMatch nm = hc_find_longer_match(src, prev, cur_ptr, matchlimit, full_update ? MINMATCH - 1 : last_match_pos - cur,
+                                                           nb_searches, lane);
+                if (nm.len == 0) continue;
+                if (nm.len > sufficient_len || nm.len + cur >= HC_OPT_NUM) {     /* immediate encoding */
+                    best_mlen = nm.len; best_off = nm.off; last_match_pos = cur + 1;
+                    direct = true;
+                    break;
+                }
+                const int cur_litlen = (int)uni(o_litlen[cur]);
+                const int cur_mlen = (int)(uni(o_ml_off[cur]) & 0xffffu);
+                /* before the match: literals at the beginning */
+                if (lane >= 1 && lane < MINMATCH) {
+                    const int price = p_cur - hc_literals_price(cur_litlen) + hc_literals_price(cur_litlen + lane);
+                    const int pos = cur + lane;
+                    if (price < (int)o_price[pos]) K4_OPT_SET(pos, 1, 0, cur_litlen + lane, price);
+                }
+                wave_sync();
+                /* prices using the match at position cur, one length per lane */
+                {
+                    int ll, base;
+                    if (cur_mlen == 1) {
+                        ll = cur_litlen;
+                        base = cur > ll ? (int)uni(o_price[cur - ll]) : 0;
+                    } else {
+                        ll = 0;
+                        base = p_cur;
+                    }
+                    const int lmp = last_match_pos;
+                    bool took_last = false;
+                    for (int ml = MINMATCH + lane; ml <= nm.len; ml += 64) {
+                        const int pos = cur + ml;
+                        const int price = base + hc_sequence_price(ll, ml);
+                        if (pos > lmp + 3 || price <= (int)o_price[pos]) {
+                            K4_OPT_SET(pos, ml, nm.off, ll, price);
+                            if (ml == nm.len) took_last = true;
+                        }
+                    }
+                    /* the last length of the match may extend the table (:993-995) */
+                    if (__ballot(took_last) && lmp < cur + nm.len) last_match_pos = cur + nm.len;
+                    wave_sync();
+                }
+                /* complete the following positions with literals */
+                {
+                    const uint32_t base_price = uni(o_price[last_match_pos]);
+                    if (lane >= 1 && lane <= 3) K4_OPT_SET(last_match_pos + lane, 1, 0, lane, base_price + (uint32_t)hc_literals_price(lane));
+                }
+                wave_sync();
+            }
+            if (!direct) {
+                const uint32_t mo = uni(o_ml_off[last_match_pos]);
+                best_mlen = (int)(mo & 0xffffu);
+                best_off = (int)(mo >> 16);
+                cur = last_match_pos - best_mlen;
+            }
+            /* encode: walk the chosen path backwards, then emit it forwards (:1018-1059) */
+            {
+                int candidate_pos = cur, sel_ml = best_mlen, sel_off = best_off;
+                for (;;) {
+                    const uint32_t mo = uni(o_ml_off[candidate_pos]);
+                    const int next_ml = (int)(mo & 0xffffu), next_off = (int)(mo >> 16);
+                    wave_sync();
+                    if (lane == 0) o_ml_off[candidate_pos] = (uint32_t)sel_ml | ((uint32_t)sel_off << 16);
+                    wave_sync();
+                    sel_ml = next_ml; sel_off = next_off;
+                    if (next_ml > candidate_pos) break;
+                    candidate_pos -= next_ml;
+                }
+            }
+            {
+                int r = 0;
+                while (r < last_match_pos) {
+                    const uint32_t mo = uni(o_ml_off[r]);
+                    const int ml = (int)(mo & 0xffffu), offset = (int)(mo >> 16);
+                    if (ml == 1) { ip++; r++; continue; }
+                    r += ml;
+                    if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ip - (uint32_t)offset, limited, oend, lane)) return 0;
+                }
+            }
+        }
+    }
+#undef K4_OPT_SET
+    /* _last_literals (:1062-1098) */
+    {
+        const uint32_t last_run = U - anchor;
+        const uint32_t lit_length = (last_run + 255u - RUN_MASK) / 255u;
+        if (limited && op + 1 + (int64_t)lit_length + (int64_t)last_run > oend) return 0;
+        if (last_run >= (uint32_t)RUN_MASK) {
+            const uint32_t acc = last_run - RUN_MASK;
+            const uint32_t nb = acc / 255u;
+            if (lane == 0) dst[op] = (uint8_t)(RUN_MASK << ML_BITS);
+            wave_fill(dst + op + 1, 255, nb, lane);
+            if (lane == 0) dst[op + 1 + nb] = (uint8_t)(acc - nb * 255u);
+            op += 2 + nb;
+        } else {
+            if (lane == 0) dst[op] = (uint8_t)(last_run << ML_BITS);
+            op++;
+        }
+        wave_copy(dst + op, src + anchor, last_run, lane);
+        op += last_run;
+    }
+    return (int)op;
+}
+
 /* clTable (LL64.high.cs:1124-1138), hash-chain levels */
 __device__ __forceinline__ int hc_nb_searches(int level)
 {
@@ -729,6 +989,26 @@ __global__ __launch_bounds__(64) void k4_hc_parse_kernel(HcArgs a)
         uint8_t *d = a.dst + a.dstOff[b];
         if (hc_nb_searches(a.level) <= 4) ret = hc_parse_block<true>(s, src_len, d, cap < 0 ? 0 : cap, a.level, cand, flen, blen, lane);
         else ret = hc_parse_block<false>(s, src_len, d, cap < 0 ? 0 : cap, a.level, cand, flen, blen, lane);
+    }
+    if (lane == 0) {
+        int r = ret;
+        if (!(a.flags & FLAG_RAW_RETURN)) r = src_len <= 0 ? 0 : (ret <= 0 ? -1 : ret);   /* LZ4Codec.cs:45-51 */
+        a.outLen[b] = r;
+    }
+}
+
+/* levels 10..12: one wavefront per block, the price table in LDS (48 KiB: three blocks per CU) */
+__global__ __launch_bounds__(64) void k4_hc_parse_opt_kernel(HcArgs a)
+{
+    __shared__ uint32_t opt_lds[HC_OPT_LDS_DWORDS];
+    const int lane = lane_id();
+    const long long b = (long long)blockIdx.x;
+    const int src_len = a.srcLen[b];
+    const int cap = a.dstCap[b];
+    int ret = 0;
+    if (src_len > 0 || (a.flags & FLAG_RAW_RETURN)) {
+        const uint32_t *prev = (const uint32_t *)(a.work + a.workOff[b]);
+        ret = hc_parse_block_opt(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.level, prev, opt_lds, lane);
     }
     if (lane == 0) {
         int r = ret;

@@ -276,7 +276,8 @@ def test_full_size_config2_properties(oracle):
 
 
 # ---- HC levels (BASELINE.json configs[4]) -----------------------------------
-@pytest.mark.parametrize("level", [LZ4Level.L03_HC, LZ4Level.L04_HC, LZ4Level.L06_HC, LZ4Level.L08_HC, LZ4Level.L09_HC])
+@pytest.mark.parametrize("level", [LZ4Level.L03_HC, LZ4Level.L04_HC, LZ4Level.L06_HC, LZ4Level.L08_HC, LZ4Level.L09_HC,
+                                   LZ4Level.L10_OPT, LZ4Level.L11_OPT, LZ4Level.L12_MAX])
 def test_hc_single_block_roundtrip(oracle, level):
     for data in (corpus.lorem(0x172a5), corpus.class_bytes("webster", 65536, 3), corpus.repeated(7, 1000)):
         target = np.full(LZ4Codec.MaximumOutputSize(data.size), 0xCD, np.uint8)
@@ -349,11 +350,42 @@ def test_hc_level9_pattern_analysis_batch(oracle):
     assert all(d == b.tobytes() for d, b in zip(dec, blocks))
 
 
-def test_unsupported_levels_fail_loudly():
+@pytest.mark.parametrize("level", [LZ4Level.L10_OPT, LZ4Level.L11_OPT, LZ4Level.L12_MAX])
+def test_optimal_parser_levels_batch(oracle, level):
+    """L10_OPT..L12_MAX = LZ4HC_compress_optimal (LL64.high.cs:802-1122): pattern runs, the 12 classes, limited output;
+    byte-compared with the oracle (itself byte-equal to liblz4 at these levels)"""
+    rng = np.random.default_rng(10)
+    blocks = []
+    for unit in (b"a", b"ab", b"abcd", b"abc"):
+        parts = []
+        for _ in range(40):
+            parts.append(np.frombuffer(unit * int(rng.integers(1, 400)), np.uint8))
+            parts.append(rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8))
+        blocks.append(np.concatenate(parts))
+    blocks += [corpus.class_bytes(name, 30000, 12) for name in corpus.SILESIA_NAMES]
+    blocks += [corpus.lorem(70000), np.zeros(0, np.uint8), corpus.lorem(12), corpus.lorem(13)]
+    enc = LZ4Codec.EncodeBatch(blocks, level)
+    for i, b in enumerate(blocks):
+        if b.size == 0:
+            assert enc[i] == b""
+            continue
+        r, w = oracle.compress_hc(b, int(level))
+        assert enc[i] == w[:r].tobytes(), i
+    dec = LZ4Codec.DecodeBatch(enc, [b.size for b in blocks])
+    assert all(d == b.tobytes() for d, b in zip(dec, blocks))
+    b = blocks[6]
+    r, w = oracle.compress_hc(b, int(level))
+    assert LZ4Codec.Encode(b, np.zeros(r, np.uint8), level) == r
+    assert LZ4Codec.Encode(b, np.zeros(r - 1, np.uint8), level) < 0
+
+
+def test_every_level_of_the_enum_is_implemented():
     data = corpus.lorem(5000)
-    for level in (LZ4Level.L10_OPT, LZ4Level.L11_OPT, LZ4Level.L12_MAX):
-        with pytest.raises(NotImplementedError):
-            LZ4Codec.Encode(data, np.zeros(6000, np.uint8), level)
+    for level in LZ4Level:
+        tgt = np.zeros(LZ4Codec.MaximumOutputSize(data.size), np.uint8)
+        n = LZ4Codec.Encode(data, tgt, level)
+        out = np.zeros(data.size, np.uint8)
+        assert n > 0 and LZ4Codec.Decode(tgt[:n].copy(), out) == data.size and out.tobytes() == data.tobytes()
 
 
 def test_dispatch_variants_give_identical_bytes(oracle):
