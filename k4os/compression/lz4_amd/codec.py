@@ -80,7 +80,21 @@ def _ptr(a: np.ndarray) -> int:
     return a.ctypes.data
 
 
-class LZ4Codec:
+class _LZ4CodecMeta(type):
+    """LZ4Codec.Enforce32 (LZ4Codec.cs:14-25) switches the reference to its 32-bit engine, whose fast encoder emits
+    different bytes for blocks of 64 KiB and more.  That arm is not built here; asking for it fails loudly."""
+
+    @property
+    def Enforce32(cls) -> bool:
+        return False
+
+    @Enforce32.setter
+    def Enforce32(cls, value: bool) -> None:
+        if value:
+            raise NotImplementedError("LZ4Codec.Enforce32: the 32-bit engine (LL32) is not implemented by the device path")
+
+
+class LZ4Codec(metaclass=_LZ4CodecMeta):
     """Static class for compressing and decompressing LZ4 blocks (reference LZ4Codec.cs)."""
 
     Version = 192  # block format of lz4 1.9.2 (LZ4Codec.cs:13)
@@ -122,8 +136,22 @@ class LZ4Codec:
         """Decode(source, target) or Decode(source, sourceOffset, sourceLength, target,
         targetOffset, targetLength).  Returns bytes written, 0 for an empty source, or a negative
         value if the target is too small / the block is corrupt."""
-        if len(args) == 3:                                       # Decode(source, target, dictionary): LZ4Codec.cs:144-160
+        if len(args) == 3:                                       # Decode(source, target, dictionary): LZ4Codec.cs:198-216
             return LZ4Codec._decode_with_dictionary(*args)
+        if len(args) == 9:                                       # ... with offsets and lengths: LZ4Codec.cs:250-266
+            src, dst = _ro_view(args[0], "source"), _rw_view(args[3], "target")
+            so, sl, to, tl = int(args[1]), int(args[2]), int(args[4]), int(args[5])
+            _validate(src, so, sl, "source")
+            _validate(dst, to, tl, "target")
+            if args[6] is None:                                  # dictionary.Validate(..., allowNullIfEmpty: true)
+                if int(args[7]) != 0 or int(args[8]) != 0:
+                    raise ValueError("dictionary is null but offset / length are not zero")
+                dct = np.zeros(0, np.uint8)
+            else:
+                d = _ro_view(args[6], "dictionary")
+                _validate(d, int(args[7]), int(args[8]), "dictionary")
+                dct = d[int(args[7]):int(args[7]) + int(args[8])]
+            return LZ4Codec._decode_with_dictionary(src[so:so + sl], dst[to:to + tl], dct)
         long = _split_args(args, 2, "Decode")
         if long is None:
             src, dst = _ro_view(args[0], "source"), _rw_view(args[1], "target")

@@ -240,7 +240,6 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 if (lane == 0) tab.put(h2, ip - 2u);                /* :394 */
             }
             wave_sync();
-            unsigned long long ts = prof_now<PROF>();
             if (PROF) { n_round++; }
             uint32_t h = 0, cand = 0;
             if (valid) {
@@ -248,13 +247,11 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 cand = tab.get(h);
                 scr[h & scr_mask] = (uint8_t)lane;
             }
-            if (PROF) { ts = prof_now<PROF>(); }
             const Around ca = load_around(src, cand);
             wave_sync();
             const bool flagged = valid && scr[h & scr_mask] != (uint8_t)lane;
             const bool hit_tab = valid && (BYU16 || cand + (uint32_t)DISTANCE_MAX >= pos) && ca.seq == pa.seq;
             const uint32_t info = extension_info(pa.pre, pa.next, pa.pre_ok, ca.pre, ca.next, ca.pre_ok, matchlimit - (pos + MINMATCH));
-            if (PROF) { ts = prof_now<PROF>(); }
 
             /* ---------------- groups: lanes of the window with equal hashes ---------------- */
             unsigned long long G = me;
@@ -270,7 +267,6 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 }
             }
             const unsigned long long dirty = __ballot(G != me);
-            if (PROF) { ts = prof_now<PROF>(); }
 
             /* ---------------- resolve: every sequence that starts in the window ---------------- */
             const unsigned long long t1 = prof_now<PROF>();

@@ -456,6 +456,11 @@ def test_issue64_chained_record_with_dictionary(oracle):
     assert n < 0 and LZ4Codec.Decode(c1, np.zeros(u1, np.uint8)) == -1
     # too small a target
     assert LZ4Codec.Decode(c1, np.zeros(u1 - 1, np.uint8), first) == -1
+    # the overload with offsets and lengths (LZ4Codec.cs:250-266), dictionary may be null when empty
+    big = np.full(u1 + 20, 0xCD, np.uint8)
+    assert LZ4Codec.Decode(c1, 0, c1.size, big, 10, u1, first, 0, first.size) == u1
+    assert big[10:10 + u1].tobytes() == want[u0:u0 + u1].tobytes() and (big[:10] == 0xCD).all() and (big[10 + u1:] == 0xCD).all()
+    assert LZ4Codec.Decode(c0, 0, c0.size, np.zeros(u0, np.uint8), 0, u0, None, 0, 0) == u0
 
 
 def test_dictionary_batch_matches_oracle(oracle):

@@ -115,3 +115,12 @@ def test_byte_balanced_ranges(world):
     assert byte_balanced_ranges([5], 3)[-1][1] == 1
     eq = byte_balanced_ranges([65536] * 4096, 8)
     assert all(b - a == 512 for a, b in eq)
+
+
+def test_enforce32_fails_loudly():
+    from k4os.compression.lz4_amd import LZ4Codec
+    assert LZ4Codec.Enforce32 is False
+    LZ4Codec.Enforce32 = False
+    with pytest.raises(NotImplementedError):
+        LZ4Codec.Enforce32 = True
+    assert LZ4Codec.Enforce32 is False
