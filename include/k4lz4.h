@@ -62,6 +62,8 @@ enum k4lz4_flags {
     K4LZ4_FLAG_NO_SPLIT = 16,     /* encode: do not run part of the batch on the global-memory-table kernel */
     K4LZ4_FLAG_ALLOW_COPY = 64,   /* encode: LZ4EncoderBase.Encode(allowCopy) -- a block that does not shrink is stored raw, outLen = -srcLen;
                                      outLen = 0 where the reference throws "target buffer too small" (Encoders/LZ4EncoderBase.cs:66-88) */
+    K4LZ4_FLAG_X32 = 128,         /* fast encode / pickle: the 32-bit engine's bytes (LZ4Codec.Enforce32, LZ4Codec.cs:14-25): inputs of
+                                     64 KiB and more are hashed with LZ4_hash4 instead of LZ4_hash5 (x32/LL32.tools.cs:141-148) */
     K4LZ4_FLAG_PARTIAL = 32       /* decode: LZ4Codec.PartialDecode -- stop once dstCap[i] bytes are produced (LZ4Codec.cs:123-173) */
 };
 
@@ -79,6 +81,9 @@ K4LZ4_API int k4lz4_synchronize(k4lz4_ctx *ctx, void *stream);
 
 /* LZ4Codec.MaximumOutputSize (LZ4Codec.cs:30-31) == LL.LZ4_compressBound (Engine/LL.tools.cs:38-40).
  * Pure host arithmetic. */
+/* LZ4Codec.Enforce32 (process-wide, like LL.Enforce32): every fast-level encode and pickle behaves as with K4LZ4_FLAG_X32 */
+K4LZ4_API void k4lz4_set_enforce32(int on);
+K4LZ4_API int k4lz4_get_enforce32(void);
 K4LZ4_API int k4lz4_compress_bound(int n);
 
 /* ---- per-block entry points: the Engine/LLxx.cs seam, same argument order and returns ------

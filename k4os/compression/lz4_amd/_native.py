@@ -18,6 +18,7 @@ FLAG_NO_REORDER = 4
 FLAG_REORDER = 8
 FLAG_NO_SPLIT = 16
 FLAG_PARTIAL = 32
+FLAG_X32 = 128
 FLAG_ALLOW_COPY = 64
 
 _u8p = C.c_void_p
@@ -32,6 +33,8 @@ SYMBOLS = {
     "k4lz4_last_error": (C.c_char_p, [C.c_void_p]),
     "k4lz4_ctx_device": (C.c_int, [C.c_void_p]),
     "k4lz4_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "k4lz4_set_enforce32": (None, [C.c_int]),
+    "k4lz4_get_enforce32": (C.c_int, []),
     "k4lz4_compress_bound": (C.c_int, [C.c_int]),
     "k4lz4_last_status": (C.c_int, []),
     "k4lz4_compress_fast": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, C.c_int]),

@@ -81,17 +81,17 @@ def _ptr(a: np.ndarray) -> int:
 
 
 class _LZ4CodecMeta(type):
-    """LZ4Codec.Enforce32 (LZ4Codec.cs:14-25) switches the reference to its 32-bit engine, whose fast encoder emits
-    different bytes for blocks of 64 KiB and more.  That arm is not built here; asking for it fails loudly."""
+    """LZ4Codec.Enforce32 (LZ4Codec.cs:14-25): process-wide switch to the reference's 32-bit engine.  In a 64-bit
+    process that engine differs from LL64 only in the fast encoder's hash for inputs of 64 KiB and more
+    (x32/LL32.tools.cs:141-148, x32/LL32.fast.cs:543-545); the switch is kept in libk4lz4 (k4lz4_set_enforce32)."""
 
     @property
     def Enforce32(cls) -> bool:
-        return False
+        return bool(_native.load_library().k4lz4_get_enforce32())
 
     @Enforce32.setter
     def Enforce32(cls, value: bool) -> None:
-        if value:
-            raise NotImplementedError("LZ4Codec.Enforce32: the 32-bit engine (LL32) is not implemented by the device path")
+        _native.load_library().k4lz4_set_enforce32(1 if value else 0)
 
 
 class LZ4Codec(metaclass=_LZ4CodecMeta):

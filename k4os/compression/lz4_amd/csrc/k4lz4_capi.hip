@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <new>
 #include <string>
@@ -77,6 +78,9 @@ int hip_fail(k4lz4_ctx *ctx, hipError_t e, const char *what)
     } while (0)
 
 enum Kind { KIND_ENCODE, KIND_DECODE, KIND_PICKLE, KIND_UNPICKLE };
+
+/* LL.Enforce32 (Engine/LL.tools.cs:19-27): a process-wide switch in the reference, so here too */
+std::atomic<int> g_enforce32{0};
 
 int check_level(k4lz4_ctx *ctx, int level)
 {
@@ -191,7 +195,8 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
         k4::BatchArgs a{};
         a.src = src; a.srcOff = srcOff + first; a.srcLen = srcLen + first;
         a.dst = dst; a.dstOff = dstOff + first; a.dstCap = dstCap + first;
-        a.outLen = outLen + first; a.n = cnt; a.level = level; a.accel = ctx->accel; a.flags = flags;
+        a.outLen = outLen + first; a.n = cnt; a.level = level; a.accel = ctx->accel;
+        a.flags = flags | (g_enforce32.load(std::memory_order_relaxed) ? K4LZ4_FLAG_X32 : 0);
         a.prof = ctx->prof ? ctx->prof + k4::PROF_STRIDE * first : nullptr;
         if (dd && dd->dict) {
             a.dict = dd->dict; a.dictOff = dd->off + first; a.dictLen = dd->len + first;
@@ -433,6 +438,9 @@ int single(Kind kind, const uint8_t *src, uint8_t *dst, int srcLen, int dstCap, 
 extern "C" {
 
 int k4lz4_version(void) { return K4LZ4_VERSION; }
+
+void k4lz4_set_enforce32(int on) { g_enforce32.store(on ? 1 : 0, std::memory_order_relaxed); }
+int k4lz4_get_enforce32(void) { return g_enforce32.load(std::memory_order_relaxed); }
 
 int k4lz4_device_count(void)
 {

@@ -32,6 +32,7 @@ enum : int {
 enum : int {
     FLAG_RAW_RETURN = 1,  /* outLen = LLxx-level return instead of the LZ4Codec mapping */
     FLAG_PICKLE_WRITER = 2,
+    FLAG_X32 = 128,        /* fast encoder: LZ4Codec.Enforce32 -- the 32-bit engine's hash for inputs of 64 KiB and more */
     FLAG_PARTIAL = 32,     /* decode: LZ4_decompress_safe_partial semantics, dstCap = target size */
 };
 

@@ -24,9 +24,10 @@
 
 namespace k4 {
 
-template <bool BYU16> struct FastTable;
+/* TYPE 0: byU32 + hash5 (LL64), 1: byU16 + hash4, 2: byU32 + hash4 (LL32 in a 64-bit process, LZ4Codec.Enforce32) */
+template <int TYPE> struct FastTable;
 
-template <> struct FastTable<true> {   /* byU16: 8192 x u16, hash4 >> 19 (LL.tools.cs:46-51) */
+template <> struct FastTable<1> {   /* byU16: 8192 x u16, hash4 >> 19 (LL.tools.cs:46-51) */
     uint16_t *t;
     __device__ __forceinline__ static uint32_t hash(const uint8_t *p) { return (ld32u(p) * 2654435761u) >> (32 - 13); }
     /* same hash from bytes already in registers: seq = bytes p..p+3, next = bytes p+4..p+11 */
@@ -34,7 +35,7 @@ template <> struct FastTable<true> {   /* byU16: 8192 x u16, hash4 >> 19 (LL.too
     __device__ __forceinline__ uint32_t get(uint32_t h) const { return t[h]; }
     __device__ __forceinline__ void put(uint32_t h, uint32_t pos) const { t[h] = (uint16_t)pos; }
 };
-template <> struct FastTable<false> {  /* byU32: 4096 x u32, hash5 (LL.tools.cs:53-58, LL64.tools.cs:135-143) */
+template <> struct FastTable<0> {  /* byU32: 4096 x u32, hash5 (LL.tools.cs:53-58, LL64.tools.cs:135-143) */
     uint32_t *t;
     __device__ __forceinline__ static uint32_t hash(const uint8_t *p)
     {
@@ -44,6 +45,13 @@ template <> struct FastTable<false> {  /* byU32: 4096 x u32, hash5 (LL.tools.cs:
     {
         return (uint32_t)((((next << 32) | seq) << 24) * 889523592379ull >> (64 - 12));
     }
+    __device__ __forceinline__ uint32_t get(uint32_t h) const { return t[h]; }
+    __device__ __forceinline__ void put(uint32_t h, uint32_t pos) const { t[h] = pos; }
+};
+template <> struct FastTable<2> {  /* byU32: 4096 x u32, hash4 >> 20: x32/LL32.tools.cs:141-148 has no hash5 arm; x32/LL32.fast.cs:543-545 */
+    uint32_t *t;
+    __device__ __forceinline__ static uint32_t hash(const uint8_t *p) { return (ld32u(p) * 2654435761u) >> (32 - 12); }
+    __device__ __forceinline__ static uint32_t hash_of(uint32_t seq, uint64_t) { return (seq * 2654435761u) >> (32 - 12); }
     __device__ __forceinline__ uint32_t get(uint32_t h) const { return t[h]; }
     __device__ __forceinline__ void put(uint32_t h, uint32_t pos) const { t[h] = pos; }
 };
@@ -161,7 +169,7 @@ __device__ __forceinline__ uint32_t extension_info(uint32_t a_pre, uint64_t a_ne
  * After 64 misses the schedule's step grows (LL64.fast.cs:156-172); those rounds probe the strided
  * positions and stop at their first sequence.
  */
-template <bool BYU16, bool PROF = false>
+template <bool BYU16, bool PROF = false, bool X32 = false>
 __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
                                                  uint32_t accel, uint32_t *ldsw, int lane, unsigned long long *pc = nullptr,
                                                  bool dry = false, uint32_t *seq_count = nullptr, uint32_t *gtab = nullptr)
@@ -175,7 +183,8 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
     const bool limited = dst_cap < compress_bound(src_len);         /* :524 */
     const uint64_t olimit = (uint64_t)(dst_cap < 0 ? 0 : dst_cap);
     const uint32_t U = (uint32_t)src_len;
-    FastTable<BYU16> tab;
+    typedef FastTable<BYU16 ? 1 : (X32 ? 2 : 0)> Table;
+    Table tab;
     /* the table normally lives in LDS; `gtab` (16 KiB of global memory) lets more blocks run per CU */
     uint32_t *const tabmem = gtab ? gtab : ldsw;
     tab.t = (decltype(tab.t))tabmem;
@@ -193,7 +202,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
         const uint32_t mflimit_plus_one = U - MFLIMIT + 1;
         const uint32_t matchlimit = U - LASTLITERALS;
 
-        if (lane == 0) tab.put(FastTable<BYU16>::hash(src), 0);     /* :119-122 */
+        if (lane == 0) tab.put(Table::hash(src), 0);     /* :119-122 */
         uint32_t ip = 1;       /* cursor of a fresh round */
         uint32_t sbase = 1;    /* where the current search loop started (:466) */
         uint32_t jbase = 0;    /* probes of the current search already done (0: fresh round) */
@@ -236,14 +245,14 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             const bool valid = valid_n;
             const Around pa = pa_n;
             if (shift) {
-                const uint32_t h2 = FastTable<BYU16>::hash(src + ip - 2);
+                const uint32_t h2 = Table::hash(src + ip - 2);
                 if (lane == 0) tab.put(h2, ip - 2u);                /* :394 */
             }
             wave_sync();
             if (PROF) { n_round++; }
             uint32_t h = 0, cand = 0;
             if (valid) {
-                h = FastTable<BYU16>::hash_of(pa.seq, pa.next);
+                h = Table::hash_of(pa.seq, pa.next);
                 cand = tab.get(h);
                 scr[h & scr_mask] = (uint8_t)lane;
             }
@@ -557,10 +566,11 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
 
 /* LL64.LZ4_compress_fast (LL64.fast.cs:517-576): table type by input size */
 __device__ __forceinline__ int compress_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
-                                                   int accel, uint32_t *ldsw, int lane, uint32_t *gtab = nullptr)
+                                                   int accel, uint32_t *ldsw, int lane, uint32_t *gtab = nullptr, bool x32 = false)
 {
     const uint32_t a = accel < 1 ? 1u : (accel > 65536 ? 65536u : (uint32_t)accel);
     if (src_len < LIMIT_64K) return encode_fast_block<true>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
+    if (x32) return encode_fast_block<false, false, true>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
     return encode_fast_block<false>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
 }
 
@@ -637,7 +647,7 @@ __global__ __launch_bounds__(64) void k4_encode_fast_kernel(BatchArgs a)
     const uint8_t *src = a.src + a.srcOff[b];
     uint8_t *dst = a.dst + a.dstOff[b];
     int ret = 0;
-    if (src_len > 0 || (a.flags & FLAG_RAW_RETURN)) ret = compress_fast_block(src, src_len, dst, cap < 0 ? 0 : cap, a.accel, tab, lane);
+    if (src_len > 0 || (a.flags & FLAG_RAW_RETURN)) ret = compress_fast_block(src, src_len, dst, cap < 0 ? 0 : cap, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0);
     if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
 }
 
@@ -655,7 +665,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     int ret = 0;
     if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
         ret = compress_fast_block(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.accel, stage, lane,
-                                  a.gtab + 4096ull * (unsigned long long)blockIdx.x);
+                                  a.gtab + 4096ull * (unsigned long long)blockIdx.x, (a.flags & FLAG_X32) != 0);
     if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
 }
 

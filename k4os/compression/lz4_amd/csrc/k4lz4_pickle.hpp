@@ -82,7 +82,7 @@ __device__ __forceinline__ int pickle_block(const uint8_t *src, int U, uint8_t *
     if (U <= 0) return 0;                                   /* pickle.cs:53-54 */
     if (cap < 1 + 4 + U) return -1;
     int C = 0;
-    if (U > 1) C = compress_fast_block(src, U, dst + 5, U - 1, 1, tabw, lane);
+    if (U > 1) C = compress_fast_block(src, U, dst + 5, U - 1, 1, tabw, lane, nullptr, (flags & FLAG_X32) != 0);
     return pickle_finish(src, U, dst, C, flags, lane);
 }
 

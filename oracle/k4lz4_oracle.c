@@ -69,6 +69,9 @@ K4O_API int k4o_compress_bound(int n)
 
 /* LL.tools.cs:46-51 (hash4, byU16 => 13 bits) */
 static inline uint32_t hash_seq4_u16(uint32_t seq) { return (seq * 2654435761u) >> (32 - 13); }
+/* LL32 (Enforce32): LZ4_hashPosition has no hash5 arm (x32/LL32.tools.cs:141-148), so a byU32 table is indexed by
+ * LZ4_hash4 with LZ4_HASHLOG = 12 bits (LL.tools.cs:46-51) */
+static inline uint32_t hash_seq4_u32(uint32_t seq) { return (seq * 2654435761u) >> (32 - 12); }
 /* LL.tools.cs:53-58 (hash5 on 64-bit, byU32 => 12 bits), LL64.tools.cs:135-143 */
 static inline uint32_t hash_seq5_u32(uint64_t seq)
 {
@@ -100,7 +103,7 @@ typedef struct {
  * Offsets (not pointers) are used for all bounds arithmetic.
  */
 static int fast_generic(fast_table_t *tbl, const uint8_t *src, uint8_t *dst, int src_len,
-                        int dst_cap, int limited, int by_u16, int accel)
+                        int dst_cap, int limited, int by_u16, int accel, int x32)
 {
     uint16_t *t16 = (uint16_t *)tbl->words;
     uint32_t *t32 = tbl->words;
@@ -115,7 +118,7 @@ static int fast_generic(fast_table_t *tbl, const uint8_t *src, uint8_t *dst, int
     if (by_u16 && src_len >= LIMIT_64K) return 0;                        /* :92 */
     if (src_len < LZ4_MIN_LENGTH) goto last_literals;                    /* :117 */
 
-#define HASH_AT(pos) (by_u16 ? hash_seq4_u16(rd32(src + (pos))) : hash_seq5_u32(rd64(src + (pos))))
+#define HASH_AT(pos) (by_u16 ? hash_seq4_u16(rd32(src + (pos))) : x32 ? hash_seq4_u32(rd32(src + (pos))) : hash_seq5_u32(rd64(src + (pos))))
 #define TGET(h) (by_u16 ? (uint32_t)t16[h] : t32[h])
 #define TPUT(h, v) do { if (by_u16) t16[h] = (uint16_t)(v); else t32[h] = (uint32_t)(v); } while (0)
 
@@ -244,7 +247,20 @@ K4O_API int k4o_compress_fast(const uint8_t *src, uint8_t *dst, int src_len, int
     if (accel < 1) accel = 1;
     int limited = !(dst_cap >= k4o_compress_bound(src_len));
     int by_u16 = src_len < LIMIT_64K;
-    return fast_generic(&tbl, src, dst, src_len, limited ? dst_cap : 0, limited, by_u16, accel);
+    return fast_generic(&tbl, src, dst, src_len, limited ? dst_cap : 0, limited, by_u16, accel, 0);
+}
+
+/* LL32.LZ4_compress_fast as LZ4Codec.Enforce32 = true runs it in a 64-bit process (x32/LL32.fast.cs:517-576): the table
+ * type for >= 64 KiB inputs is still byU32 (`sizeof(void*) < 8` is false, :543-545), only the hash differs.
+ * PARITY UNPINNED: no 32-bit lz4 build is available here to compare with. */
+K4O_API int k4o_compress_fast_x32(const uint8_t *src, uint8_t *dst, int src_len, int dst_cap, int accel)
+{
+    fast_table_t tbl;
+    memset(&tbl, 0, sizeof tbl);
+    if (accel < 1) accel = 1;
+    int limited = !(dst_cap >= k4o_compress_bound(src_len));
+    int by_u16 = src_len < LIMIT_64K;
+    return fast_generic(&tbl, src, dst, src_len, limited ? dst_cap : 0, limited, by_u16, accel, 1);
 }
 
 /* ------------------------------------------------------------------------------------

@@ -73,6 +73,16 @@ class Oracle:
         ret = self.lib.k4o_compress_hc(_ptr(src if src.size else np.zeros(1, np.uint8)), _ptr(dst), src.size, cap, level)
         return ret, dst[:cap]
 
+    def compress_fast_x32(self, src: np.ndarray, cap: int | None = None, accel: int = 1):
+        """LL32.LZ4_compress_fast as LZ4Codec.Enforce32 runs it in a 64-bit process (parity unpinned, see the C source)"""
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        if cap is None:
+            cap = self.compress_bound(src.size)
+        dst = np.full(max(cap, 1), 0xCD, dtype=np.uint8)
+        self.lib.k4o_compress_fast_x32.argtypes = self.lib.k4o_compress_fast.argtypes
+        ret = self.lib.k4o_compress_fast_x32(_ptr(src if src.size else np.zeros(1, np.uint8)), _ptr(dst), src.size, cap, accel)
+        return ret, dst[:cap]
+
     def decompress_safe(self, src: np.ndarray, cap: int, fill: int = 0xCD):
         src = np.ascontiguousarray(src, dtype=np.uint8)
         dst = np.full(max(cap, 1), fill, dtype=np.uint8)

@@ -474,3 +474,24 @@ def test_encode_random_stress(emu, oracle):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.run(2, 5, oracle, emu, verbose=False)
+
+
+def test_encode_x32_arm_matches_oracle(emu, oracle):
+    """LZ4Codec.Enforce32 (K4LZ4_FLAG_X32 = 128): inputs of 64 KiB and more are hashed with LZ4_hash4 (12 bits) into
+    the byU32 table (x32/LL32.tools.cs:141-148, x32/LL32.fast.cs:543-545); smaller inputs are unaffected"""
+    blocks = [corpus.class_bytes("dickens", 65547, 1), corpus.class_bytes("xml", 100000, 2), corpus.lorem(200000),
+              corpus.class_bytes("samba", 65546, 3), corpus.lorem(5000), corpus.random_bytes(70000, 4)]
+    src, soff, slen = pack(blocks)
+    caps = [oracle.compress_bound(b.size) for b in blocks]
+    dst, doff, dcap = arena(caps)
+    out = emu.encode_batch(src, soff, slen, dst, doff, dcap, flags=128)
+    differs = 0
+    for i, b in enumerate(blocks):
+        r, w = oracle.compress_fast_x32(b)
+        assert out[i] == r and dst[int(doff[i]):int(doff[i]) + r].tobytes() == w[:r].tobytes(), i
+        n, back = oracle.decompress_safe(w[:r], b.size)
+        assert n == b.size and back[:n].tobytes() == b.tobytes()
+        differs += w[:r].tobytes() != oracle.encode(b)
+        if b.size < 65547:
+            assert w[:r].tobytes() == oracle.encode(b)
+    assert differs >= 3            # the large compressible blocks really take the other hash

@@ -498,3 +498,24 @@ def test_dictionary_batch_matches_oracle(oracle):
         assert out[i] == n, (i, out[i], n)
         if n > 0:
             assert dst[int(doff[i]):int(doff[i]) + n].tobytes() == ref[:n].tobytes()
+
+
+def test_enforce32_switch(oracle):
+    """LZ4Codec.Enforce32 = true: the 32-bit engine's bytes for blocks of 64 KiB and more, everything else unchanged;
+    the switch is process-wide like the reference's (LL.Enforce32) and is restored here"""
+    big = [corpus.class_bytes("dickens", 70000, 1), corpus.lorem(150000)]
+    small = corpus.class_bytes("dickens", 60000, 2)
+    assert LZ4Codec.Enforce32 is False
+    try:
+        LZ4Codec.Enforce32 = True
+        enc = LZ4Codec.EncodeBatch(big + [small])
+        for b, e in zip(big, enc):
+            r, w = oracle.compress_fast_x32(b)
+            assert e == w[:r].tobytes() and e != oracle.encode(b)
+        assert enc[2] == oracle.encode(small)
+        assert LZ4Codec.DecodeBatch(enc, [b.size for b in big] + [small.size]) == [b.tobytes() for b in big] + [small.tobytes()]
+        p = LZ4Pickler.Pickle(big[0])
+        assert LZ4Pickler.Unpickle(p) == big[0].tobytes()
+    finally:
+        LZ4Codec.Enforce32 = False
+    assert LZ4Codec.EncodeBatch(big)[0] == oracle.encode(big[0])

@@ -117,10 +117,10 @@ def test_byte_balanced_ranges(world):
     assert all(b - a == 512 for a, b in eq)
 
 
-def test_enforce32_fails_loudly():
+def test_enforce32_switch_round_trips():
     from k4os.compression.lz4_amd import LZ4Codec
     assert LZ4Codec.Enforce32 is False
+    LZ4Codec.Enforce32 = True
+    assert LZ4Codec.Enforce32 is True
     LZ4Codec.Enforce32 = False
-    with pytest.raises(NotImplementedError):
-        LZ4Codec.Enforce32 = True
     assert LZ4Codec.Enforce32 is False
