@@ -466,10 +466,10 @@ def test_decode_with_dictionary_issue64_and_synthetic(emu, oracle):
 
 
 def test_encode_random_stress(emu, oracle):
-    """scripts/emu_stress_encode.py (two rounds of it): inputs built to provoke equal hashes inside one
+    """tests/tools/emu_stress_encode.py (two rounds of it): inputs built to provoke equal hashes inside one
     64-position window, matches ending at window edges, long literal runs, limited output, accel > 1"""
     import importlib.util
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "emu_stress_encode.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "emu_stress_encode.py")
     spec = importlib.util.spec_from_file_location("emu_stress_encode", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

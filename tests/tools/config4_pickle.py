@@ -6,7 +6,7 @@ sample; sizes for all."""
 import json, os, sys, time
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from k4os.compression.lz4_amd import corpus
 from k4os.compression.lz4_amd.device import DeviceBatch, DeviceCodec

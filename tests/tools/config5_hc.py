@@ -4,7 +4,7 @@ equal the oracle's exactly) and GiB/s next to the oracle HC on the host cores.""
 import json, os, sys, time
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from k4os.compression.lz4_amd import LZ4Codec, LZ4Level, corpus, make_arena
 from k4os.compression.lz4_amd.device import DeviceBatch, DeviceCodec

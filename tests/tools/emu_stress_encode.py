@@ -1,10 +1,10 @@
 #!/usr/bin/env python
 """Randomised stress of the fast encoder kernel under the host wave emulator against the oracle:
 inputs built to provoke equal hashes inside one 64-position window, matches ending near window
-edges, long literal runs, limited output.  Usage: scripts/emu_stress_encode.py [rounds] [seed]"""
+edges, long literal runs, limited output.  Usage: tests/tools/emu_stress_encode.py [rounds] [seed]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle_lib import Oracle
 from emu_lib import Emu

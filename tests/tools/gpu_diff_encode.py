@@ -2,7 +2,7 @@
 """GPU vs oracle per-block diff of the fast encoder on the bench workload, per dispatch variant."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle_lib import Oracle
 from k4os.compression.lz4_amd import LZ4Codec, corpus, make_arena
