@@ -218,7 +218,7 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
                  * (front of the dispatch order) take those slots; the others are encoded at the same
                  * time on a second queue by the global-memory-table variant of the kernel. */
                 /* measured on MI355X (profiles/r02_split_sweep.txt): best when the LDS-table kernel gets one full
-                 * residency of the chip (8 blocks of 18 KiB per CU) or about 48 % of a larger batch; one block more
+                 * residency of the chip (8 blocks per CU) or about 48 % of a larger batch; one block more
                  * than a residency starts a second pass and costs 20 % */
                 const char *pct_env = getenv("K4LZ4_SPLIT_PCT");
                 const int64_t lds_slots = 8 * (int64_t)ctx->cu_count;

@@ -86,8 +86,8 @@ __device__ __forceinline__ uint32_t wave_count(const uint8_t *a, const uint8_t *
     }
 }
 
-constexpr int ENCODE_SCRATCH_BYTES = 2048;     /* same-hash detection: one byte per slot */
-constexpr int ENCODE_SCRATCH_BYTES_GTAB = 512; /* global-table variant: fewer slots (more false alarms), so that LDS never limits it */
+constexpr int ENCODE_SCRATCH_BYTES = 1024;     /* same-hash detection: one bit per hash value (8192 of them) */
+constexpr int ENCODE_SCRATCH_BYTES_GTAB = 1024;
 constexpr int ENCODE_LDS_DWORDS = 4096 + ENCODE_SCRATCH_BYTES / 4;   /* hash table + detection slots */
 
 /* length field tail: `rem` encoded as 255-run + final byte (LL64.fast.cs:262-272,:365-381,:484-495) */
@@ -136,8 +136,8 @@ __device__ __forceinline__ uint32_t extension_info(uint32_t a_pre, uint64_t a_ne
 
 /*
  * LL64.LZ4_compress_generic for one block.  `ldsw`: ENCODE_LDS_DWORDS dwords of LDS owned by this
- * wave (16 KiB hash table, zeroed here = LZ4_initStream, LL.tools.cs:235-239; then the detection
- * slots).  Returns bytes written, 0 when the output does not fit.
+ * wave (16 KiB hash table, zeroed here = LZ4_initStream, LL.tools.cs:235-239; then the 1 KiB bit set
+ * of the same-hash detection).  Returns bytes written, 0 when the output does not fit.
  *
  * One round looks at 64 probe positions -- normally the 64 consecutive positions from the cursor --
  * and resolves EVERY sequence that starts inside that window, not just the first:
@@ -146,8 +146,9 @@ __device__ __forceinline__ uint32_t extension_info(uint32_t a_pre, uint64_t a_ne
  *            the hashes up in the table as it stood at the start of the round; load the 16 bytes
  *            around the 64 candidates; per lane: would this position hit, how far does the match
  *            extend (up to 4 back / 12 forward from registers).
- *   groups   lanes whose hashes collide inside the window are found through one byte-wide LDS slot
- *            per hash; each such lane keeps the bit mask of its group.  A lane's candidate is the
+ *   groups   lanes whose hashes collide inside the window are found through one LDS bit per hash
+ *            value (atomic OR: the old value tells a lane that another one was there first); each
+ *            such lane keeps the bit mask of its group.  A lane's candidate is the
  *            highest visited-or-future lane of its group below it (its bytes come from that lane's
  *            registers), else the table entry.
  *   hops     wave-uniform chain over the window, one v_readlane per sequence: first stop at or
@@ -188,11 +189,11 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
     /* the table normally lives in LDS; `gtab` (16 KiB of global memory) lets more blocks run per CU */
     uint32_t *const tabmem = gtab ? gtab : ldsw;
     tab.t = (decltype(tab.t))tabmem;
-    uint8_t *const scr = (uint8_t *)(gtab ? ldsw : ldsw + 4096);
-    const uint32_t scr_mask = gtab ? (uint32_t)(ENCODE_SCRATCH_BYTES_GTAB - 1) : (uint32_t)(ENCODE_SCRATCH_BYTES - 1);
+    uint32_t *const seen = gtab ? ldsw : ldsw + 4096;       /* bit h: a lane of the current window hashed to h */
     const unsigned long long me = 1ull << lane, below_me = me - 1ull;
 
     for (int k = lane; k < 1024; k += 64) ((uint4 *)tabmem)[k] = make_uint4(0u, 0u, 0u, 0u);
+    for (int k = lane; k < ENCODE_SCRATCH_BYTES / 4; k += 64) seen[k] = 0u;
     wave_sync();
 
     uint32_t anchor = 0;
@@ -251,14 +252,13 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             wave_sync();
             if (PROF) { n_round++; }
             uint32_t h = 0, cand = 0;
+            bool flagged = false;              /* another lane of this window has the same hash (at least one lane of every group sees it) */
             if (valid) {
                 h = Table::hash_of(pa.seq, pa.next);
                 cand = tab.get(h);
-                scr[h & scr_mask] = (uint8_t)lane;
+                flagged = ((atomicOr(&seen[h >> 5], 1u << (h & 31u)) >> (h & 31u)) & 1u) != 0u;
             }
             const Around ca = load_around(src, cand);
-            wave_sync();
-            const bool flagged = valid && scr[h & scr_mask] != (uint8_t)lane;
             const bool hit_tab = valid && (BYU16 || cand + (uint32_t)DISTANCE_MAX >= pos) && ca.seq == pa.seq;
             const uint32_t info = extension_info(pa.pre, pa.next, pa.pre_ok, ca.pre, ca.next, ca.pre_ok, matchlimit - (pos + MINMATCH));
 
@@ -266,6 +266,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             unsigned long long G = me;
             {
                 unsigned long long fl = __ballot(flagged);
+                if (valid) seen[h >> 5] = 0u;      /* every lane has recorded its hash by now: wipe the words this window touched */
                 while (fl) {
                     const int j = ctz64(fl);
                     const uint32_t hj = __builtin_amdgcn_readlane(h, j);
