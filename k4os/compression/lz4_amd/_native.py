@@ -75,6 +75,36 @@ _lib = None
 _lib_lock = threading.Lock()
 
 
+def _share_hip_runtime():
+    """PyTorch-ROCm wheels carry their own libamdhip64.so.  Two HIP runtimes in one process do not both
+    see the GPU, and which one a process gets would depend on whether torch or libk4lz4 was imported
+    first.  Map torch's copy (if there is one) before libk4lz4.so so that its NEEDED libamdhip64.so.7
+    binds to it, and a later `import torch` finds the same runtime.  No torch import, no GPU touch."""
+    import importlib.util
+    if any("libamdhip64" in line for line in _mapped_objects()):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass        # fall back to the system runtime named by libk4lz4.so's RUNPATH
+
+
+def _mapped_objects():
+    try:
+        with open("/proc/self/maps") as f:
+            return f.readlines()
+    except OSError:
+        return []
+
+
 def load_library(path: str | None = None):
     """dlopen libk4lz4.so and type every declared symbol.  Does not touch the GPU."""
     global _lib
@@ -86,6 +116,7 @@ def load_library(path: str | None = None):
             raise NativeLibraryError(
                 f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        _share_hip_runtime()
         lib = C.CDLL(p)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol

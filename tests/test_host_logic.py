@@ -124,3 +124,15 @@ def test_enforce32_switch_round_trips():
     assert LZ4Codec.Enforce32 is True
     LZ4Codec.Enforce32 = False
     assert LZ4Codec.Enforce32 is False
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """libk4lz4.so and torch must bind the same libamdhip64: with two copies mapped only the first sees the GPU."""
+    import subprocess, sys
+    code = (
+        "from k4os.compression.lz4_amd import _native; _native.load_library(); import torch;"
+        "print(len({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}))"
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(__import__('pathlib').Path(__file__).resolve().parents[1]))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "1"
