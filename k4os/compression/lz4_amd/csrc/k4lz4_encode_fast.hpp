@@ -134,6 +134,46 @@ __device__ __forceinline__ uint32_t extension_info(uint32_t a_pre, uint64_t a_ne
     return c8 | (nb << 4) | ((e == 8u && fwd_max > 8u) ? 0x100u : 0u) | (ok ? 0x200u : 0u);
 }
 
+/* The serial part of a round: from cursor lane q follow stop -> end of its match -> next stop, until a stop whose
+ * word carries one of the 0xf40 flags (hit needs attention / window left / invalid lane) or no stop is left
+ * (stop == 0).  Written out in scalar ISA: the compiler's version of this two-exit uniform loop carries its exit
+ * reasons in extra mask registers and takes 18 instructions and three branches per hop; this takes 9 and two. */
+__device__ __forceinline__ void hop_chain(unsigned long long hmx, uint32_t hopv, uint32_t &q, unsigned long long &hits,
+                                          int &f, uint32_t &hv, unsigned long long &stop)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t t;
+    asm volatile(
+        "s_lshl_b64 %[stop], -1, %[q]\n\t"
+        "s_and_b64 %[stop], %[stop], %[hmx]\n\t"
+        "s_cbranch_scc0 .Lhop_end%=\n"
+        ".Lhop_next%=:\n\t"
+        "s_ff1_i32_b64 %[f], %[stop]\n\t"
+        "v_readlane_b32 %[hv], %[hopv], %[f]\n\t"
+        "s_bitset1_b64 %[hits], %[f]\n\t"
+        "s_and_b32 %[t], %[hv], 0xf40\n\t"
+        "s_cbranch_scc1 .Lhop_end%=\n\t"
+        "s_and_b32 %[q], %[hv], 63\n\t"
+        "s_lshl_b64 %[stop], -1, %[q]\n\t"
+        "s_and_b64 %[stop], %[stop], %[hmx]\n\t"
+        "s_cbranch_scc1 .Lhop_next%=\n"
+        ".Lhop_end%=:"
+        : [stop] "=&s"(stop), [q] "+s"(q), [hits] "+s"(hits), [f] "+s"(f), [hv] "+s"(hv), [t] "=&s"(t)
+        : [hmx] "s"(hmx), [hopv] "v"(hopv)
+        : "scc");
+#else
+    for (;;) {
+        stop = hmx & (~0ull << q);
+        if (!stop) break;
+        f = ctz64(stop);
+        hv = readlane_u32(hopv, f);
+        hits |= 1ull << f;
+        if (hv & 0xf40u) break;
+        q = hv & 63u;
+    }
+#endif
+}
+
 /*
  * LL64.LZ4_compress_generic for one block.  `ldsw`: ENCODE_LDS_DWORDS dwords of LDS owned by this
  * wave (16 KiB hash table, zeroed here = LZ4_initStream, LL.tools.cs:235-239; then the 1 KiB bit set
@@ -359,15 +399,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 uint32_t hv = 0;
                 int f = 0;
                 unsigned long long stop;
-                for (;;) {
-                    stop = hmx & (~0ull << q);
-                    if (!stop) break;
-                    f = ctz64(stop);
-                    hv = readlane_u32(hopv, f);
-                    hits |= 1ull << f;
-                    if (hv & 0xf40u) break;
-                    q = hv & 63u;
-                }
+                hop_chain(hmx, hopv, q, hits, f, hv, stop);
                 if (!stop || (hv & 0x800u)) {
                     hits &= ~inv_m;
                     if (hits) anchor = ip0 + q;
@@ -396,15 +428,18 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                     if (PROF) n_dup++;
                     derive(hits);
                     const bool lost = j1 >= 0 && ((skipped >> (j1 & 63)) & 1ull) != 0ull;
-                    if (!general && (__ballot(lost) & multi_m)) general = true;
-                    if (general) {
-                        candidates();
-                    } else {
-                        chit = lost ? hit_tab : hit1;
-                        cpos = lost ? cand : pos1;
-                        cinfo = lost ? info : info1;
+                    const unsigned long long lost_m = __ballot(lost) & (~0ull << q);   /* lanes behind the cursor no longer matter */
+                    if (lost_m) {
+                        if (!general && (lost_m & multi_m)) general = true;
+                        if (general) {
+                            candidates();
+                        } else {
+                            chit = lost ? hit_tab : hit1;
+                            cpos = lost ? cand : pos1;
+                            cinfo = lost ? info : info1;
+                        }
+                        publish();
                     }
-                    publish();
                     if (PROF) t_rec += prof_now<PROF>() - tr0;
                 }
             }
