@@ -188,6 +188,38 @@ __device__ __forceinline__ void lane_store32(uint8_t *d, const uint64_t (&v)[4],
     }
 }
 
+/* A run of up to 32 bytes held by one lane as its full 8-byte chunks plus a word with its LAST 8 bytes
+ * (runs under 8 bytes: v[0] only).  Storing it then needs no byte-granular tail: the last word is written over
+ * the end of the last full chunk (the same bytes twice), a 4..7 byte run as two overlapping dwords.  Nothing
+ * outside [d, d + len) is touched.  `readable` = bytes that may be read from s on (>= len). */
+struct LaneRun { uint64_t v[4]; uint64_t last; };
+
+__device__ __forceinline__ void lane_run_load(LaneRun &r, const uint8_t *s, uint32_t len, uint32_t readable)
+{
+    r.v[0] = 0;
+    if (len != 0u) r.v[0] = readable >= 8u ? ld64u(s) : load_tail(s, readable);
+#pragma unroll
+    for (uint32_t c = 1; c < 4u; c++) r.v[c] = 8u * c + 8u <= len ? ld64u(s + 8u * c) : 0ull;
+    r.last = len >= 8u ? ld64u(s + len - 8u) : 0ull;
+}
+
+__device__ __forceinline__ void lane_run_store(uint8_t *d, const LaneRun &r, uint32_t len)
+{
+    if (len >= 8u) {
+        ((U64u *)d)->v = r.v[0];
+        if (len >= 16u) ((U64u *)(d + 8))->v = r.v[1];
+        if (len >= 24u) ((U64u *)(d + 16))->v = r.v[2];
+        if (len >= 32u) ((U64u *)(d + 24))->v = r.v[3];
+        ((U64u *)(d + len - 8u))->v = r.last;
+    } else if (len >= 4u) {
+        ((U32u *)d)->v = (uint32_t)r.v[0];
+        ((U32u *)(d + len - 4u))->v = (uint32_t)(r.v[0] >> (8u * (len - 4u)));
+    } else {
+        if (len & 2u) ((U16u *)d)->v = (uint16_t)r.v[0];
+        if (len & 1u) d[len - 1u] = (uint8_t)(r.v[0] >> (8u * (len - 1u)));
+    }
+}
+
 /* Orders this wave's LDS accesses only (LDS executes a wave's accesses in order; this pins the
  * compiler) -- unlike wave_sync() it never waits for global stores to be acknowledged. */
 __device__ __forceinline__ void lds_sync()

@@ -385,9 +385,9 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             uint8_t *stg = (uint8_t *)(d_mlen + 64);
             const uint32_t mdst = v_out + v_llen, mend = mdst + v_mlen, msrc = mdst - v_moff;
             const uint32_t before = has_m && msrc < o0 ? (o0 - msrc < v_mlen ? o0 - msrc : v_mlen) : 0u;   /* source bytes before the batch */
-            uint64_t L[4], M[4];
-            lane_load32(L, in + v_lpos, mine ? v_llen : 0u, (uint32_t)src_size - v_lpos);
-            lane_load32(M, out + msrc, before, (uint32_t)out_size - msrc);
+            LaneRun L, M;
+            lane_run_load(L, in + v_lpos, mine ? v_llen : 0u, (uint32_t)src_size - v_lpos);
+            lane_run_load(M, out + msrc, before, (uint32_t)out_size - msrc);
             /* dependencies among the matches of the batch, as below */
             const uint32_t send = msrc + v_mlen < mdst ? msrc + v_mlen : mdst;
             lds_sync();
@@ -404,8 +404,8 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             unsigned long long deps = 0;
             const bool later = has_m && before < v_mlen;            /* some source bytes are this batch's output */
             if (later && lo < hi_c) deps = ((hi_c >= 64u ? 0ull : (1ull << hi_c)) - 1ull) & ~((1ull << lo) - 1ull);
-            if (mine && v_llen != 0u) lane_store32(stg + (v_out - o0), L, v_llen);
-            if (before) lane_store32(stg + (mdst - o0), M, before);
+            if (mine && v_llen != 0u) lane_run_store(stg + (v_out - o0), L, v_llen);
+            if (before) lane_run_store(stg + (mdst - o0), M, before);
             if (PROF) t2 = prof_now<PROF>();
             /* the part of every match that comes out of the stage: stage[src_s ..) -> stage[dst_s ..), `n` bytes */
             const uint32_t n = later ? v_mlen - before : 0u;
@@ -417,10 +417,9 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 const unsigned long long rmask = __ballot(ready);
                 lds_sync();
                 if (ready) {
-                    uint64_t R[4];
-#pragma unroll
-                    for (uint32_t c = 0; c < 4u; c++) R[c] = 8u * c < n ? ld64u(stg + src_s + 8u * c) : 0ull;
-                    lane_store32(stg + dst_s, R, n);
+                    LaneRun R;
+                    lane_run_load(R, stg + src_s, n, 8u);           /* the stage has slack behind it */
+                    lane_run_store(stg + dst_s, R, n);
                 }
                 pend &= ~rmask;
             }
