@@ -160,34 +160,6 @@ __device__ __forceinline__ uint64_t load_tail(const uint8_t *p, uint32_t avail)
     return v;
 }
 
-/* the load half / store half of lane_copy32, for copies whose loads are issued well before the stores
- * and whose result goes to two places (global memory and an LDS stage) */
-__device__ __forceinline__ void lane_load32(uint64_t (&v)[4], const uint8_t *s, uint32_t len, uint32_t readable)
-{
-#pragma unroll
-    for (uint32_t c = 0; c < 4u; c++) {
-        v[c] = 0;
-        if (8u * c < len) v[c] = (8u * c + 8u <= readable) ? ld64u(s + 8u * c) : load_tail(s + 8u * c, readable - 8u * c);
-    }
-}
-__device__ __forceinline__ void lane_store32(uint8_t *d, const uint64_t (&v)[4], uint32_t len)
-{
-#pragma unroll
-    for (uint32_t c = 0; c < 4u; c++) {
-        if (8u * c >= len) break;
-        uint32_t rem = len - 8u * c;
-        uint8_t *q = d + 8u * c;
-        uint64_t x = v[c];
-        if (rem >= 8u) {
-            ((U64u *)q)->v = x;
-        } else {
-            if (rem & 4u) { ((U32u *)q)->v = (uint32_t)x; x >>= 32; q += 4; }
-            if (rem & 2u) { ((U16u *)q)->v = (uint16_t)x; x >>= 16; q += 2; }
-            if (rem & 1u) { *q = (uint8_t)x; }
-        }
-    }
-}
-
 /* A run of up to 32 bytes held by one lane as its full 8-byte chunks plus a word with its LAST 8 bytes
  * (runs under 8 bytes: v[0] only).  Storing it then needs no byte-granular tail: the last word is written over
  * the end of the last full chunk (the same bytes twice), a 4..7 byte run as two overlapping dwords.  Nothing
@@ -238,26 +210,9 @@ __device__ __forceinline__ void lds_sync()
  * len bytes.  `readable` = bytes that may be read starting at s (>= len). */
 __device__ __forceinline__ void lane_copy32(uint8_t *d, const uint8_t *s, uint32_t len, uint32_t readable)
 {
-    uint64_t v[4];
-#pragma unroll
-    for (uint32_t c = 0; c < 4u; c++) {
-        v[c] = 0;
-        if (8u * c < len) v[c] = (8u * c + 8u <= readable) ? ld64u(s + 8u * c) : load_tail(s + 8u * c, readable - 8u * c);
-    }
-#pragma unroll
-    for (uint32_t c = 0; c < 4u; c++) {
-        if (8u * c >= len) break;
-        uint32_t rem = len - 8u * c;
-        uint8_t *q = d + 8u * c;
-        uint64_t x = v[c];
-        if (rem >= 8u) {
-            ((U64u *)q)->v = x;
-        } else {
-            if (rem & 4u) { ((U32u *)q)->v = (uint32_t)x; x >>= 32; q += 4; }
-            if (rem & 2u) { ((U16u *)q)->v = (uint16_t)x; x >>= 16; q += 2; }
-            if (rem & 1u) { *q = (uint8_t)x; }
-        }
-    }
+    LaneRun r;
+    lane_run_load(r, s, len, readable);
+    lane_run_store(d, r, len);
 }
 
 /*
