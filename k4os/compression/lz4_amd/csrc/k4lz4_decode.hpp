@@ -425,14 +425,17 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             }
             lds_sync();
             /* the finished batch leaves the stage in one pass, 16 bytes per lane */
-            for (uint32_t k = 16u * (uint32_t)lane; k < T; k += 1024u) {
-                if (k + 16u <= T) {
-                    const uint4 v = *(const uint4 *)(stg + k);
-                    U128u o;
-                    o.v[0] = v.x; o.v[1] = v.y; o.v[2] = v.z; o.v[3] = v.w;
-                    st128u(out + o0 + k, o);
-                } else {
-                    for (uint32_t t = k; t < T; t++) out[o0 + t] = stg[t];
+            for (uint32_t k = 16u * (uint32_t)lane; k + 16u <= T; k += 1024u) {
+                const uint4 v = *(const uint4 *)(stg + k);
+                U128u o;
+                o.v[0] = v.x; o.v[1] = v.y; o.v[2] = v.z; o.v[3] = v.w;
+                st128u(out + o0 + k, o);
+            }
+            if (T & 15u) {                                          /* the last, partial 16 bytes: once more as the batch's last 16 */
+                if (T >= 16u) {
+                    if (lane == 0) st128u(out + o0 + T - 16u, ld128u(stg + T - 16u));
+                } else if ((uint32_t)lane < T) {
+                    out[o0 + (uint32_t)lane] = stg[lane];
                 }
             }
         } else {
