@@ -44,33 +44,46 @@ constexpr int DECODE_STAGE_BYTES = 2048;          /* a batch's output, kept in L
 constexpr int DECODE_LDS_DWORDS = RING_DWORDS + 5 * 64 + (DECODE_STAGE_BYTES + 64) / 4;   /* ring + 5 descriptor arrays + stage */
 constexpr int MAX_SEQ_PER_ROUND = 22;            /* 64 hypotheses, >= 3 stream bytes per sequence */
 
-/* PARSE's serial part: from hypothesis 0 follow the `next` links (bits 0-9 of a lane's word) while the
- * hypotheses are usable (bit 31) and stay inside the 64-lane window; T collects the real sequences, idx ends
- * on the first position not taken.  Scalar ISA by hand: 7 instructions and one taken branch per sequence,
- * where the compiler's loop has 14 and two. */
-__device__ __forceinline__ void follow_tokens(uint32_t packed, unsigned long long &T, uint32_t &idx)
+/* PARSE's serial part: from hypothesis 0 follow the `next` links while the hypotheses are usable and stay inside
+ * the 64-lane window; T collects the real sequences, idx ends on the first position not taken.  A lane's word:
+ * bits 0-5 next lane if the chain goes on from here, bit 7 it does not (hypothesis unusable, or next token outside
+ * the window), bit 8 usable, bits 9.. next.  Scalar ISA by hand -- 5 instructions and one branch per sequence
+ * (arrive, mark, read, step); the compiler's loop has 14 and two.  The lane the chain stops on is marked before it
+ * is known to be usable and unmarked afterwards if it was not. */
+__device__ __forceinline__ uint32_t token_word(bool fast, uint32_t next)
+{
+    return (fast && next < 64u ? next : 0x80u) | (fast ? 0x100u : 0u) | (next << 9);
+}
+__device__ __forceinline__ void follow_tokens(uint32_t word, unsigned long long &T, uint32_t &idx)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t pk;
+    uint32_t pk, at = 0;
+    T = 0;
     asm volatile(
         ".Ltok_next%=:\n\t"
-        "v_readlane_b32 %[pk], %[packed], %[idx]\n\t"
-        "s_cmp_gt_i32 %[pk], -1\n\t"
-        "s_cbranch_scc1 .Ltok_end%=\n\t"
-        "s_bitset1_b64 %[T], %[idx]\n\t"
-        "s_and_b32 %[idx], %[pk], 0x3ff\n\t"
-        "s_cmp_lt_u32 %[idx], 64\n\t"
-        "s_cbranch_scc1 .Ltok_next%=\n"
-        ".Ltok_end%=:"
-        : [T] "+s"(T), [idx] "+s"(idx), [pk] "=&s"(pk)
-        : [packed] "v"(packed)
+        "s_bitset1_b64 %[T], %[at]\n\t"
+        "v_readlane_b32 %[pk], %[word], %[at]\n\t"
+        "s_and_b32 %[at], %[pk], 0x7f\n\t"
+        "s_bitcmp0_b32 %[pk], 7\n\t"
+        "s_cbranch_scc1 .Ltok_next%="
+        : [T] "+s"(T), [at] "+s"(at), [pk] "=&s"(pk)
+        : [word] "v"(word)
         : "scc");
+    const uint32_t last = 63u - (uint32_t)__builtin_clzll(T);
+    if (pk & 0x100u) {
+        idx = pk >> 9;
+    } else {
+        T &= ~(1ull << last);
+        idx = last;
+    }
 #else
+    T = 0;
+    idx = 0;
     while (idx < 64u) {
-        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane(packed, (int)idx);
-        if ((int32_t)pk >= 0) break;
+        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane(word, (int)idx);
+        if (!(pk & 0x100u)) break;
         T |= 1ull << idx;
-        idx = pk & 0x3ffu;
+        idx = pk >> 9;
     }
 #endif
 }
@@ -201,7 +214,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                     fast = fast && ext != 255u && (int64_t)ip + next < iend - LASTLITERALS + 1;
                 }
                 const uint32_t outlen = L + mlen;
-                const uint32_t packed = next | (outlen << 10) | (fast ? 0x80000000u : 0u);
+                const uint32_t packed = token_word(fast, next);
 
                 /* follow the true chain from hypothesis 0: one v_readlane per real sequence */
                 unsigned long long T = 0;
