@@ -351,6 +351,15 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             uint32_t hopv;                     /* per lane, as a hit: bits 0-6 lane after its match (>= 64: outside the window),
                                                 * 0x100 match runs past the known bytes, 0x200 block ends after it (:391),
                                                 * 0x400 its match covers a lane that may be a later lane's candidate */
+            /* a lane's hop word, were it a hit with a match of MINMATCH + c8 bytes */
+            auto hop_word = [&](uint32_t c8, uint32_t long_flag) -> uint32_t {
+                const uint32_t qn_full = (uint32_t)lane + MINMATCH + c8;
+                const uint32_t qn = contig && qn_full < 127u ? qn_full : 127u;
+                /* lanes lane+1 .. qn-1 except qn-2 are never visited if this lane is a hit */
+                const unsigned long long inside = ~(below_me | me) & ((1ull << (qn & 63u)) - 1ull) & ~(1ull << ((qn - 2u) & 63u));
+                const bool trig = qn < 64u && (inside & cand_m) != 0ull;
+                return (valid ? 0u : 0x800u) | qn | long_flag | (pos + MINMATCH + c8 >= mflimit_plus_one ? 0x200u : 0u) | (trig ? 0x400u : 0u);
+            };
             auto publish = [&]() {
                 hmx = __ballot(chit) | inv_m;
                 const bool counted = xcode != 0xffffffffu;          /* this lane's long match has been measured already */
@@ -358,12 +367,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 epos = pos + MINMATCH + c8;
                 /* a visited-or-future lane with a later lane in its group may be that lane's candidate */
                 cand_m = __ballot(((skipped >> lane) & 1ull) == 0ull && (G & ~(below_me | me)) != 0ull);
-                const uint32_t qn_full = (uint32_t)lane + MINMATCH + c8;
-                const uint32_t qn = contig && qn_full < 127u ? qn_full : 127u;
-                /* lanes lane+1 .. qn-1 except qn-2 are never visited if this lane is a hit */
-                const unsigned long long inside = ~(below_me | me) & ((1ull << (qn & 63u)) - 1ull) & ~(1ull << ((qn - 2u) & 63u));
-                const bool trig = qn < 64u && (inside & cand_m) != 0ull;
-                hopv = (valid ? 0u : 0x800u) | qn | (counted ? 0u : (cinfo & 0x100u)) | (epos >= mflimit_plus_one ? 0x200u : 0u) | (trig ? 0x400u : 0u);
+                hopv = hop_word(c8, counted ? 0u : (cinfo & 0x100u));
             };
             /* from the hits so far: the lanes inside their matches (never visited) and the lanes right after them */
             unsigned long long cursors = 1;
@@ -387,6 +391,10 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 hit1 = chit; pos1 = cpos; info1 = cinfo;
             }
             publish();
+            /* the word of a pair lane that has fallen back to its table candidate; candidate lanes lost so far.
+             * (cand_m only shrinks while the round goes on: a stale one costs a needless check, never a missed one) */
+            const uint32_t hop_tab = dirty ? hop_word(info & 15u, info & 0x100u) : hopv;
+            unsigned long long lost_cands = 0;
             const unsigned long long ta = prof_now<PROF>();
             if (PROF) c_s1 += ta - t1;
             unsigned long long t_rec = 0;
@@ -426,19 +434,23 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 if (sk & cand_m) {
                     const unsigned long long tr0 = prof_now<PROF>();
                     if (PROF) n_dup++;
-                    derive(hits);
-                    const bool lost = j1 >= 0 && ((skipped >> (j1 & 63)) & 1ull) != 0ull;
+                    lost_cands |= sk & cand_m;
+                    const bool lost = j1 >= 0 && ((lost_cands >> (j1 & 63)) & 1ull) != 0ull;
                     const unsigned long long lost_m = __ballot(lost) & (~0ull << q);   /* lanes behind the cursor no longer matter */
                     if (lost_m) {
                         if (!general && (lost_m & multi_m)) general = true;
                         if (general) {
+                            derive(hits);
                             candidates();
-                        } else {
-                            chit = lost ? hit_tab : hit1;
-                            cpos = lost ? cand : pos1;
-                            cinfo = lost ? info : info1;
+                            publish();
+                        } else if (lost && (uint32_t)lane >= q) {   /* pair: the other alternative, both known up front */
+                            chit = hit_tab;
+                            cpos = cand;
+                            cinfo = info;
+                            epos = pos + MINMATCH + (info & 15u);
+                            hopv = hop_tab;
                         }
-                        publish();
+                        if (!general) hmx = __ballot(chit) | inv_m;
                     }
                     if (PROF) t_rec += prof_now<PROF>() - tr0;
                 }
