@@ -192,6 +192,29 @@ __device__ __forceinline__ void lane_run_store(uint8_t *d, const LaneRun &r, uin
     }
 }
 
+/* One lane moves n <= 32 bytes between two places that do not overlap and where 8 bytes may be READ past
+ * either end of the source (an LDS stage with slack): the same chunks-plus-last-word scheme as LaneRun with the
+ * loads placed where they are needed, so that the common lengths (4..16) pass through two predicated regions. */
+__device__ __forceinline__ void lane_move32_slack(uint8_t *d, const uint8_t *s, uint32_t n)
+{
+    const uint64_t v0 = ld64u(s);
+    if (n >= 8u) {
+        const uint64_t vt = ld64u(s + n - 8u);
+        ((U64u *)d)->v = v0;
+        if (n > 16u) {
+            ((U64u *)(d + 8))->v = ld64u(s + 8);
+            if (n > 24u) ((U64u *)(d + 16))->v = ld64u(s + 16);
+        }
+        ((U64u *)(d + n - 8u))->v = vt;
+    } else if (n >= 4u) {
+        ((U32u *)d)->v = (uint32_t)v0;
+        ((U32u *)(d + n - 4u))->v = (uint32_t)(v0 >> (8u * (n - 4u)));
+    } else {
+        if (n & 2u) ((U16u *)d)->v = (uint16_t)v0;
+        if (n & 1u) d[n - 1u] = (uint8_t)(v0 >> (8u * (n - 1u)));
+    }
+}
+
 /* Orders this wave's LDS accesses only (LDS executes a wave's accesses in order; this pins the
  * compiler) -- unlike wave_sync() it never waits for global stores to be acknowledged. */
 __device__ __forceinline__ void lds_sync()

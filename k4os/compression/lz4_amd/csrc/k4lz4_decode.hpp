@@ -429,11 +429,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 const bool ready = ((pend >> lane) & 1ull) != 0 && (deps & pend) == 0;
                 const unsigned long long rmask = __ballot(ready);
                 lds_sync();
-                if (ready) {
-                    LaneRun R;
-                    lane_run_load(R, stg + src_s, n, 8u);           /* the stage has slack behind it */
-                    lane_run_store(stg + dst_s, R, n);
-                }
+                if (ready) lane_move32_slack(stg + dst_s, stg + src_s, n);   /* the stage has slack behind it */
                 pend &= ~rmask;
             }
             lds_sync();
