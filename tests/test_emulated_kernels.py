@@ -476,6 +476,17 @@ def test_encode_random_stress(emu, oracle):
     mod.run(2, 5, oracle, emu, verbose=False)
 
 
+def test_decode_random_stress(emu, oracle):
+    """tests/tools/emu_stress_encode.py run_decode (three rounds): exact / oversized / undersized destinations, streams
+    with a flipped byte, guard bytes behind every destination"""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "emu_stress_encode.py")
+    spec = importlib.util.spec_from_file_location("emu_stress_encode", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run_decode(3, 7, oracle, emu, verbose=False)
+
+
 def test_encode_x32_arm_matches_oracle(emu, oracle):
     """LZ4Codec.Enforce32 (K4LZ4_FLAG_X32 = 128): inputs of 64 KiB and more are hashed with LZ4_hash4 (12 bits) into
     the byU32 table (x32/LL32.tools.cs:141-148, x32/LL32.fast.cs:543-545); smaller inputs are unaffected"""

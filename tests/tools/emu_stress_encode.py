@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Randomised stress of the fast encoder kernel under the host wave emulator against the oracle:
+"""Randomised stress of the fast encoder kernel (and, second half, of the decoder kernel) under the host wave emulator against the oracle:
 inputs built to provoke equal hashes inside one 64-position window, matches ending near window
 edges, long literal runs, limited output.  Usage: tests/tools/emu_stress_encode.py [rounds] [seed]"""
 import os, sys
@@ -86,5 +86,46 @@ def run(rounds, seed, oracle, emu, verbose=True):
         if verbose:
             print("round", r, "ok", len(blocks), "blocks accel", accel, flush=True)
 
+def run_decode(rounds, seed, oracle, emu, verbose=True):
+    """The decoder kernel on the oracle's streams of the same inputs: destinations of exactly the decoded size,
+    larger, and too small; streams with a flipped byte; 16 guard bytes behind every destination (the lane copies
+    write overlapping words, none may leave its run); results and bytes against the oracle's safe decoder."""
+    rng = np.random.default_rng(seed + 1000)
+    for r in range(rounds):
+        blocks = []
+        for _ in range(48):
+            n = int(rng.choice([rng.integers(0, 40), rng.integers(13, 300), rng.integers(300, 6000), rng.integers(6000, 70000)]))
+            blocks.append(gen(rng, n) if n else np.zeros(0, np.uint8))
+        comp = []
+        for b in blocks:
+            if b.size == 0:
+                comp.append(np.zeros(0, np.uint8)); continue
+            n, out = oracle.compress_fast(b, LZ4Codec.MaximumOutputSize(b.size), 1)
+            c = out[:n].copy()
+            if rng.random() < 0.15 and n > 4:                 # hostile: one byte changed
+                c[int(rng.integers(0, n))] ^= int(rng.integers(1, 256))
+            comp.append(c)
+        src, soff, slen = pack_blocks(comp)
+        caps = []
+        for b in blocks:
+            k = rng.random()
+            caps.append(b.size if k < 0.6 else (b.size + int(rng.integers(1, 100)) if k < 0.8 else int(rng.integers(0, b.size + 1))))
+        caps = np.array(caps, np.int32)
+        d1, o1 = make_arena(caps + 16, fill=0xCD)
+        got = emu.decode_batch(src, soff, slen, d1, o1, caps, flags=1)    # raw engine results
+        for i, b in enumerate(blocks):
+            if comp[i].size == 0:
+                continue
+            n, ref = oracle.decompress_safe(comp[i], int(caps[i]))
+            assert got[i] == n, (r, i, b.size, int(caps[i]), int(got[i]), n)
+            if n > 0:
+                a = d1[int(o1[i]):int(o1[i]) + n]
+                assert np.array_equal(a, ref[:n]), (r, i, b.size, int(np.argmax(a != ref[:n])))
+            assert (d1[int(o1[i]) + caps[i]:int(o1[i]) + caps[i] + 16] == 0xCD).all(), (r, i, 'guard')
+        if verbose:
+            print("decode round", r, "ok", len(blocks), "blocks", flush=True)
+
+
 if __name__ == "__main__":
     main()
+    run_decode(int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 1, Oracle(), Emu())
