@@ -231,9 +231,15 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                  * that left the shortcut also obey the end-of-block rule (:427-433).  The first
                  * sequence that fails, and everything after it, is left to the scalar parser. */
                 const int64_t mdst_l = v_o64 + L;
-                const unsigned long long bad =
-                    __ballot(in_t && ((cls_g ? mdst_l > oend - MFLIMIT : v_o64 > shortoend) || (int64_t)offset > mdst_l ||
-                                      (general && mdst_l + (int64_t)mlen > oend - MATCH_SAFEGUARD)));
+                unsigned long long bad;
+                if (op + (int64_t)__builtin_amdgcn_readlane(incl, 63) <= oend - 64) {
+                    /* every chosen sequence ends at least 64 bytes before the end of the output: the three
+                     * end-of-block rules hold for all of them, only the offset can be wrong */
+                    bad = __ballot(in_t && offset > v_o + L);
+                } else {
+                    bad = __ballot(in_t && ((cls_g ? mdst_l > oend - MFLIMIT : v_o64 > shortoend) || (int64_t)offset > mdst_l ||
+                                            (general && mdst_l + (int64_t)mlen > oend - MATCH_SAFEGUARD)));
+                }
                 int64_t cur_op;
                 if (bad) {
                     const int b = ctz64(bad);
