@@ -329,8 +329,12 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             unsigned long long skipped = 0;    /* lanes inside matches: never put into the table */
             unsigned long long hmx, cand_m;    /* lanes that stop the chain (hits, invalid lanes); lanes that may be a later lane's candidate */
             uint32_t epos;                     /* per lane: where its match would end */
+            /* candidate lanes (lanes with a later lane in their group) that ended up inside a match: they were never put.
+             * Every such lane is recorded when the chain covers it, so for candidates this mask says all `skipped` would */
+            unsigned long long lost_cands = 0;
+            const unsigned long long cand0 = __ballot((G & ~(below_me | me)) != 0ull);
             auto candidates = [&]() {          /* general form: highest visited-or-future lane of the group below this one */
-                const unsigned long long eff = G & below_me & ~skipped;
+                const unsigned long long eff = G & below_me & ~lost_cands;
                 const int j = eff ? 63 - (int)__clzll((long long)eff) : -1;
                 const int sj = j & 63;
                 const uint32_t vj = (uint32_t)__shfl((int)pa.seq, sj), pj = (uint32_t)__shfl((int)pa.pre, sj);
@@ -366,7 +370,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 const uint32_t c8 = counted ? xcode : (cinfo & 15u);
                 epos = pos + MINMATCH + c8;
                 /* a visited-or-future lane with a later lane in its group may be that lane's candidate */
-                cand_m = __ballot(((skipped >> lane) & 1ull) == 0ull && (G & ~(below_me | me)) != 0ull);
+                cand_m = cand0 & ~lost_cands;
                 hopv = hop_word(c8, counted ? 0u : (cinfo & 0x100u));
             };
             /* from the hits so far: the lanes inside their matches (never visited) and the lanes right after them */
@@ -394,7 +398,6 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             /* the word of a pair lane that has fallen back to its table candidate; candidate lanes lost so far.
              * (cand_m only shrinks while the round goes on: a stale one costs a needless check, never a missed one) */
             const uint32_t hop_tab = dirty ? hop_word(info & 15u, info & 0x100u) : hopv;
-            unsigned long long lost_cands = 0;
             const unsigned long long ta = prof_now<PROF>();
             if (PROF) c_s1 += ta - t1;
             unsigned long long t_rec = 0;
@@ -440,7 +443,6 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                     if (lost_m) {
                         if (!general && (lost_m & multi_m)) general = true;
                         if (general) {
-                            derive(hits);
                             candidates();
                             publish();
                         } else if (lost && (uint32_t)lane >= q) {   /* pair: the other alternative, both known up front */
