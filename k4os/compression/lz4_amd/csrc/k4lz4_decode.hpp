@@ -131,14 +131,61 @@ __device__ __forceinline__ void wave_dict_copy(uint8_t *out, const uint8_t *dict
 }
 
 /*
+ * Two wavefronts per block (k4_decode_pair_kernel): a decoder wave spends ~85 % of its cycles waiting on its own
+ * dependent chains, so PARSE (wave A) and LITERALS/MATCHES (wave B) of one block run side by side, batch k+1 being
+ * parsed while batch k is copied.  The waves share a two-slot queue of batch descriptors in LDS:
+ *   pipe[0] head  batches published by A      pipe[1] tail  batches taken by B
+ *   pipe[8 + 8 * slot ..]  nseq, output position of the batch, its byte count, last-batch flag, the block's result
+ *   pipe[PIPE_DESC + 320 * slot ..]  the five descriptor arrays
+ *   pipe[PIPE_SCRATCH ..]  B's two sort arrays, pipe[PIPE_STAGE ..] B's output stage
+ * LDS executes in order, so "write the batch, wait for the writes, then advance head" is a release; the reader polls
+ * with s_sleep between attempts and gives up (block fails) after PIPE_SPIN_MAX polls instead of hanging.
+ */
+constexpr int PIPE_DESC = 32, PIPE_SCRATCH = PIPE_DESC + 2 * 320, PIPE_STAGE = PIPE_SCRATCH + 128;
+constexpr int PIPE_DWORDS = PIPE_STAGE + (DECODE_STAGE_BYTES + 64) / 4;
+constexpr int DECODE_PAIR_LDS_DWORDS = RING_DWORDS + PIPE_DWORDS;
+constexpr uint32_t PIPE_SPIN_MAX = 1u << 24;
+constexpr int PIPE_TIMEOUT = -0x7ffffff0;
+
+__device__ __forceinline__ uint32_t pipe_load(const uint32_t *p)
+{
+#ifndef K4_HOST_EMU
+    return uni(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+#else
+    return uni(*(const volatile uint32_t *)p);             /* one lane's view for the whole wave */
+#endif
+}
+__device__ __forceinline__ void pipe_store(uint32_t *p, uint32_t v, int lane)
+{
+    lds_sync();
+#ifndef K4_HOST_EMU
+    if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    if (lane == 0) *(volatile uint32_t *)p = v;
+#endif
+    lds_sync();
+}
+/* poll until *p - base >= want (counters only grow); false after PIPE_SPIN_MAX polls */
+__device__ __forceinline__ bool pipe_wait(const uint32_t *p, uint32_t want)
+{
+    for (uint32_t spin = 0; spin < PIPE_SPIN_MAX; spin++) {
+        if (pipe_load(p) >= want) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
+/*
  * Decode one block.  Returns what LL64.LZ4_decompress_safe returns: the number of bytes written,
  * or -(input position) - 1 when the stream is malformed (LL64.dec.cs:465).
  * `lds`: DECODE_LDS_DWORDS dwords of LDS owned by this wave.
  */
-template <bool PROF = false>
+/* ROLE 0: one wave does everything.  ROLE 1: PARSE only, batches go into the pair's queue (`pipe`).  ROLE 2: takes
+ * batches from the queue and does LITERALS / MATCHES; returns the block's result. */
+template <bool PROF = false, int ROLE = 0>
 __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uint8_t *out, int out_size, int lane,
                                             uint32_t *lds, unsigned long long *pc = nullptr, bool partial = false,
-                                            DecodeDict dict = DecodeDict{nullptr, 0u, 0})
+                                            DecodeDict dict = DecodeDict{nullptr, 0u, 0}, uint32_t *pipe = nullptr)
 {
     /* lowPrefix relative to out (<= 0), the size used by the offset check (:149,:338) */
     const int64_t low_prefix = dict.mode == 1 ? -(int64_t)dict.size : 0;
@@ -159,9 +206,13 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     if (src_size <= 0) return -1;                          /* :172 */
 
     StreamRing win;
-    win.init(lds, in, (uint32_t)src_size, lane);
-    uint32_t *d_lpos = lds + RING_DWORDS, *d_llen = d_lpos + 64, *d_out = d_llen + 64, *d_moff = d_out + 64,
-             *d_mlen = d_moff + 64;
+    if (ROLE != 2) win.init(lds, in, (uint32_t)src_size, lane);
+    uint32_t *d_lpos = ROLE == 0 ? lds + RING_DWORDS : pipe + PIPE_DESC, *d_llen = d_lpos + 64, *d_out = d_llen + 64,
+             *d_moff = d_out + 64, *d_mlen = d_moff + 64;
+    /* MATCHES sorts destination ranges in two arrays: the descriptor arrays themselves when one wave does it all */
+    uint32_t *w_out = ROLE == 0 ? d_out : pipe + PIPE_SCRATCH, *w_end = ROLE == 0 ? d_llen : pipe + PIPE_SCRATCH + 64;
+    uint8_t *const stage_base = ROLE == 0 ? (uint8_t *)(d_mlen + 64) : (uint8_t *)(pipe + PIPE_STAGE);
+    uint32_t batch_no = 0;                                  /* ROLE 1/2: batches published / taken so far */
 
     const int64_t iend = src_size;
     const int64_t oend = out_size;
@@ -172,11 +223,27 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     for (;;) {
         /* ======================= PARSE ======================= */
         const unsigned long long t0 = prof_now<PROF>();
-        const int64_t op_batch = op;
+        int64_t op_batch = op;
         int nseq = 0;
         int err = 0;
         bool done = false;
-        while (nseq <= 64 - MAX_SEQ_PER_ROUND && !done) {
+        uint32_t *meta = nullptr;
+        if (ROLE != 0) {
+            const uint32_t slot = batch_no & 1u;
+            meta = pipe + 8 + 8 * slot;
+            d_lpos = pipe + PIPE_DESC + 320 * slot; d_llen = d_lpos + 64; d_out = d_llen + 64; d_moff = d_out + 64; d_mlen = d_moff + 64;
+            if (ROLE == 1) {                                /* the slot is free once the other wave has taken batch_no - 2 */
+                if (batch_no >= 2u && !pipe_wait(pipe + 1, batch_no - 1u)) return PIPE_TIMEOUT;
+            } else {
+                if (!pipe_wait(pipe + 0, batch_no + 1u)) return PIPE_TIMEOUT;
+                nseq = (int)uni(meta[0]);
+                op_batch = (int64_t)uni(meta[1]);
+                op = op_batch + (int64_t)uni(meta[2]);
+                done = uni(meta[3]) != 0u;
+                err = (int)uni(meta[4]);                    /* the block's result, valid with `done` */
+            }
+        }
+        while (ROLE != 2 && nseq <= 64 - MAX_SEQ_PER_ROUND && !done) {
             /* ---- speculative round: 64 hypotheses "a token starts at ip + lane" ---- */
             const int64_t lim = shortiend - 1 - ip;        /* hypotheses i < lim satisfy ip + i + 1 < shortiend */
             if (lim > 0 || iend - RUN_MASK - 1 - ip > 0) {
@@ -380,7 +447,21 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             op += adv;
             if (last) done = true;
         }
-        if (err) return err;
+        if (ROLE == 1) {                                    /* publish the batch (or the failure) and go on parsing */
+            if (lane == 0) {
+                meta[0] = err ? 0u : (uint32_t)nseq;
+                meta[1] = (uint32_t)op_batch;
+                meta[2] = err ? 0u : (uint32_t)(op - op_batch);
+                meta[3] = (err || done) ? 1u : 0u;
+                meta[4] = (uint32_t)(err ? err : (int)op);
+            }
+            pipe_store(pipe + 0, batch_no + 1u, lane);
+            batch_no++;
+            if (err) return err;
+            if (done) return (int)op;
+            continue;
+        }
+        if (ROLE == 0 && err) return err;
         wave_sync();
         const bool mine = lane < nseq;
         const uint32_t v_lpos = mine ? d_lpos[lane] : 0u;
@@ -388,6 +469,10 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
         const uint32_t v_out = mine ? d_out[lane] : 0u;
         const uint32_t v_moff = mine ? d_moff[lane] : 0u;
         const uint32_t v_mlen = mine ? d_mlen[lane] : 0u;
+        if (ROLE == 2) {                                    /* the descriptors are in registers: the slot may be refilled */
+            pipe_store(pipe + 1, batch_no + 1u, lane);
+            batch_no++;
+        }
         const unsigned long long t1 = prof_now<PROF>();
 
         const uint32_t o0 = (uint32_t)op_batch, T = (uint32_t)(op - op_batch);
@@ -401,7 +486,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
              * match sources that lie before the batch's output (they are final).  Matches that read this
              * batch's own output take it from the LDS stage, so the dependency rounds never wait for global
              * memory; the finished batch is then written out in one coalesced pass. */
-            uint8_t *stg = (uint8_t *)(d_mlen + 64);
+            uint8_t *stg = stage_base;
             const uint32_t mdst = v_out + v_llen, mend = mdst + v_mlen, msrc = mdst - v_moff;
             const uint32_t before = has_m && msrc < o0 ? (o0 - msrc < v_mlen ? o0 - msrc : v_mlen) : 0u;   /* source bytes before the batch */
             LaneRun L, M;
@@ -410,14 +495,14 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             /* dependencies among the matches of the batch, as below */
             const uint32_t send = msrc + v_mlen < mdst ? msrc + v_mlen : mdst;
             lds_sync();
-            d_out[lane] = mine ? mdst : 0xffffffffu;
-            d_llen[lane] = mine ? mend : 0xffffffffu;
+            w_out[lane] = mine ? mdst : 0xffffffffu;
+            w_end[lane] = mine ? mend : 0xffffffffu;
             lds_sync();
             uint32_t lo = 0, hi = 0;
 #pragma unroll
             for (uint32_t step = 32; step != 0; step >>= 1) {
-                if (d_llen[lo + step - 1u] <= msrc) lo += step;
-                if (d_out[hi + step - 1u] < send) hi += step;
+                if (w_end[lo + step - 1u] <= msrc) lo += step;
+                if (w_out[hi + step - 1u] < send) hi += step;
             }
             const uint32_t hi_c = hi < (uint32_t)lane ? hi : (uint32_t)lane;
             unsigned long long deps = 0;
@@ -477,15 +562,15 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             const uint32_t send = msrc + v_mlen < mdst ? msrc + v_mlen : mdst;   /* source bytes below own output */
             /* destination ranges sorted by lane: publish [mdst, mend) (sentinel for idle lanes) */
             wave_sync();
-            d_out[lane] = mine ? mdst : 0xffffffffu;
-            d_llen[lane] = mine ? mend : 0xffffffffu;
+            w_out[lane] = mine ? mdst : 0xffffffffu;
+            w_end[lane] = mine ? mend : 0xffffffffu;
             wave_sync();
             /* first lane whose match ends above msrc, first lane whose match starts at/after send */
             uint32_t lo = 0, hi = 0;
 #pragma unroll
             for (uint32_t step = 32; step != 0; step >>= 1) {
-                if (d_llen[lo + step - 1u] <= msrc) lo += step;
-                if (d_out[hi + step - 1u] < send) hi += step;
+                if (w_end[lo + step - 1u] <= msrc) lo += step;
+                if (w_out[hi + step - 1u] < send) hi += step;
             }
             /* dependencies: lanes [lo, hi) below this lane */
             const uint32_t hi_c = hi < (uint32_t)lane ? hi : (uint32_t)lane;
@@ -522,6 +607,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             const unsigned long long t3 = prof_now<PROF>();
             c_parse += t1 - t0; c_lit += t2 - t1; c_match += t3 - t2; n_batch++; n_seq += (unsigned long long)nseq;
         }
+        if (ROLE == 2 && done) return err;                  /* the result the parsing wave arrived at */
         if (done) break;
     }
     if (PROF && pc && lane == 0) {
@@ -578,6 +664,36 @@ __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_decode_kernel(Bat
 {
     __shared__ uint32_t lds[DECODE_WAVES_PER_WG][DECODE_LDS_DWORDS];
     decode_kernel_body(a, lds);
+}
+
+/* ... and with at most half as many blocks as the chip has wave slots, two waves per block: wave 2p parses block p of
+ * the workgroup, wave 2p+1 copies (see the queue above).  8 waves per SIMD need <= 64 VGPRs. */
+constexpr int DECODE_PAIRS_PER_WG = 4;
+__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k4_decode_pair_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
+    const int lane = lane_id();
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t pair = wave >> 1, role = wave & 1u;
+    const long long b = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
+    uint32_t *ring = lds[pair], *pipe = lds[pair] + RING_DWORDS;
+    if (lane < 8 && role == 0) pipe[lane] = 0u;             /* head, tail */
+    __syncthreads();
+    if (b >= a.n) return;
+    const int src_len = a.srcLen[b];
+    const int cap = a.dstCap[b];
+    const uint8_t *in = a.src + a.srcOff[b];
+    uint8_t *out = a.dst + a.dstOff[b];
+    const bool run = src_len > 0 || (a.flags & FLAG_RAW_RETURN);
+    const bool partial = (a.flags & FLAG_PARTIAL) != 0;
+    const DecodeDict dict = block_dict(a, b, out);
+    if (role == 0) {
+        if (run) decode_block<false, 1>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, nullptr, partial, dict, pipe);
+    } else {
+        int ret = 0;
+        if (run) ret = decode_block<false, 2>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, nullptr, partial, dict, pipe);
+        if (lane == 0) a.outLen[b] = codec_decode_result(src_len, ret, a.flags);
+    }
 }
 
 /* many more blocks than the chip holds: throughput counts, so one more wave per SIMD (<= 72 VGPRs) is worth the

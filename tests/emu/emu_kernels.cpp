@@ -22,6 +22,20 @@ int k4emu_decode_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t
     return 0;
 }
 
+/* the two-waves-per-block decoder (parse wave + copy wave, LDS queue between them) */
+int k4emu_decode_pair_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                            const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int flags,
+                            const uint8_t *dict, const uint64_t *dictOff, const int32_t *dictLen, int threads)
+{
+    k4::BatchArgs a{};
+    a.src = src; a.srcOff = srcOff; a.srcLen = srcLen; a.dst = dst; a.dstOff = dstOff; a.dstCap = dstCap;
+    a.outLen = outLen; a.n = n; a.accel = 1; a.flags = flags; a.dict = dict; a.dictOff = dictOff; a.dictLen = dictLen;
+    if (n <= 0) return 0;
+    unsigned grid = (unsigned)((n + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG);
+    k4emu::launch_fn(dim3(grid), dim3(128 * k4::DECODE_PAIRS_PER_WG), [=] { k4::k4_decode_pair_kernel(a); }, threads);
+    return 0;
+}
+
 int k4emu_decode_dict_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
                             const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int flags,
                             const uint8_t *dict, const uint64_t *dictOff, const int32_t *dictLen, int threads)

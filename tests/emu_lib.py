@@ -52,6 +52,8 @@ class Emu:
         self.lib.k4emu_decode_batch.argtypes = b + [C.c_int, C.c_int]
         self.lib.k4emu_encode_batch.argtypes = b + [C.c_int, C.c_int, C.c_int, C.c_int]
         self.lib.k4emu_decode_dict_batch.argtypes = b + [C.c_int, _u8p, C.c_void_p, C.c_void_p, C.c_int]
+        self.lib.k4emu_decode_pair_batch.argtypes = b + [C.c_int, _u8p, C.c_void_p, C.c_void_p, C.c_int]
+        self.pair = False      # True: decode_batch / decode_dict_batch run the two-waves-per-block kernel
         self.lib.k4emu_xxh32_batch.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_uint32, C.c_int]
         self.lib.k4emu_allow_copy.argtypes = b + [C.c_int]
         self.lib.k4emu_decode_chain_batch.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u8p,
@@ -68,6 +70,12 @@ class Emu:
 
     def decode_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, flags=0, threads=0):
         out = np.full(len(src_len), -12345, dtype=np.int32)
+        if self.pair:
+            rc = self.lib.k4emu_decode_pair_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
+                                                  dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data, len(src_len),
+                                                  flags, None, None, None, threads)
+            assert rc == 0
+            return out
         rc = self.lib.k4emu_decode_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
                                          dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data,
                                          len(src_len), flags, threads)
@@ -123,7 +131,8 @@ class Emu:
 
     def decode_dict_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, dct, dict_off, dict_len, flags=0, threads=0):
         out = np.full(len(src_len), -12345, dtype=np.int32)
-        rc = self.lib.k4emu_decode_dict_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
+        fn = self.lib.k4emu_decode_pair_batch if self.pair else self.lib.k4emu_decode_dict_batch
+        rc = fn(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
                                               dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data, len(src_len),
                                               flags, self._p(dct), dict_off.ctypes.data, dict_len.ctypes.data, threads)
         assert rc == 0

@@ -506,3 +506,21 @@ def test_encode_x32_arm_matches_oracle(emu, oracle):
         if b.size < 65547:
             assert w[:r].tobytes() == oracle.encode(b)
     assert differs >= 3            # the large compressible blocks really take the other hash
+
+
+@pytest.fixture()
+def emu_pair(emu):
+    """the same emulator driver with decode routed to k4_decode_pair_kernel (parse wave + copy wave per block)"""
+    emu.pair = True
+    yield emu
+    emu.pair = False
+
+
+@pytest.mark.parametrize("case", [test_decode_matches_oracle_and_guards, test_decode_golden_issue64,
+                                  test_decode_malformed_parity_with_oracle, test_decode_special_cases,
+                                  test_decode_all_classes_various_sizes, test_decode_hostile_streams_random,
+                                  test_partial_decode_matches_oracle, test_decode_with_dictionary_issue64_and_synthetic,
+                                  test_decode_random_stress], ids=lambda f: f.__name__)
+def test_pair_kernel_passes_the_decoder_tests(case, emu_pair, oracle):
+    """every decoder test above, run once more through the two-waves-per-block kernel"""
+    case(emu_pair, oracle)
