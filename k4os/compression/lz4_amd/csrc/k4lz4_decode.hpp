@@ -133,7 +133,7 @@ __device__ __forceinline__ void wave_dict_copy(uint8_t *out, const uint8_t *dict
 /*
  * Two wavefronts per block (k4_decode_pair_kernel): a decoder wave spends ~85 % of its cycles waiting on its own
  * dependent chains, so PARSE (wave A) and LITERALS/MATCHES (wave B) of one block run side by side, batch k+1 being
- * parsed while batch k is copied.  The waves share a two-slot queue of batch descriptors in LDS:
+ * parsed while batch k is copied.  The waves share a PIPE_SLOTS-deep queue of batch descriptors in LDS:
  *   pipe[0] head  batches published by A      pipe[1] tail  batches taken by B
  *   pipe[8 + 8 * slot ..]  nseq, output position of the batch, its byte count, last-batch flag, the block's result
  *   pipe[PIPE_DESC + 320 * slot ..]  the five descriptor arrays
@@ -141,7 +141,8 @@ __device__ __forceinline__ void wave_dict_copy(uint8_t *out, const uint8_t *dict
  * LDS executes in order, so "write the batch, wait for the writes, then advance head" is a release; the reader polls
  * with s_sleep between attempts and gives up (block fails) after PIPE_SPIN_MAX polls instead of hanging.
  */
-constexpr int PIPE_DESC = 32, PIPE_SCRATCH = PIPE_DESC + 2 * 320, PIPE_STAGE = PIPE_SCRATCH + 128;
+constexpr int PIPE_SLOTS = 4;                     /* batches in flight between the two waves (power of two) */
+constexpr int PIPE_DESC = 8 + 8 * PIPE_SLOTS, PIPE_SCRATCH = PIPE_DESC + PIPE_SLOTS * 320, PIPE_STAGE = PIPE_SCRATCH + 128;
 constexpr int PIPE_DWORDS = PIPE_STAGE + (DECODE_STAGE_BYTES + 64) / 4;
 constexpr int DECODE_PAIR_LDS_DWORDS = RING_DWORDS + PIPE_DWORDS;
 constexpr uint32_t PIPE_SPIN_MAX = 1u << 24;
@@ -229,11 +230,11 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
         bool done = false;
         uint32_t *meta = nullptr;
         if (ROLE != 0) {
-            const uint32_t slot = batch_no & 1u;
+            const uint32_t slot = batch_no & (uint32_t)(PIPE_SLOTS - 1);
             meta = pipe + 8 + 8 * slot;
             d_lpos = pipe + PIPE_DESC + 320 * slot; d_llen = d_lpos + 64; d_out = d_llen + 64; d_moff = d_out + 64; d_mlen = d_moff + 64;
-            if (ROLE == 1) {                                /* the slot is free once the other wave has taken batch_no - 2 */
-                if (batch_no >= 2u && !pipe_wait(pipe + 1, batch_no - 1u)) return PIPE_TIMEOUT;
+            if (ROLE == 1) {                                /* the slot is free once the other wave has taken batch_no - PIPE_SLOTS */
+                if (batch_no >= (uint32_t)PIPE_SLOTS && !pipe_wait(pipe + 1, batch_no + 1u - (uint32_t)PIPE_SLOTS)) return PIPE_TIMEOUT;
             } else {
                 if (!pipe_wait(pipe + 0, batch_no + 1u)) return PIPE_TIMEOUT;
                 nseq = (int)uni(meta[0]);
