@@ -212,7 +212,9 @@ def main():
                        "parallelism": f"{world} x independent block ranges, no data-path collective"},
             "bit_exact": bit_exact,
             "roofline": roof(enc_avg, "k4_encode_fast_kernel"),
-            "roofline_decode": roof(dec_avg, "k4_decode_kernel"),
+            # batches of up to 16 blocks per CU are decoded by the two-waves-per-block kernel (k4lz4_capi.hip launch())
+            "roofline_decode": roof(dec_avg, "k4_decode_pair_kernel" if n <= 16 * 256 and not os.environ.get("K4LZ4_NO_PAIR")
+                                    else "k4_decode_kernel"),
             "cpu_baseline": cpu,
         }
         print(json.dumps(result), flush=True)
