@@ -47,8 +47,10 @@ constexpr int MAX_SEQ_PER_ROUND = 22;            /* 64 hypotheses, >= 3 stream b
 /* PARSE's serial part: from hypothesis 0 follow the `next` links while the hypotheses are usable and stay inside
  * the 64-lane window; T collects the real sequences, idx ends on the first position not taken.  A lane's word:
  * bits 0-5 next lane if the chain goes on from here, bit 7 it does not (hypothesis unusable, or next token outside
- * the window), bit 8 usable, bits 9.. next.  Scalar ISA by hand -- 5 instructions and one branch per sequence
- * (arrive, mark, read, step); the compiler's loop has 14 and two.  The lane the chain stops on is marked before it
+ * the window), bit 8 usable, bits 9.. next.  Scalar ISA by hand -- 4 instructions per sequence (mark, read, test,
+ * branch), unrolled four times so that three of four branches fall through; s_bitset1 and v_readlane take the lane
+ * from the low six bits of the word just read, so one v_readlane feeds the next directly.  The compiler's loop has
+ * 14 instructions and two branches per sequence.  The lane the chain stops on is marked before it
  * is known to be usable and unmarked afterwards if it was not. */
 __device__ __forceinline__ uint32_t token_word(bool fast, uint32_t next)
 {
@@ -57,16 +59,32 @@ __device__ __forceinline__ uint32_t token_word(bool fast, uint32_t next)
 __device__ __forceinline__ void follow_tokens(uint32_t word, unsigned long long &T, uint32_t &idx)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t pk, at = 0;
+    uint32_t pk = 0;                                        /* a word's low six bits are the next lane: it selects the lane itself */
     T = 0;
     asm volatile(
         ".Ltok_next%=:\n\t"
-        "s_bitset1_b64 %[T], %[at]\n\t"
-        "v_readlane_b32 %[pk], %[word], %[at]\n\t"
-        "s_and_b32 %[at], %[pk], 0x7f\n\t"
+        "s_bitset1_b64 %[T], %[pk]\n\t"
+        "s_nop 0\n\t"                                        /* v_readlane wrote pk: 4 wait states before it selects a lane */
+        "v_readlane_b32 %[pk], %[word], %[pk]\n\t"
+        "s_bitcmp1_b32 %[pk], 7\n\t"
+        "s_cbranch_scc1 .Ltok_end%=\n\t"
+        "s_bitset1_b64 %[T], %[pk]\n\t"
+        "s_nop 0\n\t"                                        /* v_readlane wrote pk: 4 wait states before it selects a lane */
+        "v_readlane_b32 %[pk], %[word], %[pk]\n\t"
+        "s_bitcmp1_b32 %[pk], 7\n\t"
+        "s_cbranch_scc1 .Ltok_end%=\n\t"
+        "s_bitset1_b64 %[T], %[pk]\n\t"
+        "s_nop 0\n\t"                                        /* v_readlane wrote pk: 4 wait states before it selects a lane */
+        "v_readlane_b32 %[pk], %[word], %[pk]\n\t"
+        "s_bitcmp1_b32 %[pk], 7\n\t"
+        "s_cbranch_scc1 .Ltok_end%=\n\t"
+        "s_bitset1_b64 %[T], %[pk]\n\t"
+        "s_nop 0\n\t"                                        /* v_readlane wrote pk: 4 wait states before it selects a lane */
+        "v_readlane_b32 %[pk], %[word], %[pk]\n\t"
         "s_bitcmp0_b32 %[pk], 7\n\t"
-        "s_cbranch_scc1 .Ltok_next%="
-        : [T] "+s"(T), [at] "+s"(at), [pk] "=&s"(pk)
+        "s_cbranch_scc1 .Ltok_next%=\n"
+        ".Ltok_end%=:"
+        : [T] "+s"(T), [pk] "+s"(pk)
         : [word] "v"(word)
         : "scc");
     const uint32_t last = 63u - (uint32_t)__builtin_clzll(T);
@@ -194,6 +212,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     const bool check_offset = chk_size < 65536;
     const bool prefix64 = dict.mode == 1 && dict.size == 65536u;
     unsigned long long c_parse = 0, c_lit = 0, c_match = 0, n_batch = 0, n_round = 0, n_seq = 0, n_slow = 0;
+    unsigned long long c_hyp = 0, c_chain = 0, c_rules = 0, c_slots = 0, n_spec = 0;   /* PARSE split: speculative rounds */
     prof_place<PROF>(pc, 8, lane);
     const unsigned long long t_begin = prof_now<PROF>();
     if (out_size == 0) {                                   /* LL64.dec.cs:162-168 */
@@ -248,6 +267,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             /* ---- speculative round: 64 hypotheses "a token starts at ip + lane" ---- */
             const int64_t lim = shortiend - 1 - ip;        /* hypotheses i < lim satisfy ip + i + 1 < shortiend */
             if (lim > 0 || iend - RUN_MASK - 1 - ip > 0) {
+                const unsigned long long tp0 = prof_now<PROF>();
                 win.ensure((uint32_t)ip + win.a0, lane);
                 const uint32_t q = (uint32_t)ip + win.a0 + (uint32_t)lane;
                 const uint32_t t4 = win.read4(q);
@@ -287,7 +307,9 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 /* follow the true chain from hypothesis 0: one v_readlane per real sequence */
                 unsigned long long T = 0;
                 uint32_t idx = 0;
+                const unsigned long long tp1 = prof_now<PROF>();
                 follow_tokens(packed, T, idx);
+                const unsigned long long tp2 = prof_now<PROF>();
                 /* output position of every chosen sequence: prefix sum of the chosen lengths */
                 bool in_t = ((T >> lane) & 1ull) != 0;
                 const uint32_t incl = wave_inclusive_scan(in_t ? outlen : 0u);
@@ -318,6 +340,8 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 } else {
                     cur_op = op + (int64_t)__builtin_amdgcn_readlane(incl, 63);
                 }
+                const unsigned long long tp3 = prof_now<PROF>();
+                if (PROF) { c_hyp += tp1 - tp0; c_chain += tp2 - tp1; c_rules += tp3 - tp2; n_spec++; }
                 if (T) {
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(T >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)T, 0u));
                     if (in_t) {
@@ -331,6 +355,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                     nseq += __popcll(T);
                     ip += idx;
                     op = cur_op;
+                    if (PROF) c_slots += prof_now<PROF>() - tp3;
                     continue;
                 }
             }
@@ -614,6 +639,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     if (PROF && pc && lane == 0) {
         pc[0] = prof_now<PROF>() - t_begin; pc[1] = c_parse; pc[2] = c_lit; pc[3] = c_match;
         pc[4] = n_batch; pc[5] = n_round; pc[6] = n_seq; pc[7] = n_slow;
+        pc[11] = c_hyp; pc[12] = c_chain; pc[13] = c_rules; pc[14] = c_slots; pc[15] = n_spec;
     }
     prof_place<PROF>(pc, 9, lane);
     return (int)op;

@@ -52,6 +52,12 @@ for decode in (False, True):
         d = c[np.arange(0, n, 12)].mean(axis=0)
         print("dickens resolve split per round: initial candidates %.0f  hop loop %.0f  recompute %.0f  post %.0f ; recomputes/round %.2f" % (tuple(d[11:15] / d[5]) + (d[6] / d[5],)))
         print("ALL     resolve split per round: initial %.0f hop %.0f recompute %.0f post %.0f" % tuple(m[11:15] / m[5]))
+    if decode:
+        for name in ("dickens", "ALL"):
+            sel = np.arange(n) if name == "ALL" else np.array([i for i in range(n) if names[i % len(names)] == name])
+            r = c[sel][:, 15].mean()
+            print(f"{name} PARSE split per speculative round ({r:.0f} rounds per block): ring+hypotheses {c[sel][:, 11].mean() / r:.0f}  chain {c[sel][:, 12].mean() / r:.0f}"
+                  f"  scan+rules {c[sel][:, 13].mean() / r:.0f}  slots {c[sel][:, 14].mean() / r:.0f}  (whole PARSE {c[sel][:, 1].mean() / r:.0f})")
     st, en = c[:, 8], c[:, 9]
     ev = sorted([(t, 1) for t in st] + [(t, -1) for t in en])
     cur = mx = 0
