@@ -46,47 +46,38 @@ constexpr int MAX_SEQ_PER_ROUND = 22;            /* 64 hypotheses, >= 3 stream b
 
 /* PARSE's serial part: from hypothesis 0 follow the `next` links while the hypotheses are usable and stay inside
  * the 64-lane window; T collects the real sequences, idx ends on the first position not taken.  A lane's word:
- * bits 0-5 next lane if the chain goes on from here, bit 7 it does not (hypothesis unusable, or next token outside
- * the window), bit 8 usable, bits 9.. next.  Scalar ISA by hand -- 4 instructions per sequence (mark, read, test,
- * branch), unrolled four times so that three of four branches fall through; s_bitset1 and v_readlane take the lane
- * from the low six bits of the word just read, so one v_readlane feeds the next directly.  The compiler's loop has
- * 14 instructions and two branches per sequence.  The lane the chain stops on is marked before it
+ * bits 0-5 next lane if the chain goes on from here, else the lane itself; bit 7 the chain ends here (hypothesis
+ * unusable, or next token outside the window), bit 8 usable, bits 9.. next.  Scalar ISA by hand, and without a branch
+ * in the loop-carried path: s_bitset1 and v_readlane take the lane from the low six bits of the word just read, so
+ * one v_readlane feeds the next directly, and a lane where the chain ends points at itself, so hopping on is
+ * harmless -- 24 hops (a window holds at most 22 sequences) are laid out straight, with an exit test after 8 and 16.
+ * The compiler's loop has 14 instructions and two branches per sequence.  The lane the chain stops on is marked before it
  * is known to be usable and unmarked afterwards if it was not. */
-__device__ __forceinline__ uint32_t token_word(bool fast, uint32_t next)
+__device__ __forceinline__ uint32_t token_word(bool fast, uint32_t next, int lane)
 {
-    return (fast && next < 64u ? next : 0x80u) | (fast ? 0x100u : 0u) | (next << 9);
+    return (fast && next < 64u ? next : (0x80u | (uint32_t)lane)) | (fast ? 0x100u : 0u) | (next << 9);
 }
 __device__ __forceinline__ void follow_tokens(uint32_t word, unsigned long long &T, uint32_t &idx)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t pk = 0;                                        /* a word's low six bits are the next lane: it selects the lane itself */
     T = 0;
+#define K4_HOP "s_bitset1_b64 %[T], %[pk]\n\ts_nop 2\n\tv_readlane_b32 %[pk], %[word], %[pk]\n\t"
+#define K4_HOP8 K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP
     asm volatile(
-        ".Ltok_next%=:\n\t"
-        "s_bitset1_b64 %[T], %[pk]\n\t"
-        "s_nop 0\n\t"                                        /* v_readlane wrote pk: 4 wait states before it selects a lane */
-        "v_readlane_b32 %[pk], %[word], %[pk]\n\t"
+        K4_HOP8
         "s_bitcmp1_b32 %[pk], 7\n\t"
         "s_cbranch_scc1 .Ltok_end%=\n\t"
-        "s_bitset1_b64 %[T], %[pk]\n\t"
-        "s_nop 0\n\t"                                        /* v_readlane wrote pk: 4 wait states before it selects a lane */
-        "v_readlane_b32 %[pk], %[word], %[pk]\n\t"
+        K4_HOP8
         "s_bitcmp1_b32 %[pk], 7\n\t"
         "s_cbranch_scc1 .Ltok_end%=\n\t"
-        "s_bitset1_b64 %[T], %[pk]\n\t"
-        "s_nop 0\n\t"                                        /* v_readlane wrote pk: 4 wait states before it selects a lane */
-        "v_readlane_b32 %[pk], %[word], %[pk]\n\t"
-        "s_bitcmp1_b32 %[pk], 7\n\t"
-        "s_cbranch_scc1 .Ltok_end%=\n\t"
-        "s_bitset1_b64 %[T], %[pk]\n\t"
-        "s_nop 0\n\t"                                        /* v_readlane wrote pk: 4 wait states before it selects a lane */
-        "v_readlane_b32 %[pk], %[word], %[pk]\n\t"
-        "s_bitcmp0_b32 %[pk], 7\n\t"
-        "s_cbranch_scc1 .Ltok_next%=\n"
+        K4_HOP8
         ".Ltok_end%=:"
         : [T] "+s"(T), [pk] "+s"(pk)
         : [word] "v"(word)
         : "scc");
+#undef K4_HOP8
+#undef K4_HOP
     const uint32_t last = 63u - (uint32_t)__builtin_clzll(T);
     if (pk & 0x100u) {
         idx = pk >> 9;
@@ -302,7 +293,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                     fast = fast && ext != 255u && (int64_t)ip + next < iend - LASTLITERALS + 1;
                 }
                 const uint32_t outlen = L + mlen;
-                const uint32_t packed = token_word(fast, next);
+                const uint32_t packed = token_word(fast, next, lane);
 
                 /* follow the true chain from hypothesis 0: one v_readlane per real sequence */
                 unsigned long long T = 0;
