@@ -408,6 +408,50 @@ def test_dispatch_variants_give_identical_bytes(oracle):
         assert np.array_equal(out, want) and np.array_equal(dst, ref_dst)
 
 
+def test_decoder_kernel_variants_give_identical_results(oracle):
+    """Which decoder kernel a batch gets is scheduling only: two waves per block (up to 16 blocks per CU), one wave
+    per block (K4LZ4_NO_PAIR=1, or up to 24 per CU), the dense build (more).  Same bytes and the same verdict on
+    damaged streams from all of them."""
+    import os
+    rng = np.random.default_rng(12)
+    blocks = [b for b in corpus.silesia_like_blocks(480, 8192, seed=13)]
+    blocks += [corpus.class_bytes("dickens", 70000, 3), corpus.lorem(3), np.zeros(0, np.uint8), corpus.repeated(9, 40000)]
+    enc = [np.frombuffer(oracle.encode(b), np.uint8).copy() if b.size else np.zeros(0, np.uint8) for b in blocks]
+    for i in range(0, 480, 7):                               # hostile: one byte changed
+        if enc[i].size > 8:
+            enc[i][int(rng.integers(0, enc[i].size))] ^= int(rng.integers(1, 256))
+    sizes = [b.size for b in blocks]
+
+    def run(batch_enc, batch_sizes):
+        src, soff, slen = pack_blocks(batch_enc)
+        caps = np.array(batch_sizes, np.int32)
+        dst, doff = make_arena(caps + 16, fill=0xCD)
+        out = LZ4Codec.DecodeBatchPacked(src, soff, slen, dst, doff, caps, flags=1)     # raw engine results
+        return out.copy(), dst.copy()
+
+    pair = run(enc, sizes)
+    os.environ["K4LZ4_NO_PAIR"] = "1"
+    try:
+        single = run(enc, sizes)
+    finally:
+        del os.environ["K4LZ4_NO_PAIR"]
+    assert np.array_equal(pair[0], single[0])
+    _, off = make_arena(np.array(sizes, np.int32) + 16)
+    for i, b in enumerate(blocks):
+        want, ref = oracle.decompress_safe(enc[i], b.size) if enc[i].size else (pair[0][i], None)
+        assert pair[0][i] == want, (i, int(pair[0][i]), want)
+        if want > 0:
+            a = pair[1][int(off[i]):int(off[i]) + want]
+            c = single[1][int(off[i]):int(off[i]) + want]
+            assert np.array_equal(a, ref[:want]) and np.array_equal(c, ref[:want]), i
+        for arr in (pair[1], single[1]):
+            assert (arr[int(off[i]) + b.size:int(off[i]) + b.size + 16] == 0xCD).all(), (i, "guard")
+    # the dense build: the same blocks 14 times over (> 24 blocks per CU)
+    many_enc, many_sizes = enc * 14, sizes * 14
+    dense = run(many_enc, many_sizes)
+    assert np.array_equal(dense[0], np.tile(pair[0], 14))
+
+
 # ---- PartialDecode (LZ4Codec.cs:123-173; reference test PartialDecodeTests) ---------------------
 @pytest.mark.parametrize("cls", ["dickens", "xml", "x-ray", "nci"])
 def test_partial_decode_matches_oracle(oracle, cls):
