@@ -57,8 +57,8 @@ enum k4lz4_level {
 enum k4lz4_flags {
     K4LZ4_FLAG_RAW_RETURN = 1,    /* outLen = LLxx-level return values */
     K4LZ4_FLAG_PICKLE_WRITER = 2, /* LZ4Pickler IBufferWriter path header rule (LZ4Pickler.pickle.cs:113-158) */
-    K4LZ4_FLAG_NO_REORDER = 4,    /* encode/pickle: dispatch blocks in index order instead of most-expensive-first */
-    K4LZ4_FLAG_REORDER = 8,       /* decode/unpickle: dispatch longest inputs first (useful for ragged batches) */
+    K4LZ4_FLAG_NO_REORDER = 4,    /* encode/pickle/unpickle: dispatch blocks in index order instead of most-expensive-first */
+    K4LZ4_FLAG_REORDER = 8,       /* decode: dispatch longest inputs first (useful for ragged batches; unpickle does it by default) */
     K4LZ4_FLAG_NO_SPLIT = 16,     /* encode: do not run part of the batch on the global-memory-table kernel */
     K4LZ4_FLAG_ALLOW_COPY = 64,   /* encode: LZ4EncoderBase.Encode(allowCopy) -- a block that does not shrink is stored raw, outLen = -srcLen;
                                      outLen = 0 where the reference throws "target buffer too small" (Encoders/LZ4EncoderBase.cs:66-88) */

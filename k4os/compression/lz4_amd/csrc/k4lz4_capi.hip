@@ -178,7 +178,10 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
     }
     /* cost-ordered dispatch (most expensive blocks first): encoders by default, decoders on request */
     const bool reorder = n > 1 &&
-                         (encode_like ? !(flags & K4LZ4_FLAG_NO_REORDER) : (flags & K4LZ4_FLAG_REORDER) != 0);
+                         (encode_like ? !(flags & K4LZ4_FLAG_NO_REORDER)
+                                      : ((flags & K4LZ4_FLAG_REORDER) != 0 ||
+                                         /* pickles are ragged by nature: start the long ones first unless told not to */
+                                         (kind == KIND_UNPICKLE && n > 64 && !(flags & K4LZ4_FLAG_NO_REORDER))));
     uint32_t *d_cost = nullptr, *d_order = nullptr, *d_hist = nullptr;
     if (reorder) {
         const size_t cnt_max = (size_t)std::min<int64_t>(chunk_max, n);

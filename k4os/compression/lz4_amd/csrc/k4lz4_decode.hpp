@@ -665,8 +665,9 @@ __device__ __forceinline__ void decode_kernel_body(const BatchArgs &a, uint32_t 
 {
     const int lane = lane_id();
     const uint32_t wave = uni(threadIdx.x >> 6);
-    const long long b = (long long)blockIdx.x * DECODE_WAVES_PER_WG + (long long)wave;
-    if (b >= a.n) return;
+    const long long slot = (long long)blockIdx.x * DECODE_WAVES_PER_WG + (long long)wave;
+    if (slot >= a.n) return;
+    const long long b = a.order ? (long long)uni(a.order[slot]) : slot;    /* K4LZ4_FLAG_REORDER: longest first */
     const int src_len = a.srcLen[b];
     const int cap = a.dstCap[b];
     const uint8_t *in = a.src + a.srcOff[b];
@@ -693,11 +694,12 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
     const int lane = lane_id();
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t pair = wave >> 1, role = wave & 1u;
-    const long long b = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
+    const long long slot = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
     uint32_t *ring = lds[pair], *pipe = lds[pair] + RING_DWORDS;
     if (lane < 8 && role == 0) pipe[lane] = 0u;             /* head, tail */
     __syncthreads();
-    if (b >= a.n) return;
+    if (slot >= a.n) return;
+    const long long b = a.order ? (long long)uni(a.order[slot]) : slot;
     const int src_len = a.srcLen[b];
     const int cap = a.dstCap[b];
     const uint8_t *in = a.src + a.srcOff[b];

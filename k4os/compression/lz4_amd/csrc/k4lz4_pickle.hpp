@@ -145,8 +145,9 @@ __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_unpickle_kernel(B
     __shared__ uint32_t lds[DECODE_WAVES_PER_WG][DECODE_LDS_DWORDS];
     const int lane = lane_id();
     const uint32_t wave = uni(threadIdx.x >> 6);
-    const long long b = (long long)blockIdx.x * DECODE_WAVES_PER_WG + (long long)wave;
-    if (b >= a.n) return;
+    const long long slot = (long long)blockIdx.x * DECODE_WAVES_PER_WG + (long long)wave;
+    if (slot >= a.n) return;
+    const long long b = a.order ? (long long)uni(a.order[slot]) : slot;    /* longest envelope first */
     const int r = unpickle_block(a.src + a.srcOff[b], a.srcLen[b], a.dst + a.dstOff[b], a.dstCap[b], lane, lds[wave]);
     if (lane == 0) a.outLen[b] = r;
 }
