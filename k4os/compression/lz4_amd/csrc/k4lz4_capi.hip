@@ -263,7 +263,10 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
             hipLaunchKernelGGL(k4::k4_pickle_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a);
             break;
         case KIND_UNPICKLE:
-            hipLaunchKernelGGL(k4::k4_unpickle_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
+            if (cnt <= 64 * (int64_t)ctx->cu_count && !getenv("K4LZ4_NO_PAIR"))
+                hipLaunchKernelGGL(k4::k4_unpickle_pair_kernel, dim3((unsigned)((cnt + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
+                                   dim3(128 * k4::DECODE_PAIRS_PER_WG), 0, stream, a);
+            else hipLaunchKernelGGL(k4::k4_unpickle_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
             break;
         }
         if (kind == KIND_ENCODE && (flags & K4LZ4_FLAG_ALLOW_COPY))

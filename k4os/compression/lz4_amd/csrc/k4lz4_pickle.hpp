@@ -111,7 +111,9 @@ __device__ __forceinline__ PickleHeader unpickle_header(const uint8_t *src, int 
 
 /* Unpickle(source, output): returns the unpickled size (== cap), 0 for an empty pickle,
  * -1 where the reference throws (unpickle.cs:115-128,:134,:143-144) */
-__device__ __forceinline__ int unpickle_block(const uint8_t *src, int len, uint8_t *dst, int cap, int lane, uint32_t *lds)
+template <int ROLE = 0>
+__device__ __forceinline__ int unpickle_block(const uint8_t *src, int len, uint8_t *dst, int cap, int lane, uint32_t *lds,
+                                              uint32_t *pipe = nullptr)
 {
     if (len == 0) return 0;
     const PickleHeader h = unpickle_header(src, len);
@@ -119,12 +121,13 @@ __device__ __forceinline__ int unpickle_block(const uint8_t *src, int len, uint8
     if (cap != h.result_len) return -1;
     const int data_len = len - h.data_offset;
     if (!h.compressed) {
-        wave_copy(dst, src + h.data_offset, (uint32_t)data_len, lane);
+        if (ROLE != 1) wave_copy(dst, src + h.data_offset, (uint32_t)data_len, lane);
         return h.result_len;
     }
     int decoded = 0;                                        /* LZ4Codec.Decode: empty -> 0 */
     if (data_len > 0) {
-        decoded = decode_block(src + h.data_offset, data_len, dst, cap, lane, lds);
+        decoded = decode_block<false, ROLE>(src + h.data_offset, data_len, dst, cap, lane, lds, nullptr, false,
+                                            DecodeDict{nullptr, 0u, 0}, pipe);
         if (decoded <= 0) decoded = -1;
     }
     return decoded == h.result_len ? decoded : -1;
@@ -150,6 +153,32 @@ __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_unpickle_kernel(B
     const long long b = a.order ? (long long)uni(a.order[slot]) : slot;    /* longest envelope first */
     const int r = unpickle_block(a.src + a.srcOff[b], a.srcLen[b], a.dst + a.dstOff[b], a.dstCap[b], lane, lds[wave]);
     if (lane == 0) a.outLen[b] = r;
+}
+
+/* Pickles are ragged (1 KiB .. 4 MiB in BASELINE configs[3]) and, started longest first, the call lasts as long as
+ * its biggest message: the two waves per message of k4_decode_pair_kernel shorten exactly that. */
+__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_waves_per_eu(4, 8))) void k4_unpickle_pair_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
+    const int lane = lane_id();
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t pair = wave >> 1, role = wave & 1u;
+    const long long slot = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
+    uint32_t *ring = lds[pair], *pipe = lds[pair] + RING_DWORDS;
+    if (lane < 8 && role == 0) pipe[lane] = 0u;
+    __syncthreads();
+    if (slot >= a.n) return;
+    const long long b = a.order ? (long long)uni(a.order[slot]) : slot;
+    const int len = a.srcLen[b];
+    const uint8_t *src = a.src + a.srcOff[b];
+    uint8_t *dst = a.dst + a.dstOff[b];
+    const int cap = a.dstCap[b];
+    if (role == 0) {
+        unpickle_block<1>(src, len, dst, cap, lane, ring, pipe);
+    } else {
+        const int r = unpickle_block<2>(src, len, dst, cap, lane, ring, pipe);
+        if (lane == 0) a.outLen[b] = r;
+    }
 }
 
 /* HC levels: the block encoder runs as its own kernels between these two.

@@ -116,6 +116,19 @@ int k4emu_unpickle_batch(const uint8_t *src, const uint64_t *srcOff, const int32
     return 0;
 }
 
+int k4emu_unpickle_pair_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                              const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int flags,
+                              int threads)
+{
+    k4::BatchArgs a{};
+    a.src = src; a.srcOff = srcOff; a.srcLen = srcLen; a.dst = dst; a.dstOff = dstOff; a.dstCap = dstCap;
+    a.outLen = outLen; a.n = n; a.accel = 1; a.flags = flags;
+    if (n <= 0) return 0;
+    unsigned grid = (unsigned)((n + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG);
+    k4emu::launch_fn(dim3(grid), dim3(128 * k4::DECODE_PAIRS_PER_WG), [=] { k4::k4_unpickle_pair_kernel(a); }, threads);
+    return 0;
+}
+
 int k4emu_unpickle_sizes(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, int32_t *outLen,
                          long long n, int threads)
 {

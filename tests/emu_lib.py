@@ -62,6 +62,7 @@ class Emu:
         self.lib.k4emu_order.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         self.lib.k4emu_pickle_batch.argtypes = b + [C.c_int, C.c_int, C.c_int]
         self.lib.k4emu_unpickle_batch.argtypes = b + [C.c_int, C.c_int]
+        self.lib.k4emu_unpickle_pair_batch.argtypes = b + [C.c_int, C.c_int]
         self.lib.k4emu_unpickle_sizes.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int]
 
     @staticmethod
@@ -100,7 +101,7 @@ class Emu:
 
     def unpickle_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, flags=0, threads=0):
         out = np.full(len(src_len), -12345, dtype=np.int32)
-        rc = self.lib.k4emu_unpickle_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
+        rc = (self.lib.k4emu_unpickle_pair_batch if self.pair else self.lib.k4emu_unpickle_batch)(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
                                            dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data,
                                            len(src_len), flags, threads)
         assert rc == 0

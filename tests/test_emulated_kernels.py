@@ -520,7 +520,8 @@ def emu_pair(emu):
                                   test_decode_malformed_parity_with_oracle, test_decode_special_cases,
                                   test_decode_all_classes_various_sizes, test_decode_hostile_streams_random,
                                   test_partial_decode_matches_oracle, test_decode_with_dictionary_issue64_and_synthetic,
-                                  test_decode_random_stress], ids=lambda f: f.__name__)
+                                  test_decode_random_stress, test_pickle_matches_oracle, test_unpickle_corruption],
+                         ids=lambda f: f.__name__)
 def test_pair_kernel_passes_the_decoder_tests(case, emu_pair, oracle):
     """every decoder test above, run once more through the two-waves-per-block kernel"""
     case(emu_pair, oracle)
