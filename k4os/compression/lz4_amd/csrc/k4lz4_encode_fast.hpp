@@ -30,8 +30,8 @@ template <int TYPE> struct FastTable;
 template <> struct FastTable<1> {   /* byU16: 8192 x u16, hash4 >> 19 (LL.tools.cs:46-51) */
     uint16_t *t;
     __device__ __forceinline__ static uint32_t hash(const uint8_t *p) { return (ld32u(p) * 2654435761u) >> (32 - 13); }
-    /* same hash from bytes already in registers: seq = bytes p..p+3, next = bytes p+4..p+11 */
-    __device__ __forceinline__ static uint32_t hash_of(uint32_t seq, uint64_t) { return (seq * 2654435761u) >> (32 - 13); }
+    /* same hash from bytes already in registers: seq = bytes p..p+3, n0 = bytes p+4..p+7 */
+    __device__ __forceinline__ static uint32_t hash_of(uint32_t seq, uint32_t) { return (seq * 2654435761u) >> (32 - 13); }
     __device__ __forceinline__ uint32_t get(uint32_t h) const { return t[h]; }
     __device__ __forceinline__ void put(uint32_t h, uint32_t pos) const { t[h] = (uint16_t)pos; }
 };
@@ -41,9 +41,9 @@ template <> struct FastTable<0> {  /* byU32: 4096 x u32, hash5 (LL.tools.cs:53-5
     {
         return (uint32_t)(((ld64u(p) << 24) * 889523592379ull) >> (64 - 12));
     }
-    __device__ __forceinline__ static uint32_t hash_of(uint32_t seq, uint64_t next)
+    __device__ __forceinline__ static uint32_t hash_of(uint32_t seq, uint32_t n0)   /* five bytes: seq and the low byte of n0 */
     {
-        return (uint32_t)((((next << 32) | seq) << 24) * 889523592379ull >> (64 - 12));
+        return (uint32_t)((((((uint64_t)n0) << 32) | seq) << 24) * 889523592379ull >> (64 - 12));
     }
     __device__ __forceinline__ uint32_t get(uint32_t h) const { return t[h]; }
     __device__ __forceinline__ void put(uint32_t h, uint32_t pos) const { t[h] = pos; }
@@ -51,7 +51,7 @@ template <> struct FastTable<0> {  /* byU32: 4096 x u32, hash5 (LL.tools.cs:53-5
 template <> struct FastTable<2> {  /* byU32: 4096 x u32, hash4 >> 20: x32/LL32.tools.cs:141-148 has no hash5 arm; x32/LL32.fast.cs:543-545 */
     uint32_t *t;
     __device__ __forceinline__ static uint32_t hash(const uint8_t *p) { return (ld32u(p) * 2654435761u) >> (32 - 12); }
-    __device__ __forceinline__ static uint32_t hash_of(uint32_t seq, uint64_t) { return (seq * 2654435761u) >> (32 - 12); }
+    __device__ __forceinline__ static uint32_t hash_of(uint32_t seq, uint32_t) { return (seq * 2654435761u) >> (32 - 12); }
     __device__ __forceinline__ uint32_t get(uint32_t h) const { return t[h]; }
     __device__ __forceinline__ void put(uint32_t h, uint32_t pos) const { t[h] = pos; }
 };
@@ -101,7 +101,8 @@ __device__ __forceinline__ void emit_length_run(uint8_t *dst, uint32_t op, uint3
 /* the 16 source bytes around position p: 4 before, the 4 compared ones, 8 after */
 struct Around {
     uint32_t pre, seq;
-    uint64_t next;
+    uint32_t n0, n1;           /* the 8 bytes after seq, as two words: a merged 12-byte load then needs no aligned register
+                                * pair, hence no copy that would have to wait for the load right where it was issued */
     bool pre_ok;
 };
 __device__ __forceinline__ Around load_around(const uint8_t *src, uint32_t p)
@@ -110,9 +111,9 @@ __device__ __forceinline__ Around load_around(const uint8_t *src, uint32_t p)
     a.pre_ok = p >= 4u;
     if (a.pre_ok) {
         const U128u v = ld128u(src + p - 4u);
-        a.pre = v.v[0]; a.seq = v.v[1]; a.next = ((uint64_t)v.v[3] << 32) | v.v[2];
+        a.pre = v.v[0]; a.seq = v.v[1]; a.n0 = v.v[2]; a.n1 = v.v[3];
     } else {
-        a.pre = 0; a.seq = ld32u(src + p); a.next = ld64u(src + p + 4u);
+        a.pre = 0; a.seq = ld32u(src + p); a.n0 = ld32u(src + p + 4u); a.n1 = ld32u(src + p + 8u);
     }
     return a;
 }
@@ -122,11 +123,11 @@ __device__ __forceinline__ unsigned long long geq_of(uint32_t q) { return ~0ull 
 /* What the 16+16 bytes around a position and its candidate say about the match extension:
  * bits 0-3 forward bytes beyond MINMATCH (0..8, capped at fwd_max), bits 4-6 equal bytes backwards
  * (0..4), 0x100 forward run continues past the 8 known bytes, 0x200 the 4 bytes before both are known */
-__device__ __forceinline__ uint32_t extension_info(uint32_t a_pre, uint64_t a_next, bool a_ok, uint32_t b_pre, uint64_t b_next,
-                                                   bool b_ok, uint32_t fwd_max)
+__device__ __forceinline__ uint32_t extension_info(uint32_t a_pre, uint32_t a_n0, uint32_t a_n1, bool a_ok, uint32_t b_pre, uint32_t b_n0,
+                                                   uint32_t b_n1, bool b_ok, uint32_t fwd_max)
 {
-    const uint64_t x = a_next ^ b_next;
-    const uint32_t e = x ? (uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3 : 8u;
+    const uint32_t x0 = a_n0 ^ b_n0, x1 = a_n1 ^ b_n1;
+    const uint32_t e = x0 ? (uint32_t)(__ffs((int)x0) - 1) >> 3 : (x1 ? 4u + ((uint32_t)(__ffs((int)x1) - 1) >> 3) : 8u);
     const uint32_t c8 = e < fwd_max ? e : fwd_max;
     const bool ok = a_ok && b_ok;
     const uint32_t y = a_pre ^ b_pre;
@@ -269,8 +270,10 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 npos = sbase_n + probe_offset(j + 1u, accel);
             }
             valid_n = t0 || (npos <= mflimit_plus_one && npos >= sbase_n);   /* :172 */
-            pa_n.pre = 0; pa_n.seq = 0; pa_n.next = 0; pa_n.pre_ok = false;
-            if (valid_n) pa_n = load_around(src, pos_n);
+            /* unconditional (an invalid lane reads the block's first bytes and nobody looks at them): a load inside a
+             * predicated region gets its result copied into the merged registers right there, and the copy waits for it --
+             * the loads would not fly during commit and emission at all */
+            pa_n = load_around(src, valid_n ? pos_n : 0u);
         };
         prepare();
 
@@ -294,13 +297,13 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             uint32_t h = 0, cand = 0;
             bool flagged = false;              /* another lane of this window has the same hash (at least one lane of every group sees it) */
             if (valid) {
-                h = Table::hash_of(pa.seq, pa.next);
+                h = Table::hash_of(pa.seq, pa.n0);
                 cand = tab.get(h);
                 flagged = ((atomicOr(&seen[h >> 5], 1u << (h & 31u)) >> (h & 31u)) & 1u) != 0u;
             }
             const Around ca = load_around(src, cand);
             const bool hit_tab = valid && (BYU16 || cand + (uint32_t)DISTANCE_MAX >= pos) && ca.seq == pa.seq;
-            const uint32_t info = extension_info(pa.pre, pa.next, pa.pre_ok, ca.pre, ca.next, ca.pre_ok, matchlimit - (pos + MINMATCH));
+            const uint32_t info = extension_info(pa.pre, pa.n0, pa.n1, pa.pre_ok, ca.pre, ca.n0, ca.n1, ca.pre_ok, matchlimit - (pos + MINMATCH));
 
             /* ---------------- groups: lanes of the window with equal hashes ---------------- */
             unsigned long long G = me;
@@ -338,13 +341,13 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 const int j = eff ? 63 - (int)__clzll((long long)eff) : -1;
                 const int sj = j & 63;
                 const uint32_t vj = (uint32_t)__shfl((int)pa.seq, sj), pj = (uint32_t)__shfl((int)pa.pre, sj);
-                const uint32_t nlo = (uint32_t)__shfl((int)(uint32_t)pa.next, sj), nhi = (uint32_t)__shfl((int)(uint32_t)(pa.next >> 32), sj);
+                const uint32_t nlo = (uint32_t)__shfl((int)pa.n0, sj), nhi = (uint32_t)__shfl((int)pa.n1, sj);
                 const uint32_t posj = (uint32_t)__shfl((int)pos, sj);
                 const bool okj = ((preok_m >> sj) & 1ull) != 0;
                 if (j >= 0) {
                     chit = valid && vj == pa.seq;
                     cpos = posj;
-                    cinfo = extension_info(pa.pre, pa.next, pa.pre_ok, pj, ((uint64_t)nhi << 32) | nlo, okj, fwd_max);
+                    cinfo = extension_info(pa.pre, pa.n0, pa.n1, pa.pre_ok, pj, nlo, nhi, okj, fwd_max);
                 } else {
                     chit = hit_tab;
                     cpos = cand;
@@ -514,7 +517,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                     test = false;
                 }
             }
-            if (outcome != 2) prepare();
+            prepare();                                      /* also when the block ends here: every lane is invalid then and reads offset 0 */
 
             /* ---------------- commit the visited positions, one writer per hash ---------------- */
             const unsigned long long t2 = prof_now<PROF>();
