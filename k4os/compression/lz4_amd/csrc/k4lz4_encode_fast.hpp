@@ -469,6 +469,25 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             sequences += k;
             if (PROF) n_seq += k;
 
+            /* ---------------- where the next round starts; its source loads go out now ---------------- */
+            if (outcome == 1) {
+                ip = anchor;
+                test = true;
+                jbase = 0;
+            } else if (outcome == 0) {
+                if (contig) {
+                    const uint32_t qs = q + (q_test ? 1u : 0u);     /* lane where the running search started */
+                    sbase = ip0 + qs;
+                    jbase = 64u - qs;
+                    test = false;
+                    ip = sbase;
+                } else {
+                    jbase += 64u - shift;
+                    test = false;
+                }
+            }
+            prepare();                                      /* also when the block ends here: every lane is invalid then and reads offset 0 */
+
             /* per hit lane: literal run, backward extension (:237-242), the sequence's numbers */
             const bool mine = ((hits >> lane) & 1ull) != 0ull;
             uint32_t r_ls = 0, r_ll = 0, r_off = 0, r_mc = 0, r_cq = 0, r_back = 0;
@@ -500,25 +519,6 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 const uint32_t code = xcode != 0xffffffffu ? xcode : (cinfo & 15u);
                 r_ls = anchor_l; r_ll = lit0 - back; r_off = pos - cpos; r_mc = code + back; r_cq = cq; r_back = back;
             }
-            /* ---------------- where the next round starts; its source loads go out now ---------------- */
-            if (outcome == 1) {
-                ip = anchor;
-                test = true;
-                jbase = 0;
-            } else if (outcome == 0) {
-                if (contig) {
-                    const uint32_t qs = q + (q_test ? 1u : 0u);     /* lane where the running search started */
-                    sbase = ip0 + qs;
-                    jbase = 64u - qs;
-                    test = false;
-                    ip = sbase;
-                } else {
-                    jbase += 64u - shift;
-                    test = false;
-                }
-            }
-            prepare();                                      /* also when the block ends here: every lane is invalid then and reads offset 0 */
-
             /* ---------------- commit the visited positions, one writer per hash ---------------- */
             const unsigned long long t2 = prof_now<PROF>();
             if (PROF) c_s4 += t2 - tb;
