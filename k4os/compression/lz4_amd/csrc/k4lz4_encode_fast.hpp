@@ -288,9 +288,11 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             const uint32_t pos = pos_n;
             const bool valid = valid_n;
             const Around pa = pa_n;
-            if (shift) {
-                const uint32_t h2 = Table::hash(src + ip - 2);
-                if (lane == 0) tab.put(h2, ip - 2u);                /* :394 */
+            if (shift && lane == 0) {
+                /* :394 -- the put of ip - 2.  Lane 0 probes ip itself and holds the 4 bytes before it: the bytes at
+                 * ip - 2 come out of its registers, not out of another trip to memory at the top of every such round */
+                const uint32_t seq2 = (pa.pre >> 16) | (pa.seq << 16), n2 = (pa.seq >> 16) | (pa.n0 << 16);
+                tab.put(Table::hash_of(seq2, n2), ip - 2u);
             }
             wave_sync();
             if (PROF) { n_round++; }
