@@ -303,9 +303,8 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 cand = tab.get(h);
                 flagged = ((atomicOr(&seen[h >> 5], 1u << (h & 31u)) >> (h & 31u)) & 1u) != 0u;
             }
-            const Around ca = load_around(src, cand);
-            const bool hit_tab = valid && (BYU16 || cand + (uint32_t)DISTANCE_MAX >= pos) && ca.seq == pa.seq;
-            const uint32_t info = extension_info(pa.pre, pa.n0, pa.n1, pa.pre_ok, ca.pre, ca.n0, ca.n1, ca.pre_ok, matchlimit - (pos + MINMATCH));
+            const Around ca = load_around(src, cand);       /* the round's one dependent trip to memory: everything below that
+                                                             * does not need the candidate bytes runs while it is under way */
 
             /* ---------------- groups: lanes of the window with equal hashes ---------------- */
             unsigned long long G = me;
@@ -328,6 +327,15 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             const unsigned long long inv_m = __ballot(!valid), preok_m = __ballot(pa.pre_ok);
             const uint32_t fwd_max = matchlimit - (pos + MINMATCH);
             const uint32_t anchor_in = anchor;
+            /* the common group is a pair: the later lane's candidate is the earlier lane while that one counts
+             * as visited, else the table entry -- both known up front, so losing a candidate is a select */
+            const unsigned long long gb = G & below_me;
+            const int j1 = gb ? 63 - (int)__clzll((long long)gb) : -1;
+            const unsigned long long multi_m = __ballot((gb & (gb - 1ull)) != 0ull);
+            const unsigned long long cand0 = __ballot((G & ~(below_me | me)) != 0ull);
+            /* now the candidate bytes */
+            const bool hit_tab = valid && (BYU16 || cand + (uint32_t)DISTANCE_MAX >= pos) && ca.seq == pa.seq;
+            const uint32_t info = extension_info(pa.pre, pa.n0, pa.n1, pa.pre_ok, ca.pre, ca.n0, ca.n1, ca.pre_ok, fwd_max);
             /* per lane: the candidate as the table and the visited positions of this round define it */
             uint32_t cpos = cand, cinfo = info;
             bool chit = hit_tab;
@@ -337,7 +345,6 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             /* candidate lanes (lanes with a later lane in their group) that ended up inside a match: they were never put.
              * Every such lane is recorded when the chain covers it, so for candidates this mask says all `skipped` would */
             unsigned long long lost_cands = 0;
-            const unsigned long long cand0 = __ballot((G & ~(below_me | me)) != 0ull);
             auto candidates = [&]() {          /* general form: highest visited-or-future lane of the group below this one */
                 const unsigned long long eff = G & below_me & ~lost_cands;
                 const int j = eff ? 63 - (int)__clzll((long long)eff) : -1;
@@ -388,11 +395,6 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 skipped = __ballot(in && (uint32_t)lane + 2u != qp);
                 cursors = 1ull | __ballot(hb != 0ull && (uint32_t)lane == qp);
             };
-            /* the common group is a pair: the later lane's candidate is the earlier lane while that one counts
-             * as visited, else the table entry -- both known up front, so losing a candidate is a select */
-            const unsigned long long gb = G & below_me;
-            const int j1 = gb ? 63 - (int)__clzll((long long)gb) : -1;
-            const unsigned long long multi_m = __ballot((gb & (gb - 1ull)) != 0ull);
             bool hit1 = hit_tab, general = false;
             uint32_t pos1 = cand, info1 = info;
             if (dirty) {
