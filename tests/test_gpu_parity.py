@@ -422,14 +422,16 @@ def test_decoder_kernel_variants_give_identical_results(oracle):
             enc[i][int(rng.integers(0, enc[i].size))] ^= int(rng.integers(1, 256))
     sizes = [b.size for b in blocks]
 
-    def run(batch_enc, batch_sizes):
+    def run(batch_enc, batch_sizes, flags=1):                 # 1 = raw engine results
         src, soff, slen = pack_blocks(batch_enc)
         caps = np.array(batch_sizes, np.int32)
         dst, doff = make_arena(caps + 16, fill=0xCD)
-        out = LZ4Codec.DecodeBatchPacked(src, soff, slen, dst, doff, caps, flags=1)     # raw engine results
+        out = LZ4Codec.DecodeBatchPacked(src, soff, slen, dst, doff, caps, flags=flags)
         return out.copy(), dst.copy()
 
     pair = run(enc, sizes)
+    longest_first = run(enc, sizes, flags=1 | 8)             # K4LZ4_FLAG_REORDER: dispatch order only
+    assert np.array_equal(pair[0], longest_first[0]) and np.array_equal(pair[1], longest_first[1])
     os.environ["K4LZ4_NO_PAIR"] = "1"
     try:
         single = run(enc, sizes)
