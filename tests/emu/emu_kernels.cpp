@@ -138,6 +138,19 @@ int k4emu_unpickle_sizes(const uint8_t *src, const uint64_t *srcOff, const int32
     return 0;
 }
 
+/* unit test of the per-lane run copies (k4lz4_common.hpp): lane l moves len[l] bytes src+soff[l] -> dst+doff[l];
+ * mode 0 lane_copy32 (any memory), 1 lane_move32_slack (8 readable bytes past either end of the source) */
+int k4emu_lane_copy(const uint8_t *src, const uint32_t *soff, uint8_t *dst, const uint32_t *doff, const uint32_t *len,
+                    uint32_t src_size, int mode)
+{
+    k4emu::launch_fn(dim3(1), dim3(64), [=] {
+        const int lane = k4::lane_id();
+        if (mode == 0) k4::lane_copy32(dst + doff[lane], src + soff[lane], len[lane], src_size - soff[lane]);
+        else if (len[lane]) k4::lane_move32_slack(dst + doff[lane], src + soff[lane], len[lane]);
+    }, 1);
+    return 0;
+}
+
 int k4emu_xxh32_batch(const uint8_t *data, const uint64_t *off, const uint64_t *len, uint32_t *out, long long n,
                       uint32_t seed, int threads)
 {

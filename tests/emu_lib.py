@@ -139,6 +139,12 @@ class Emu:
         assert rc == 0
         return out
 
+    def lane_copy(self, src, soff, dst, doff, length, mode):
+        self.lib.k4emu_lane_copy.argtypes = [_u8p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+        rc = self.lib.k4emu_lane_copy(self._p(src), soff.ctypes.data, self._p(dst), doff.ctypes.data, length.ctypes.data,
+                                      src.size, mode)
+        assert rc == 0
+
     def xxh32_batch(self, data, off, length, seed=0, threads=0):
         out = np.zeros(len(off), dtype=np.uint32)
         rc = self.lib.k4emu_xxh32_batch(self._p(data), off.ctypes.data, length.ctypes.data, out.ctypes.data, len(off), seed, threads)

@@ -525,3 +525,29 @@ def emu_pair(emu):
 def test_pair_kernel_passes_the_decoder_tests(case, emu_pair, oracle):
     """every decoder test above, run once more through the two-waves-per-block kernel"""
     case(emu_pair, oracle)
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["lane_copy32", "lane_move32_slack"])
+def test_lane_run_copies_every_length_and_alignment(emu, mode):
+    """k4lz4_common.hpp LaneRun / lane_move32_slack: chunks plus an overlapping last word, no byte tails -- every length
+    0..32 at every source and destination alignment, nothing outside [d, d + len) touched; lane_copy32 also with the
+    source ending exactly where the run ends (no read past it)"""
+    rng = np.random.default_rng(8)
+    for trial in range(40):
+        length = np.array([(l + trial) % 33 for l in range(64)], np.uint32)
+        sal, dal = rng.integers(0, 8, 64), rng.integers(0, 8, 64)
+        soff = (np.arange(64) * 48 + sal).astype(np.uint32)
+        doff = (np.arange(64) * 64 + 16 + dal).astype(np.uint32)
+        if mode == 0:
+            # pack the runs back to back at the very end of the source buffer for the last lanes: readable == len there
+            size = int(soff[-1] + length[-1])
+        else:
+            size = int(soff[-1] + 32 + 8)
+        src = rng.integers(0, 256, size, dtype=np.uint8)
+        dst = np.full(64 * 64 + 64, 0xCD, np.uint8)
+        emu.lane_copy(src, soff, dst, doff, length, mode)
+        want = np.full_like(dst, 0xCD)
+        for l in range(64):
+            n = int(length[l])
+            want[int(doff[l]):int(doff[l]) + n] = src[int(soff[l]):int(soff[l]) + n]
+        assert np.array_equal(dst, want), (trial, int(np.argmax(dst != want)))
