@@ -716,7 +716,11 @@ int k4lz4_decode_chain_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const ui
     K4_HIP(ctx, hipSetDevice(ctx->device));
     k4::ChainArgs a{src, blkOff, blkLen, firstBlk, nBlk, blockSize, chained, dst, dstOff, dstCap, (long long *)outLen, nStreams};
     const unsigned grid = (unsigned)((nStreams + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
-    hipLaunchKernelGGL(k4::k4_decode_chain_kernel, dim3(grid), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, (hipStream_t)stream, a);
+    if (nStreams <= 16 * (int64_t)ctx->cu_count && !getenv("K4LZ4_NO_PAIR"))    /* room for two waves per stream */
+        hipLaunchKernelGGL(k4::k4_decode_chain_pair_kernel, dim3((unsigned)((nStreams + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
+                           dim3(128 * k4::DECODE_PAIRS_PER_WG), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(k4::k4_decode_chain_kernel, dim3(grid), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, (hipStream_t)stream, a);
     K4_HIP(ctx, hipGetLastError());
     return K4LZ4_OK;
 }

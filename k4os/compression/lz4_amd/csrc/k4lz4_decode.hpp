@@ -195,7 +195,8 @@ __device__ __forceinline__ bool pipe_wait(const uint32_t *p, uint32_t want)
 template <bool PROF = false, int ROLE = 0>
 __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uint8_t *out, int out_size, int lane,
                                             uint32_t *lds, unsigned long long *pc = nullptr, bool partial = false,
-                                            DecodeDict dict = DecodeDict{nullptr, 0u, 0}, uint32_t *pipe = nullptr)
+                                            DecodeDict dict = DecodeDict{nullptr, 0u, 0}, uint32_t *pipe = nullptr,
+                                            uint32_t *seq = nullptr)
 {
     /* lowPrefix relative to out (<= 0), the size used by the offset check (:149,:338) */
     const int64_t low_prefix = dict.mode == 1 ? -(int64_t)dict.size : 0;
@@ -223,7 +224,9 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     /* MATCHES sorts destination ranges in two arrays: the descriptor arrays themselves when one wave does it all */
     uint32_t *w_out = ROLE == 0 ? d_out : pipe + PIPE_SCRATCH, *w_end = ROLE == 0 ? d_llen : pipe + PIPE_SCRATCH + 64;
     uint8_t *const stage_base = ROLE == 0 ? (uint8_t *)(d_mlen + 64) : (uint8_t *)(pipe + PIPE_STAGE);
-    uint32_t batch_no = 0;                                  /* ROLE 1/2: batches published / taken so far */
+    /* ROLE 1/2: batches published / taken so far.  A pair that decodes several blocks one after the other (linked frames)
+     * keeps counting in *seq, so the parsing wave can be blocks ahead of the copying one */
+    uint32_t batch_no = (ROLE != 0 && seq) ? *seq : 0u;
 
     const int64_t iend = src_size;
     const int64_t oend = out_size;
@@ -474,8 +477,10 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             }
             pipe_store(pipe + 0, batch_no + 1u, lane);
             batch_no++;
-            if (err) return err;
-            if (done) return (int)op;
+            if (err || done) {
+                if (seq) *seq = batch_no;
+                return err ? err : (int)op;
+            }
             continue;
         }
         if (ROLE == 0 && err) return err;
@@ -624,7 +629,10 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             const unsigned long long t3 = prof_now<PROF>();
             c_parse += t1 - t0; c_lit += t2 - t1; c_match += t3 - t2; n_batch++; n_seq += (unsigned long long)nseq;
         }
-        if (ROLE == 2 && done) return err;                  /* the result the parsing wave arrived at */
+        if (ROLE == 2 && done) {                            /* the result the parsing wave arrived at */
+            if (seq) *seq = batch_no;
+            return err;
+        }
         if (done) break;
     }
     if (PROF && pc && lane == 0) {

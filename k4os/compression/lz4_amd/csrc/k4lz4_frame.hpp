@@ -96,6 +96,64 @@ __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_decode_chain_kern
 }
 
 
+/* The same with two waves per stream (see k4_decode_pair_kernel): the parsing wave walks the stream's blocks on its own --
+ * what it needs of a block's outcome, the decoded size, it computes itself -- and may be several blocks ahead of the
+ * wave that copies; both make the same decisions about stored blocks, full targets and failures from the same numbers. */
+__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_waves_per_eu(4, 8))) void k4_decode_chain_pair_kernel(ChainArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
+    const int lane = lane_id();
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t pair = wave >> 1, role = wave & 1u;
+    const long long s = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
+    uint32_t *ring = lds[pair], *pipe = lds[pair] + RING_DWORDS;
+    if (lane < 8 && role == 0) pipe[lane] = 0u;
+    __syncthreads();
+    if (s >= a.n) return;
+    uint8_t *out = a.dst + a.dstOff[s];
+    const uint64_t cap = a.dstCap[s];
+    const uint64_t first = a.firstBlk[s];
+    const uint32_t count = a.nBlk[s];
+    const int block_size = a.blockSize[s];
+    const bool chained = a.chained[s] != 0;
+    uint64_t op = 0;
+    long long result = 0;
+    uint32_t seq = 0;
+    for (uint32_t k = 0; k < count; k++) {
+        const uint32_t lc = a.blkLen[first + k];
+        const uint32_t n = lc & 0x7fffffffu;
+        const uint8_t *in = a.src + a.blkOff[first + k];
+        const uint64_t room = cap - op;
+        if (lc & 0x80000000u) {                                  /* LZ4BlockDecoder.Inject */
+            if (n > room) { result = -9; break; }
+            if (role == 1) {
+                wave_sync();
+                wave_copy(out + op, in, n, lane);
+            }
+            op += n;
+        } else {
+            const int want = (int)(room < (uint64_t)block_size ? room : (uint64_t)block_size);
+            DecodeDict dict{nullptr, 0u, 0};
+            if (chained && op > 0) {
+                dict.end = out + op;
+                dict.size = op >= 65535u ? 65536u : (uint32_t)op;
+                dict.mode = 1;
+            }
+            int d;
+            if (role == 0) {
+                d = decode_block<false, 1>(in, (int)n, out + op, want, lane, ring, nullptr, false, dict, pipe, &seq);
+            } else {
+                wave_sync();                                     /* the previous block's stores -> this block's loads */
+                d = decode_block<false, 2>(in, (int)n, out + op, want, lane, ring, nullptr, false, dict, pipe, &seq);
+            }
+            if (d < 0) { result = room < (uint64_t)block_size ? -9 : -6; break; }
+            op += (uint64_t)d;
+        }
+    }
+    if (role == 1 && lane == 0) a.outLen[s] = result < 0 ? result : (long long)op;
+}
+
+
 /* ---- frame writer on the device (Frames/LZ4FrameWriter.async.cs:15-27 per block, :75-90 tail; LZ4FrameWriter.cs:57-108
  * header).  The host lays out WHERE things go (it knows the block split); the bytes are moved here. ----------------- */
 struct FrameBlocksArgs {

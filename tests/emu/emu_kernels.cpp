@@ -181,4 +181,15 @@ int k4emu_decode_chain_batch(const uint8_t *src, const uint64_t *blkOff, const u
     k4emu::launch_fn(dim3(grid), dim3(64 * k4::DECODE_WAVES_PER_WG), [=] { k4::k4_decode_chain_kernel(a); }, threads);
     return 0;
 }
+
+int k4emu_decode_chain_pair_batch(const uint8_t *src, const uint64_t *blkOff, const uint32_t *blkLen, const uint64_t *firstBlk,
+                                  const uint32_t *nBlk, const int32_t *blockSize, const uint8_t *chained, uint8_t *dst,
+                                  const uint64_t *dstOff, const uint64_t *dstCap, long long *outLen, long long n, int threads)
+{
+    if (n <= 0) return 0;
+    k4::ChainArgs a{src, blkOff, blkLen, firstBlk, nBlk, blockSize, chained, dst, dstOff, dstCap, outLen, n};
+    unsigned grid = (unsigned)((n + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG);
+    k4emu::launch_fn(dim3(grid), dim3(128 * k4::DECODE_PAIRS_PER_WG), [=] { k4::k4_decode_chain_pair_kernel(a); }, threads);
+    return 0;
+}
 }

@@ -159,7 +159,9 @@ class Emu:
 
     def decode_chain_batch(self, src, blk_off, blk_len, first, nblk, block_size, chained, dst, dst_off, dst_cap, threads=0):
         out = np.full(len(first), -12345, dtype=np.int64)
-        rc = self.lib.k4emu_decode_chain_batch(self._p(src), blk_off.ctypes.data, blk_len.ctypes.data, first.ctypes.data,
+        fn = self.lib.k4emu_decode_chain_pair_batch if self.pair else self.lib.k4emu_decode_chain_batch
+        fn.argtypes = self.lib.k4emu_decode_chain_batch.argtypes
+        rc = fn(self._p(src), blk_off.ctypes.data, blk_len.ctypes.data, first.ctypes.data,
                                                nblk.ctypes.data, block_size.ctypes.data, chained.ctypes.data, self._p(dst),
                                                dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data, len(first), threads)
         assert rc == 0

@@ -257,6 +257,16 @@ def test_chain_decode_kernel_matches_oracle(emu, fo, lz4f):
     assert (o1[0] < 0) == (n_ref < 0) and (o1[0] == n_ref or n_ref >= 0)
 
 
+def test_chain_decode_pair_kernel_matches_oracle(emu, fo, lz4f):
+    """the same through k4_decode_chain_pair_kernel: one wave parses the stream's blocks (and may be blocks ahead), the
+    other copies"""
+    emu.pair = True
+    try:
+        test_chain_decode_kernel_matches_oracle(emu, fo, lz4f)
+    finally:
+        emu.pair = False
+
+
 # ---- block encoder / decoder state machines (host logic; compute calls need the device) -------------
 def test_block_encoder_topup_bookkeeping():
     enc = LZ4BlockEncoder(blockSize=1000)                    # rounded up to 1 KiB
