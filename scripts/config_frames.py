@@ -2,7 +2,7 @@
 """Measurements for the frame layer on one GPU:
   xxh32   block checksums: 4096 x 64 KiB HBM-resident buffers, and one 256 MiB stream (content checksum)
   frames  LZ4Frame.EncodeBatch / DecodeBatch through the host-pointer API (PCIe + staging inclusive)
-  chain   in-order decode of linked-block frames written by liblz4, one frame per wavefront, HBM-resident"""
+  chain   in-order decode of linked-block frames written by liblz4, one frame per wavefront pair, HBM-resident"""
 import json, os, sys, time
 import numpy as np
 import torch
@@ -86,5 +86,5 @@ dcap = torch.full((nfr,), size, dtype=torch.int64, device=dev)
 tc = timed(lambda: dc.decode_chain(*args, dst, doff, dcap), reps=3)
 out = dc.decode_chain(*args, dst, doff, dcap).cpu().numpy()
 okc = bool((out == size).all()) and all(bytes(dst[i * size:(i + 1) * size].cpu().numpy()) == srcs[i % 16].tobytes() for i in (0, 5, 1023))
-print(json.dumps({"config": "chained (linked-block) frames, in-order decode, one frame per wavefront", "frames": nfr, "bytes_each": size,
+print(json.dumps({"config": "chained (linked-block) frames, in-order decode, two wavefronts per frame (one with K4LZ4_NO_PAIR=1)", "frames": nfr, "bytes_each": size,
                   "ms": round(tc * 1e3, 1), "GiBs": round(nfr * size / tc / 2**30, 1), "roundtrip_ok": okc}))
