@@ -270,7 +270,7 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
             break;
         }
         if (kind == KIND_ENCODE && (flags & K4LZ4_FLAG_ALLOW_COPY))
-            hipLaunchKernelGGL(k4::k4_allow_copy_kernel, dim3(wg4), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(k4::k4_allow_copy_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, stream, a);   /* 4 blocks per workgroup */
         K4_HIP(ctx, hipGetLastError());
     }
     return K4LZ4_OK;
