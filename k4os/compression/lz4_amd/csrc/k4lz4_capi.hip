@@ -240,13 +240,21 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
                     k4::BatchArgs ag = a;
                     ag.order = a.order + n_lds + g0;
                     ag.gtab = (uint32_t *)ctx->d_gtab;
-                    hipLaunchKernelGGL(k4::k4_encode_fast_gtab_kernel, dim3((unsigned)std::min(gchunk, n_g - g0)), dim3(64), 0, ctx->aux, ag);
+                    ag.n = std::min(gchunk, n_g - g0);
+                    hipLaunchKernelGGL(k4::k4_encode_fast_gtab_kernel, dim3((unsigned)((ag.n + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)),
+                                       dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, ctx->aux, ag);
                 }
                 K4_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
-                hipLaunchKernelGGL(k4::k4_encode_fast_kernel, dim3((unsigned)n_lds), dim3(64), 0, stream, a);
+                {
+                    k4::BatchArgs al = a;
+                    al.n = n_lds;
+                    hipLaunchKernelGGL(k4::k4_encode_fast_kernel, dim3((unsigned)((n_lds + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)),
+                                       dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, al);
+                }
                 K4_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_join, 0));
             }
-            else hipLaunchKernelGGL(k4::k4_encode_fast_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL(k4::k4_encode_fast_kernel, dim3((unsigned)((cnt + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)),
+                                    dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, a);
             break;
         case KIND_DECODE:
             if (a.prof) hipLaunchKernelGGL(k4::k4_decode_prof_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);

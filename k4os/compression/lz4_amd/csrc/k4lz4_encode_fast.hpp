@@ -694,11 +694,16 @@ __global__ __launch_bounds__(256) void k4_order_kernel(BatchArgs a)
     a.order_out[pos] = (uint32_t)b;
 }
 
-__global__ __launch_bounds__(64) void k4_encode_fast_kernel(BatchArgs a)
+constexpr int ENCODE_WAVES_PER_WG = 2;
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) void k4_encode_fast_kernel(BatchArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t tab[ENCODE_LDS_DWORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t tabs[ENCODE_WAVES_PER_WG][ENCODE_LDS_DWORDS];
     const int lane = lane_id();
-    const long long b = a.order ? (long long)uni(a.order[blockIdx.x]) : (long long)blockIdx.x;
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const long long slot = (long long)blockIdx.x * ENCODE_WAVES_PER_WG + (long long)wave;
+    if (slot >= a.n) return;
+    uint32_t *tab = tabs[wave];
+    const long long b = a.order ? (long long)uni(a.order[slot]) : slot;
     const int src_len = a.srcLen[b];
     const int cap = a.dstCap[b];
     const uint8_t *src = a.src + a.srcOff[b];
@@ -712,17 +717,21 @@ __global__ __launch_bounds__(64) void k4_encode_fast_kernel(BatchArgs a)
  * only the output stage in LDS: twice as many blocks resident per CU, each a little slower */
 /* waves_per_eu(6): at most 80 VGPRs.  Two LDS-table waves and four of these fit one SIMD's register file only
  * below that line; one register more costs 20 % of the batch rate (measured). */
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k4_encode_fast_gtab_kernel(BatchArgs a)
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void k4_encode_fast_gtab_kernel(BatchArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t stage[ENCODE_SCRATCH_BYTES_GTAB / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t stages[ENCODE_WAVES_PER_WG][ENCODE_SCRATCH_BYTES_GTAB / 4];
     const int lane = lane_id();
-    const long long b = a.order ? (long long)uni(a.order[blockIdx.x]) : (long long)blockIdx.x;
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const long long slot = (long long)blockIdx.x * ENCODE_WAVES_PER_WG + (long long)wave;
+    if (slot >= a.n) return;
+    uint32_t *stage = stages[wave];
+    const long long b = a.order ? (long long)uni(a.order[slot]) : slot;
     const int src_len = a.srcLen[b];
     const int cap = a.dstCap[b];
     int ret = 0;
     if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
         ret = compress_fast_block(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.accel, stage, lane,
-                                  a.gtab + 4096ull * (unsigned long long)blockIdx.x, (a.flags & FLAG_X32) != 0);
+                                  a.gtab + 4096ull * (unsigned long long)slot, (a.flags & FLAG_X32) != 0);
     if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
 }
 

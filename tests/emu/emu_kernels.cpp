@@ -55,7 +55,8 @@ int k4emu_encode_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t
 {
     k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, accel, flags, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n <= 0) return 0;
-    k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_encode_fast_kernel(a); }, threads);
+    k4emu::launch_fn(dim3((unsigned)((n + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG),
+                     [=] { k4::k4_encode_fast_kernel(a); }, threads);
     return 0;
 }
 
