@@ -162,7 +162,7 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
     __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
     const int lane = lane_id();
     const uint32_t wave = uni(threadIdx.x >> 6);
-    const uint32_t pair = wave >> 1, role = wave & 1u;
+    const uint32_t pair = wave >> 1, role = (wave ^ blockIdx.x) & 1u;   /* as in k4_decode_pair_kernel */
     const long long slot = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
     uint32_t *ring = lds[pair], *pipe = lds[pair] + RING_DWORDS;
     if (lane < 8 && role == 0) pipe[lane] = 0u;
