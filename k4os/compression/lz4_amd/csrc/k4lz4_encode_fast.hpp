@@ -395,11 +395,9 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 skipped = __ballot(in && (uint32_t)lane + 2u != qp);
                 cursors = 1ull | __ballot(hb != 0ull && (uint32_t)lane == qp);
             };
-            bool hit1 = hit_tab, general = false;
-            uint32_t pos1 = cand, info1 = info;
+            bool general = false;
             if (dirty) {
                 candidates();
-                hit1 = chit; pos1 = cpos; info1 = cinfo;
             }
             publish();
             /* the word of a pair lane that has fallen back to its table candidate; candidate lanes lost so far.
