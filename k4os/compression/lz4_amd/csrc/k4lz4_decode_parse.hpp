@@ -1,0 +1,343 @@
+/*
+ * k4lz4_decode_parse.hpp -- finding the token positions of an LZ4 block 64 chains at a time.
+ *
+ * What the reference does one token after the other (LL64.LZ4_decompress_generic, Engine/x64/LL64.dec.cs:175-451:
+ * token -> literal length -> skip the literals -> offset -> match length -> next token) is a dependent chain; a
+ * wavefront that follows it token by token uses one lane and pays the chain's latency per sequence.  Here a
+ * window of the compressed stream (PARSE_NL segments of 64 bytes) is parsed by all lanes at once:
+ *
+ *   MAIN   lane j follows the chain that starts at the first byte of segment j -- a guess, only lane 0 starts on
+ *          a real token -- to the end of its segment and marks the positions it visits (64-bit mask per lane).
+ *          A chain is a pure function of the position it starts at, and chains that meet stay together: a wrong
+ *          guess falls into step with the real tokens after a few hops.
+ *   EXT    each lane goes on past its segment until it lands on a position the owner of that segment marked
+ *          (from there on the two chains are the same), remembering the positions it visited on the way.
+ *   WALK   the real chain is then read off: lane 0's marks, its extension, the lane it merged into from the merge
+ *          position on, that lane's extension, ...  Where an extension gave up before merging (its list is
+ *          full), the walk follows the chain itself, one token at a time, until it meets a mark again.
+ *   LIST   the real token positions (a bit set over the window) are compacted into a list in LDS.
+ *
+ * decode_block then takes up to 64 positions of the list per batch and derives the sequence fields of all of
+ * them at once -- every lane works on a real token, instead of 64 hypotheses for the dozen tokens that a window
+ * of 64 bytes holds.  The list is advisory: every token derived from it is checked against the reference's
+ * rules, tokens that need more (long lengths, block end, anything malformed) go through the scalar parser, and a
+ * list that disagrees with where the scalar parser ends up is dropped.
+ */
+#pragma once
+#include "k4lz4_common.hpp"
+
+namespace k4 {
+
+/* A window over the compressed stream in LDS: DW dwords (power of two), slot = dword index & (DW - 1), filled
+ * with coalesced dword loads; slot DW mirrors slot 0, so two consecutive dwords can always be read as one
+ * ds_read2_b32.  Positions given to cover()/read4() are "aligned" positions: stream position + a0. */
+template <int DW> struct StreamWin {
+    uint32_t *ring;        /* DW + 1 dwords */
+    const uint32_t *base;  /* dword-aligned address at or below the first stream byte */
+    const uint8_t *bytes;  /* the stream itself */
+    uint32_t a0;           /* misalignment of the stream start: 0..3 */
+    uint32_t ndw;          /* dwords that contain stream bytes */
+    uint32_t len;          /* stream bytes */
+    uint32_t rlo, rhi;     /* dwords [rlo, rhi) are in the ring (multiples of 64, rhi - rlo <= DW) */
+
+    __device__ __forceinline__ uint32_t load(uint32_t dw) const { return dw < ndw ? base[dw] : 0u; }
+
+    __device__ __forceinline__ void init(uint32_t *lds, const uint8_t *in, uint32_t n, int lane)
+    {
+        ring = lds;
+        bytes = in;
+        len = n;
+        a0 = (uint32_t)((uintptr_t)in & 3u);
+        base = (const uint32_t *)(in - a0);
+        ndw = (a0 + n + 3u) >> 2;
+        rlo = rhi = 0u;
+        (void)lane;
+    }
+
+    /* make the ring hold the aligned byte positions [qlo, qhi); qhi - qlo <= 4 * DW - 512 */
+    __device__ __forceinline__ void cover(uint32_t qlo, uint32_t qhi, int lane)
+    {
+        const uint32_t dlo = qlo >> 2, dhi = (qhi + 3u) >> 2;
+        if (dlo >= rlo && dhi <= rhi) return;
+        wave_sync();                                     /* earlier reads of the slots that are overwritten */
+        if (dlo < rlo || dlo > rhi) rlo = rhi = dlo & ~63u;   /* a jump: start again there */
+        while (rhi < dhi) {
+            const uint32_t slot = (rhi + (uint32_t)lane) & (uint32_t)(DW - 1);
+            const uint32_t v = load(rhi + (uint32_t)lane);
+            ring[slot] = v;
+            if (slot == 0u) ring[DW] = v;
+            rhi += 64u;
+        }
+        if (rhi - rlo > (uint32_t)DW) rlo = rhi - (uint32_t)DW;
+        wave_sync();
+    }
+
+    /* one past the last stream position that can be read from the ring */
+    __device__ __forceinline__ uint32_t hi_pos() const { return (rhi << 2) - a0; }
+
+    /* 4 stream bytes at aligned byte position q (per lane) */
+    __device__ __forceinline__ uint32_t read4(uint32_t q) const
+    {
+        const uint32_t *s = ring + ((q >> 2) & (uint32_t)(DW - 1));
+        const uint32_t lo = s[0], hi = s[1];
+        return (uint32_t)((((uint64_t)hi << 32) | lo) >> ((q & 3u) * 8u));
+    }
+    /* ... at stream position p */
+    __device__ __forceinline__ uint32_t at(uint32_t p) const { return read4(p + a0); }
+
+    /* one stream byte, from the ring where it has it, else from memory; 0 past the end of the stream */
+    __device__ __forceinline__ uint32_t byte_at(uint32_t p) const
+    {
+        if (p >= len) return 0u;
+        const uint32_t q = p + a0;
+        if ((q >> 2) >= rlo && (q >> 2) < rhi) return (ring[(q >> 2) & (uint32_t)(DW - 1)] >> ((q & 3u) * 8u)) & 255u;
+        return (uint32_t)bytes[p];
+    }
+
+    /* scalar parser: the 4 stream bytes at wave-uniform stream position p */
+    __device__ __forceinline__ uint32_t fetch(uint32_t p, int lane)
+    {
+        cover(p + a0, p + a0 + 8u, lane);
+        return uni(read4(p + a0));
+    }
+};
+
+constexpr int PARSE_RING_DW = 1024;            /* 4 KiB of stream per parsing wave */
+constexpr int PARSE_NL = 52;                   /* segments (chains) per window: 52 * 64 + slack < 4 KiB */
+constexpr int PARSE_SLACK = 296;               /* bytes past the window that are kept in the ring */
+constexpr int PARSE_EXT_CAP = 24;              /* positions a chain remembers past its own segment */
+constexpr int PARSE_TOK_MAX = PARSE_NL * 22;   /* a sequence has at least 3 stream bytes */
+/* LDS of the parser, in dwords: ring (+ mirror) | main marks (2 per lane) | real-token bit set | entry offsets | extension
+ * lists | token list */
+constexpr int PARSE_OFF_MARK = PARSE_RING_DW + 2, PARSE_OFF_TRUE = PARSE_OFF_MARK + 128, PARSE_OFF_RIN = PARSE_OFF_TRUE + 128,
+              PARSE_OFF_EXT = PARSE_OFF_RIN + 64, PARSE_OFF_TOK = PARSE_OFF_EXT + 64 * PARSE_EXT_CAP / 4,
+              PARSE_LDS_DWORDS = PARSE_OFF_TOK + (PARSE_TOK_MAX + 1) / 2;
+typedef StreamWin<PARSE_RING_DW> ParseWin;
+
+/*
+ * One step of a chain.  A chain's state is (pt, pend): pend = 1 says that the sequence before had a match
+ * length of 19 or more (ML field 15), its extension byte is at pt - 1 and has not been looked at -- the token is at
+ * pt only if that byte is not 255.  Keeping that byte for the next step's read means a step needs ONE look at the
+ * stream: 4 bytes that hold (extension byte,) token and the first literal-length byte.  The step follows the
+ * layout of a sequence only (LL64.dec.cs:177-178,:228-243,:318-336: token, 255-runs of the two lengths, 2 offset
+ * bytes).  Returns the token's position (pt itself unless the extension ran on); (nx, npend) = the next state.
+ * `fail`: the sequence does not lie inside the input or a length run is longer than chains follow -- such a
+ * token ends the chain and is left to the scalar parser.
+ */
+__device__ __forceinline__ uint32_t chain_hop_slow(const ParseWin &win, uint32_t pt, uint32_t pend, uint32_t &nx, uint32_t &npend, bool &fail)
+{
+    uint32_t p = pt;
+    fail = false;
+    if (pend) {
+        uint32_t e = win.byte_at(p - 1u);
+        for (uint32_t k = 0; e == 255u && k < 24u; k++) e = win.byte_at(p++);
+        if (e == 255u) fail = true;
+    }
+    const uint32_t tok = win.byte_at(p);
+    uint32_t L = tok >> 4, q = p + 1u;
+    if (L == RUN_MASK) {
+        uint32_t e = 255u;
+        for (uint32_t k = 0; e == 255u && k < 24u; k++) { e = win.byte_at(q++); L += e; }
+        if (e == 255u) fail = true;
+    }
+    nx = q + L + 2u;
+    npend = (tok & 15u) == ML_MASK ? 1u : 0u;
+    nx += npend;
+    if (nx > win.len) fail = true;
+    return p;
+}
+
+/* the common case: at most one extension byte per length; `rare` = this lane needs chain_hop_slow instead */
+__device__ __forceinline__ void chain_hop(const ParseWin &win, uint32_t pt, uint32_t pend, uint32_t &nx, uint32_t &npend, bool &rare)
+{
+    uint32_t t = win.at(pt - pend);
+    rare = pend && (t & 255u) == 255u;
+    t >>= 8u * pend;
+    const uint32_t L = (t >> 4) & 15u, e1 = (t >> 8) & 255u;
+    const bool g = L == RUN_MASK;
+    rare = rare || (g && e1 == 255u);
+    npend = (t & 15u) == ML_MASK ? 1u : 0u;
+    nx = pt + (g ? 19u + e1 : 3u + L) + npend;
+    rare = rare || nx > win.len;
+}
+
+/*
+ * One window: the token positions of the chain that starts at stream position wb (a real token), as far as the
+ * window reaches.  Returns their number n; ptok[0..n) = positions relative to wb, ascending; end_ip = where the
+ * chain goes on after them (the first position not in the list).  n == 0: the token at wb is left to the scalar
+ * parser.  clim = iend - 16: chains only visit positions below it.  `area` = this wave's PARSE_LDS_DWORDS.
+ */
+template <bool PROF = false>
+__device__ __forceinline__ uint32_t parse_window(ParseWin &win, uint32_t wb, uint32_t clim, int lane, uint32_t *area, uint32_t &end_ip,
+                                                 unsigned long long *pc = nullptr)
+{
+    /* diagnostics (PROF): pc[0..4] cycles of cover / MAIN / EXT / WALK / LIST, pc[5..8] their loop trips (WALK: hops, then
+     * tokens followed one at a time) */
+    unsigned long long tq0 = prof_now<PROF>(), n_main = 0, n_ext = 0, n_hop = 0, n_ser = 0, n_list = 0;
+    uint32_t *pm = area + PARSE_OFF_MARK, *pt_ = area + PARSE_OFF_TRUE, *prin = area + PARSE_OFF_RIN;
+    uint8_t *myext = (uint8_t *)(area + PARSE_OFF_EXT) + (uint32_t)lane * PARSE_EXT_CAP;
+    uint16_t *ptok = (uint16_t *)(area + PARSE_OFF_TOK);
+    const uint32_t span = clim - wb;
+    const uint32_t nl = span > (uint32_t)PARSE_NL * 64u ? (uint32_t)PARSE_NL : (span + 63u) >> 6;
+    const uint32_t wend = wb + nl * 64u;
+    const uint32_t stop_at = wend < clim ? wend : clim;     /* chains do not visit positions from here on */
+    win.cover(wb + win.a0, wend + (uint32_t)PARSE_SLACK + win.a0, lane);
+
+    const unsigned long long tq1 = prof_now<PROF>();
+    /* ---- MAIN: every lane its own segment ---- */
+    const uint32_t seg0 = wb + 64u * (uint32_t)lane;
+    const uint32_t seg_stop = seg0 + 64u < clim ? seg0 + 64u : clim;
+    uint32_t p = (uint32_t)lane < nl ? seg0 : 0xffffffffu, pend = 0;      /* the state: token expected at p */
+    unsigned long long mask = 0;
+    bool stopped = false;
+    while (__ballot(p < seg_stop)) {
+        if (PROF) n_main++;
+        if (p < seg_stop) {
+            uint32_t nx, npend, tp = p;
+            bool rare;
+            chain_hop(win, p, pend, nx, npend, rare);
+            if (rare) {
+                bool fail;
+                tp = chain_hop_slow(win, p, pend, nx, npend, fail);
+                if (fail || tp >= seg_stop) {             /* the token is not this segment's after all, or cannot be followed */
+                    stopped = fail || tp >= clim;
+                    nx = tp | 0x80000000u;
+                    npend = 0;
+                    tp = 0xffffffffu;
+                }
+            }
+            if (tp != 0xffffffffu) mask |= 1ull << (tp - seg0);
+            p = nx;
+            pend = npend;
+        }
+    }
+    if (p & 0x80000000u) p &= 0x7fffffffu;                /* (left the loop through the slow path: p is a resolved token position) */
+    else if (p >= clim && p < seg0 + 64u) stopped = true;
+    const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
+    if (uni(mlo | mhi) == 0u) { end_ip = wb; return 0u; } /* the real chain's first token cannot be followed */
+    pm[2 * lane] = mlo;
+    pm[2 * lane + 1] = mhi;
+    pt_[2 * lane] = 0u;
+    pt_[2 * lane + 1] = 0u;
+    lds_sync();
+
+    /* ---- EXT: on until the chain meets the marks of a segment's owner ---- */
+    const unsigned long long tq2 = prof_now<PROF>();
+    enum : uint32_t { ST_RUN = 0, ST_MERGED = 1, ST_END = 2, ST_OPEN = 3 };
+    uint32_t st = (uint32_t)lane < nl && !stopped ? ST_RUN : ST_END;
+    uint32_t k = 0;
+    while (__ballot(st == ST_RUN)) {
+        if (PROF) n_ext++;
+        if (st == ST_RUN) {
+            if (p >= stop_at) {
+                st = ST_END;
+            } else {
+                uint32_t nx, npend, tp = p;
+                bool rare, fail = false;
+                chain_hop(win, p, pend, nx, npend, rare);
+                if (rare) tp = chain_hop_slow(win, p, pend, nx, npend, fail);
+                if (fail || tp >= stop_at) {
+                    st = ST_END; p = tp; pend = 0;
+                } else {
+                    const uint32_t r = tp - wb;
+                    if ((pm[r >> 5] >> (r & 31u)) & 1u) {
+                        st = ST_MERGED; p = tp; pend = 0;
+                    } else if (k >= (uint32_t)PARSE_EXT_CAP || tp - seg0 > 255u) {
+                        st = ST_OPEN; p = tp; pend = 0;
+                    } else {
+                        myext[k++] = (uint8_t)(tp - seg0);
+                        p = nx; pend = npend;
+                    }
+                }
+            }
+        }
+    }
+    /* a chain that ended on a position it could not look at (p >= stop_at) may still owe a look at a match-length
+     * extension: that position is approximate, which the caller allows for (the list is advisory) */
+
+    /* ---- WALK: the real chain, from lane to lane ---- */
+    const unsigned long long tq3 = prof_now<PROF>();
+    const uint32_t word = (st == ST_MERGED ? p - wb : 0u) | (st << 16);   /* how this lane's chain ended, and where it merged */
+    unsigned long long onwalk = 0;
+    uint32_t cur = 0, endp;
+    for (;;) {
+        onwalk |= 1ull << cur;
+        if (PROF) n_hop++;
+        const uint32_t w = readlane_u32(word, (int)cur);
+        uint32_t s = w >> 16;
+        if (s == ST_MERGED) {                             /* the usual hop */
+            cur = (w & 0xffffu) >> 6;
+            continue;
+        }
+        uint32_t x = readlane_u32(p, (int)cur);
+        if (s == ST_OPEN) {                               /* its list was full: follow the chain itself */
+            uint32_t xp = 0;
+            for (;;) {
+                if (x >= stop_at) { s = ST_END; break; }
+                if (PROF) n_ser++;
+                uint32_t nx, npend;
+                bool fail;
+                const uint32_t tp = uni(chain_hop_slow(win, x, xp, nx, npend, fail));
+                if (uni(fail ? 1u : 0u) || tp >= stop_at) { x = tp; s = ST_END; break; }
+                const uint32_t r = tp - wb;
+                if ((uni(pm[r >> 5]) >> (r & 31u)) & 1u) { x = tp; s = ST_MERGED; break; }
+                if (lane == 0) atomicOr(&pt_[r >> 5], 1u << (r & 31u));
+                x = uni(nx);
+                xp = uni(npend);
+            }
+            if (s == ST_MERGED) {
+                cur = (x - wb) >> 6;
+                if (lane == 0) prin[cur] = (x - wb) & 63u;             /* entry offset handed over directly */
+                continue;
+            }
+        }
+        endp = x;
+        break;
+    }
+
+    /* ---- LIST: bit set of the real tokens -> ascending positions ---- */
+    const unsigned long long tq4 = prof_now<PROF>();
+    const bool on = ((onwalk >> lane) & 1ull) != 0;
+    lds_sync();
+    if (on && st == ST_MERGED) {                          /* tell the lane this one merged into where the real chain enters it */
+        const uint32_t r = (p - wb);
+        prin[r >> 6] = r & 63u;
+    }
+    lds_sync();
+    if (on) {
+        const uint32_t rin = lane == 0 ? 0u : prin[lane];
+        uint32_t lo = mlo, hi = mhi;
+        if (rin >= 32u) { lo = 0u; hi &= ~0u << (rin - 32u); } else { lo &= ~0u << rin; }
+        if (lo) atomicOr(&pt_[2 * lane], lo);
+        if (hi) atomicOr(&pt_[2 * lane + 1], hi);
+        for (uint32_t j = 0; j < k; j++) {
+            const uint32_t r = 64u * (uint32_t)lane + (uint32_t)myext[j];
+            atomicOr(&pt_[r >> 5], 1u << (r & 31u));
+        }
+    }
+    lds_sync();
+    uint32_t tlo = (uint32_t)lane < nl ? pt_[2 * lane] : 0u, thi = (uint32_t)lane < nl ? pt_[2 * lane + 1] : 0u;
+    const uint32_t c = (uint32_t)__popc(tlo) + (uint32_t)__popc(thi);
+    const uint32_t incl = wave_inclusive_scan(c);
+    uint32_t slot = incl - c;
+    const uint32_t total = readlane_u32(incl, 63);
+    while (__ballot((tlo | thi) != 0u)) {
+        if (PROF) n_list++;
+        if (tlo | thi) {
+            uint32_t b;
+            if (tlo) { b = (uint32_t)__ffs(tlo) - 1u; tlo &= tlo - 1u; }
+            else { b = 32u + (uint32_t)__ffs(thi) - 1u; thi &= thi - 1u; }
+            ptok[slot++] = (uint16_t)(64u * (uint32_t)lane + b);
+        }
+    }
+    lds_sync();
+    if (PROF && pc && lane == 0) {
+        const unsigned long long tq5 = prof_now<PROF>();
+        pc[0] += tq1 - tq0; pc[1] += tq2 - tq1; pc[2] += tq3 - tq2; pc[3] += tq4 - tq3; pc[4] += tq5 - tq4;
+        pc[5] += n_main; pc[6] += n_ext; pc[7] += n_hop; pc[8] += n_ser; pc[9] += n_list;
+    }
+    end_ip = endp;
+    return total;
+}
+
+}  // namespace k4
