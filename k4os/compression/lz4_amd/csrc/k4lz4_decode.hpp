@@ -97,7 +97,10 @@ __device__ __forceinline__ void wave_dict_copy(uint8_t *out, const uint8_t *dict
  * LDS executes in order, so "write the batch, wait for the writes, then advance head" is a release; the reader polls
  * with s_sleep between attempts and gives up (block fails) after PIPE_SPIN_MAX polls instead of hanging.
  */
-constexpr int PIPE_SLOTS = 4;                     /* batches in flight between the two waves (power of two) */
+#ifndef K4_PIPE_SLOTS
+#define K4_PIPE_SLOTS 4
+#endif
+constexpr int PIPE_SLOTS = K4_PIPE_SLOTS;                     /* batches in flight between the two waves (power of two) */
 constexpr int PIPE_DESC = 8 + 8 * PIPE_SLOTS, PIPE_SCRATCH = PIPE_DESC + PIPE_SLOTS * 320, PIPE_STAGE = PIPE_SCRATCH + 128;
 constexpr int PIPE_DWORDS = PIPE_STAGE + (DECODE_STAGE_BYTES + 64) / 4;
 constexpr int DECODE_PAIR_LDS_DWORDS = PARSE_LDS_DWORDS + PIPE_DWORDS;
@@ -151,8 +154,8 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     const bool check_offset = chk_size < 65536;
     const bool prefix64 = dict.mode == 1 && dict.size == 65536u;
     unsigned long long c_parse = 0, c_lit = 0, c_match = 0, n_batch = 0, n_round = 0, n_seq = 0, n_slow = 0;
-    unsigned long long c_hyp = 0, c_chain = 0, c_rules = 0, c_slots = 0, n_spec = 0;   /* PARSE split: speculative rounds */
-    prof_place<PROF>(pc, 8, lane);
+    unsigned long long c_hyp = 0, c_chain = 0, c_wait = 0, n_spec = 0;   /* PARSE split: windows, deriving batches; time spent waiting for the other wave */
+    if (ROLE == 0) prof_place<PROF>(pc, 8, lane);
     const unsigned long long t_begin = prof_now<PROF>();
     if (out_size == 0) {                                   /* LL64.dec.cs:162-168 */
         if (partial) return 0;
@@ -197,10 +200,13 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             const uint32_t slot = batch_no & (uint32_t)(PIPE_SLOTS - 1);
             meta = pipe + 8 + 8 * slot;
             d_lpos = pipe + PIPE_DESC + 320 * slot; d_llen = d_lpos + 64; d_out = d_llen + 64; d_moff = d_out + 64; d_mlen = d_moff + 64;
+            const unsigned long long tw0 = prof_now<PROF>();
             if (ROLE == 1) {                                /* the slot is free once the other wave has taken batch_no - PIPE_SLOTS */
                 if (batch_no >= (uint32_t)PIPE_SLOTS && !pipe_wait(pipe + 1, batch_no + 1u - (uint32_t)PIPE_SLOTS)) return PIPE_TIMEOUT;
+                if (PROF) c_wait += prof_now<PROF>() - tw0;
             } else {
                 if (!pipe_wait(pipe + 0, batch_no + 1u)) return PIPE_TIMEOUT;
+                if (PROF) c_wait += prof_now<PROF>() - tw0;
                 nseq = (int)uni(meta[0]);
                 op_batch = (int64_t)uni(meta[1]);
                 op = op_batch + (int64_t)uni(meta[2]);
@@ -445,6 +451,10 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             batch_no++;
             if (err || done) {
                 if (seq) *seq = batch_no;
+                if (PROF && pc && lane == 0) {              /* the parsing wave's half of the pair's record */
+                    pc[0] = prof_now<PROF>() - t_begin; pc[1] = c_hyp; pc[2] = c_chain; pc[3] = c_wait;
+                    pc[4] = batch_no; pc[5] = n_spec; pc[7] = n_slow;
+                }
                 return err ? err : (int)op;
             }
             continue;
@@ -597,6 +607,10 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
         }
         if (ROLE == 2 && done) {                            /* the result the parsing wave arrived at */
             if (seq) *seq = batch_no;
+            if (PROF && pc && lane == 0) {                  /* the copying wave's half */
+                pc[8] = prof_now<PROF>() - t_begin; pc[9] = c_wait; pc[10] = c_lit; pc[11] = c_match;
+                pc[12] = n_batch; pc[13] = n_round; pc[14] = n_seq;
+            }
             return err;
         }
         if (done) break;
@@ -604,7 +618,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     if (PROF && pc && lane == 0) {
         pc[0] = prof_now<PROF>() - t_begin; pc[1] = c_parse; pc[2] = c_lit; pc[3] = c_match;
         pc[4] = n_batch; pc[5] = n_round; pc[6] = n_seq; pc[7] = n_slow;
-        pc[11] = c_hyp; pc[12] = c_chain; pc[13] = c_rules; pc[14] = c_slots; pc[15] = n_spec;
+        pc[11] = c_hyp; pc[12] = c_chain; pc[13] = 0; pc[14] = 0; pc[15] = n_spec;
     }
     prof_place<PROF>(pc, 9, lane);
     return (int)op;
@@ -661,8 +675,11 @@ __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_decode_kernel(Bat
 
 /* ... and with at most half as many blocks as the chip has wave slots, two waves per block: wave 2p parses block p of
  * the workgroup, wave 2p+1 copies (see the queue above).  8 waves per SIMD need <= 64 VGPRs. */
-constexpr int DECODE_PAIRS_PER_WG = 2;     /* measured: 4 pairs per workgroup 233 GiB/s on the bench batch, 2 pairs 242, 1 pair 223 */
-__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k4_decode_pair_kernel(BatchArgs a)
+#ifndef K4_PAIRS_PER_WG
+#define K4_PAIRS_PER_WG 2
+#endif
+constexpr int DECODE_PAIRS_PER_WG = K4_PAIRS_PER_WG;     /* measured: 4 pairs per workgroup 233 GiB/s on the bench batch, 2 pairs 242, 1 pair 223 */
+__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) void k4_decode_pair_kernel(BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
     const int lane = lane_id();
@@ -687,6 +704,34 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
     } else {
         int ret = 0;
         if (run) ret = decode_block<false, 2>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, nullptr, partial, dict, pipe);
+        if (lane == 0) a.outLen[b] = codec_decode_result(src_len, ret, a.flags);
+    }
+}
+
+/* diagnostic twin of the pair kernel: counters [0..7] by the parsing wave (total, windows, deriving, waiting for a free
+ * slot; batches, windows, -, sequences parsed one at a time), [8..14] by the copying wave (total, waiting for a batch,
+ * literals, matches; batches, dependency rounds, sequences) */
+__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) void k4_decode_pair_prof_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
+    const int lane = lane_id();
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t pair = wave >> 1, role = (wave ^ blockIdx.x) & 1u;
+    const long long slot = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
+    uint32_t *ring = lds[pair], *pipe = lds[pair] + PARSE_LDS_DWORDS;
+    if (lane < 8 && role == 0) pipe[lane] = 0u;
+    __syncthreads();
+    if (slot >= a.n) return;
+    const long long b = a.order ? (long long)uni(a.order[slot]) : slot;
+    const int src_len = a.srcLen[b];
+    const int cap = a.dstCap[b];
+    const uint8_t *in = a.src + a.srcOff[b];
+    uint8_t *out = a.dst + a.dstOff[b];
+    if (role == 0) {
+        if (src_len > 0) decode_block<true, 1>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, a.prof + PROF_STRIDE * b, false, DecodeDict{nullptr, 0u, 0}, pipe);
+    } else {
+        int ret = 0;
+        if (src_len > 0) ret = decode_block<true, 2>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, a.prof + PROF_STRIDE * b, false, DecodeDict{nullptr, 0u, 0}, pipe);
         if (lane == 0) a.outLen[b] = codec_decode_result(src_len, ret, a.flags);
     }
 }

@@ -61,12 +61,20 @@ template <int DW> struct StreamWin {
         if (dlo >= rlo && dhi <= rhi) return;
         wave_sync();                                     /* earlier reads of the slots that are overwritten */
         if (dlo < rlo || dlo > rhi) rlo = rhi = dlo & ~63u;   /* a jump: start again there */
-        while (rhi < dhi) {
-            const uint32_t slot = (rhi + (uint32_t)lane) & (uint32_t)(DW - 1);
-            const uint32_t v = load(rhi + (uint32_t)lane);
-            ring[slot] = v;
-            if (slot == 0u) ring[DW] = v;
-            rhi += 64u;
+        while (rhi < dhi) {                               /* up to eight chunks' loads in flight before the first store */
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t c = 0; c < 8u; c++) v[c] = rhi + 64u * c < dhi ? load(rhi + 64u * c + (uint32_t)lane) : 0u;
+#pragma unroll
+            for (uint32_t c = 0; c < 8u; c++) {
+                if (rhi + 64u * c < dhi) {
+                    const uint32_t slot = (rhi + 64u * c + (uint32_t)lane) & (uint32_t)(DW - 1);
+                    ring[slot] = v[c];
+                    if (slot == 0u) ring[DW] = v[c];
+                }
+            }
+            const uint32_t todo = (dhi - rhi + 63u) >> 6;
+            rhi += 64u * (todo < 8u ? todo : 8u);
         }
         if (rhi - rlo > (uint32_t)DW) rlo = rhi - (uint32_t)DW;
         wave_sync();
@@ -105,13 +113,11 @@ template <int DW> struct StreamWin {
 constexpr int PARSE_RING_DW = 1024;            /* 4 KiB of stream per parsing wave */
 constexpr int PARSE_NL = 52;                   /* segments (chains) per window: 52 * 64 + slack < 4 KiB */
 constexpr int PARSE_SLACK = 296;               /* bytes past the window that are kept in the ring */
-constexpr int PARSE_EXT_CAP = 24;              /* positions a chain remembers past its own segment */
+constexpr int PARSE_EXT_TRIPS = 32;            /* steps a chain takes past its own segment before it gives up */
 constexpr int PARSE_TOK_MAX = PARSE_NL * 22;   /* a sequence has at least 3 stream bytes */
-/* LDS of the parser, in dwords: ring (+ mirror) | main marks (2 per lane) | real-token bit set | entry offsets | extension
- * lists | token list */
+/* LDS of the parser, in dwords: ring (+ mirror) | main marks (2 per lane) | real-token bit set | entry offsets | token list */
 constexpr int PARSE_OFF_MARK = PARSE_RING_DW + 2, PARSE_OFF_TRUE = PARSE_OFF_MARK + 128, PARSE_OFF_RIN = PARSE_OFF_TRUE + 128,
-              PARSE_OFF_EXT = PARSE_OFF_RIN + 64, PARSE_OFF_TOK = PARSE_OFF_EXT + 64 * PARSE_EXT_CAP / 4,
-              PARSE_LDS_DWORDS = PARSE_OFF_TOK + (PARSE_TOK_MAX + 1) / 2;
+              PARSE_OFF_TOK = PARSE_OFF_RIN + 64, PARSE_LDS_DWORDS = PARSE_OFF_TOK + (PARSE_TOK_MAX + 1) / 2;
 typedef StreamWin<PARSE_RING_DW> ParseWin;
 
 /*
@@ -147,18 +153,54 @@ __device__ __forceinline__ uint32_t chain_hop_slow(const ParseWin &win, uint32_t
     return p;
 }
 
-/* the common case: at most one extension byte per length; `rare` = this lane needs chain_hop_slow instead */
-__device__ __forceinline__ void chain_hop(const ParseWin &win, uint32_t pt, uint32_t pend, uint32_t &nx, uint32_t &npend, bool &rare)
+/* the common case: at most one extension byte per length.  P = the expected token position in ALIGNED coordinates
+ * (stream position + a0, which is what indexes the ring); LEN = stream length + a0.  One ds_read2_b32: the four bytes
+ * from P - 1 on are (extension byte of the sequence before,) token, first literal-length byte.  `rare` = this lane
+ * needs chain_hop_slow instead. */
+__device__ __forceinline__ void chain_hop(const uint32_t *ring, uint32_t P, uint32_t pend, uint32_t LEN, uint32_t &nx, uint32_t &npend, bool &rare)
 {
-    uint32_t t = win.at(pt - pend);
-    rare = pend && (t & 255u) == 255u;
-    t >>= 8u * pend;
-    const uint32_t L = (t >> 4) & 15u, e1 = (t >> 8) & 255u;
+    const uint32_t a = P - 1u;
+    const uint32_t *s = ring + ((a >> 2) & (uint32_t)(PARSE_RING_DW - 1));
+    const uint32_t lo = s[0], hi = s[1];
+    const uint32_t t = (uint32_t)((((uint64_t)hi << 32) | lo) >> ((a & 3u) * 8u));
+    const uint32_t L = (t >> 12) & 15u, e1 = (t >> 16) & 255u;
     const bool g = L == RUN_MASK;
-    rare = rare || (g && e1 == 255u);
-    npend = (t & 15u) == ML_MASK ? 1u : 0u;
-    nx = pt + (g ? 19u + e1 : 3u + L) + npend;
-    rare = rare || nx > win.len;
+    npend = ((t >> 8) & 15u) == ML_MASK ? 1u : 0u;
+    nx = P + (g ? 19u + e1 : 3u + L) + npend;
+    rare = (pend != 0u && (t & 255u) == 255u) || (g && e1 == 255u) || nx > LEN;
+}
+
+/* the real chain from lane to lane: lane l's word = the lane its chain merged into (bits 0-5), or l itself with bit 7 set
+ * where the chain did not merge.  From lane `from` on, marks every lane passed in T and returns the lane where the hops
+ * end.  In ISA for the same reason as the encoder's hop chain: s_bitset1 and v_readlane take the lane from the low six
+ * bits of the word just read, so one read feeds the next with nothing but the wait states in between; a lane where the
+ * chain ends points at itself, so hopping on is harmless and the exit is tested once per eight hops. */
+__device__ __forceinline__ uint32_t walk_lanes(uint32_t word, uint32_t from, unsigned long long &T)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t pk = from;
+#define K4_WHOP "s_bitset1_b64 %[T], %[pk]\n\ts_nop 2\n\tv_readlane_b32 %[pk], %[word], %[pk]\n\t"
+#define K4_WHOP8 K4_WHOP K4_WHOP K4_WHOP K4_WHOP K4_WHOP K4_WHOP K4_WHOP K4_WHOP
+    asm volatile(
+        ".Lwalk_more%=:\n\t"
+        K4_WHOP8
+        "s_bitcmp0_b32 %[pk], 7\n\t"
+        "s_cbranch_scc1 .Lwalk_more%="
+        : [T] "+s"(T), [pk] "+s"(pk)
+        : [word] "v"(word)
+        : "scc");
+#undef K4_WHOP8
+#undef K4_WHOP
+    return pk & 63u;
+#else
+    uint32_t cur = from;
+    for (;;) {
+        T |= 1ull << cur;
+        const uint32_t w = readlane_u32(word, (int)cur);
+        if (w & 0x80u) return cur;
+        cur = w & 63u;
+    }
+#endif
 }
 
 /*
@@ -171,48 +213,58 @@ template <bool PROF = false>
 __device__ __forceinline__ uint32_t parse_window(ParseWin &win, uint32_t wb, uint32_t clim, int lane, uint32_t *area, uint32_t &end_ip,
                                                  unsigned long long *pc = nullptr)
 {
-    /* diagnostics (PROF): pc[0..4] cycles of cover / MAIN / EXT / WALK / LIST, pc[5..8] their loop trips (WALK: hops, then
+    /* diagnostics (PROF): pc[0..4] cycles of cover / MAIN / EXT / WALK / LIST, pc[5..9] their loop trips (WALK: hops, then
      * tokens followed one at a time) */
     unsigned long long tq0 = prof_now<PROF>(), n_main = 0, n_ext = 0, n_hop = 0, n_ser = 0, n_list = 0;
     uint32_t *pm = area + PARSE_OFF_MARK, *pt_ = area + PARSE_OFF_TRUE, *prin = area + PARSE_OFF_RIN;
-    uint8_t *myext = (uint8_t *)(area + PARSE_OFF_EXT) + (uint32_t)lane * PARSE_EXT_CAP;
     uint16_t *ptok = (uint16_t *)(area + PARSE_OFF_TOK);
+    const uint32_t *ring = win.ring;
+    /* everything below in aligned coordinates (stream position + a0) */
+    const uint32_t a0 = win.a0, W = wb + a0, CL = clim + a0, LEN = win.len + a0;
     const uint32_t span = clim - wb;
     const uint32_t nl = span > (uint32_t)PARSE_NL * 64u ? (uint32_t)PARSE_NL : (span + 63u) >> 6;
-    const uint32_t wend = wb + nl * 64u;
-    const uint32_t stop_at = wend < clim ? wend : clim;     /* chains do not visit positions from here on */
-    win.cover(wb + win.a0, wend + (uint32_t)PARSE_SLACK + win.a0, lane);
-
+    const uint32_t WEND = W + nl * 64u;
+    const uint32_t STOP = WEND < CL ? WEND : CL;          /* chains do not visit positions from here on */
+    win.cover(W, WEND + (uint32_t)PARSE_SLACK, lane);
     const unsigned long long tq1 = prof_now<PROF>();
+
     /* ---- MAIN: every lane its own segment ---- */
-    const uint32_t seg0 = wb + 64u * (uint32_t)lane;
-    const uint32_t seg_stop = seg0 + 64u < clim ? seg0 + 64u : clim;
-    uint32_t p = (uint32_t)lane < nl ? seg0 : 0xffffffffu, pend = 0;      /* the state: token expected at p */
+    const uint32_t seg0 = W + 64u * (uint32_t)lane;
+    const uint32_t seg_stop = seg0 + 64u < CL ? seg0 + 64u : CL;
+    constexpr uint32_t LEFT = 0x80000000u;                 /* set in P: left the loop on a resolved token position */
+    uint32_t P = (uint32_t)lane < nl ? seg0 : 0xffffffffu, pend = 0;      /* the state: token expected at P */
     unsigned long long mask = 0;
     bool stopped = false;
-    while (__ballot(p < seg_stop)) {
+    for (;;) {
+        const bool live = P < seg_stop;
+        if (!__ballot(live)) break;
         if (PROF) n_main++;
-        if (p < seg_stop) {
-            uint32_t nx, npend, tp = p;
-            bool rare;
-            chain_hop(win, p, pend, nx, npend, rare);
+        uint32_t nx, npend, tp = P;
+        bool rare;
+        chain_hop(ring, P, pend, LEN, nx, npend, rare);
+        rare = rare && live;
+        if (__ballot(rare)) {
             if (rare) {
                 bool fail;
-                tp = chain_hop_slow(win, p, pend, nx, npend, fail);
+                tp = chain_hop_slow(win, P - a0, pend, nx, npend, fail) + a0;
+                nx += a0;
                 if (fail || tp >= seg_stop) {             /* the token is not this segment's after all, or cannot be followed */
-                    stopped = fail || tp >= clim;
-                    nx = tp | 0x80000000u;
+                    stopped = fail || tp >= CL;
+                    nx = tp | LEFT;
                     npend = 0;
                     tp = 0xffffffffu;
                 }
             }
+        }
+        if (live) {
             if (tp != 0xffffffffu) mask |= 1ull << (tp - seg0);
-            p = nx;
+            P = nx;
             pend = npend;
         }
     }
-    if (p & 0x80000000u) p &= 0x7fffffffu;                /* (left the loop through the slow path: p is a resolved token position) */
-    else if (p >= clim && p < seg0 + 64u) stopped = true;
+    if ((uint32_t)lane >= nl) P = WEND;
+    else if (P & LEFT) P &= ~LEFT;
+    else if (P >= CL && P < seg0 + 64u) stopped = true;
     const uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
     if (uni(mlo | mhi) == 0u) { end_ip = wb; return 0u; } /* the real chain's first token cannot be followed */
     pm[2 * lane] = mlo;
@@ -225,69 +277,74 @@ __device__ __forceinline__ uint32_t parse_window(ParseWin &win, uint32_t wb, uin
     const unsigned long long tq2 = prof_now<PROF>();
     enum : uint32_t { ST_RUN = 0, ST_MERGED = 1, ST_END = 2, ST_OPEN = 3 };
     uint32_t st = (uint32_t)lane < nl && !stopped ? ST_RUN : ST_END;
-    uint32_t k = 0;
-    while (__ballot(st == ST_RUN)) {
+    unsigned long long e1 = 0, e2 = 0;                    /* positions visited in the next segment and the one after it */
+    for (uint32_t trip = 0;; trip++) {
+        const bool run = st == ST_RUN;
+        if (!__ballot(run)) break;
         if (PROF) n_ext++;
-        if (st == ST_RUN) {
-            if (p >= stop_at) {
+        const bool off_end = P >= STOP;                   /* (P is approximate while an extension byte is pending: allowed) */
+        uint32_t nx, npend, tp = P;
+        bool rare, fail = false;
+        chain_hop(ring, P, pend, LEN, nx, npend, rare);
+        rare = rare && run && !off_end;
+        if (__ballot(rare)) {
+            if (rare) {
+                tp = chain_hop_slow(win, P - a0, pend, nx, npend, fail) + a0;
+                nx += a0;
+            }
+        }
+        const uint32_t r = (tp - W) & 4095u;
+        const uint32_t mw = pm[r >> 5];
+        const uint32_t rel = tp - seg0 - 64u;             /* 0..127: inside the two segments this lane keeps marks for */
+        if (run) {
+            if (off_end) {
                 st = ST_END;
+            } else if (fail || tp >= STOP) {
+                st = ST_END; P = tp; pend = 0;
+            } else if ((mw >> (r & 31u)) & 1u) {
+                st = ST_MERGED; P = tp; pend = 0;
+            } else if (rel >= 128u || trip >= (uint32_t)PARSE_EXT_TRIPS) {
+                st = ST_OPEN; P = tp; pend = 0;
             } else {
-                uint32_t nx, npend, tp = p;
-                bool rare, fail = false;
-                chain_hop(win, p, pend, nx, npend, rare);
-                if (rare) tp = chain_hop_slow(win, p, pend, nx, npend, fail);
-                if (fail || tp >= stop_at) {
-                    st = ST_END; p = tp; pend = 0;
-                } else {
-                    const uint32_t r = tp - wb;
-                    if ((pm[r >> 5] >> (r & 31u)) & 1u) {
-                        st = ST_MERGED; p = tp; pend = 0;
-                    } else if (k >= (uint32_t)PARSE_EXT_CAP || tp - seg0 > 255u) {
-                        st = ST_OPEN; p = tp; pend = 0;
-                    } else {
-                        myext[k++] = (uint8_t)(tp - seg0);
-                        p = nx; pend = npend;
-                    }
-                }
+                const unsigned long long bit = 1ull << (rel & 63u);
+                if (rel < 64u) e1 |= bit; else e2 |= bit;
+                P = nx; pend = npend;
             }
         }
     }
-    /* a chain that ended on a position it could not look at (p >= stop_at) may still owe a look at a match-length
-     * extension: that position is approximate, which the caller allows for (the list is advisory) */
 
     /* ---- WALK: the real chain, from lane to lane ---- */
     const unsigned long long tq3 = prof_now<PROF>();
-    const uint32_t word = (st == ST_MERGED ? p - wb : 0u) | (st << 16);   /* how this lane's chain ended, and where it merged */
+    const uint32_t word = st == ST_MERGED ? (P - W) >> 6 : 0x80u | (uint32_t)lane;
     unsigned long long onwalk = 0;
     uint32_t cur = 0, endp;
     for (;;) {
-        onwalk |= 1ull << cur;
+        cur = walk_lanes(word, cur, onwalk);
         if (PROF) n_hop++;
-        const uint32_t w = readlane_u32(word, (int)cur);
-        uint32_t s = w >> 16;
-        if (s == ST_MERGED) {                             /* the usual hop */
-            cur = (w & 0xffffu) >> 6;
-            continue;
-        }
-        uint32_t x = readlane_u32(p, (int)cur);
+        uint32_t s = readlane_u32(st, (int)cur);
+        uint32_t x = readlane_u32(P, (int)cur);
         if (s == ST_OPEN) {                               /* its list was full: follow the chain itself */
             uint32_t xp = 0;
             for (;;) {
-                if (x >= stop_at) { s = ST_END; break; }
+                if (x >= STOP) { s = ST_END; break; }
                 if (PROF) n_ser++;
-                uint32_t nx, npend;
-                bool fail;
-                const uint32_t tp = uni(chain_hop_slow(win, x, xp, nx, npend, fail));
-                if (uni(fail ? 1u : 0u) || tp >= stop_at) { x = tp; s = ST_END; break; }
-                const uint32_t r = tp - wb;
+                uint32_t nx, npend, tp = x;
+                bool rare, fail = false;
+                chain_hop(ring, x, xp, LEN, nx, npend, rare);
+                if (uni(rare ? 1u : 0u)) {
+                    tp = uni(chain_hop_slow(win, x - a0, xp, nx, npend, fail)) + a0;
+                    nx += a0;
+                    if (uni(fail ? 1u : 0u) || tp >= STOP) { x = tp; s = ST_END; break; }
+                }
+                const uint32_t r = tp - W;
                 if ((uni(pm[r >> 5]) >> (r & 31u)) & 1u) { x = tp; s = ST_MERGED; break; }
                 if (lane == 0) atomicOr(&pt_[r >> 5], 1u << (r & 31u));
                 x = uni(nx);
                 xp = uni(npend);
             }
             if (s == ST_MERGED) {
-                cur = (x - wb) >> 6;
-                if (lane == 0) prin[cur] = (x - wb) & 63u;             /* entry offset handed over directly */
+                cur = (x - W) >> 6;
+                if (lane == 0) prin[cur] = (x - W) & 63u;             /* entry offset handed over directly */
                 continue;
             }
         }
@@ -299,35 +356,33 @@ __device__ __forceinline__ uint32_t parse_window(ParseWin &win, uint32_t wb, uin
     const unsigned long long tq4 = prof_now<PROF>();
     const bool on = ((onwalk >> lane) & 1ull) != 0;
     lds_sync();
-    if (on && st == ST_MERGED) {                          /* tell the lane this one merged into where the real chain enters it */
-        const uint32_t r = (p - wb);
-        prin[r >> 6] = r & 63u;
-    }
+    if (on && st == ST_MERGED) prin[(P - W) >> 6] = (P - W) & 63u;   /* tell the lane this one merged into where the real chain enters it */
     lds_sync();
     if (on) {
         const uint32_t rin = lane == 0 ? 0u : prin[lane];
-        uint32_t lo = mlo, hi = mhi;
-        if (rin >= 32u) { lo = 0u; hi &= ~0u << (rin - 32u); } else { lo &= ~0u << rin; }
-        if (lo) atomicOr(&pt_[2 * lane], lo);
-        if (hi) atomicOr(&pt_[2 * lane + 1], hi);
-        for (uint32_t j = 0; j < k; j++) {
-            const uint32_t r = 64u * (uint32_t)lane + (uint32_t)myext[j];
-            atomicOr(&pt_[r >> 5], 1u << (r & 31u));
-        }
+        const unsigned long long mine = mask & (~0ull << rin);
+        if ((uint32_t)mine) atomicOr(&pt_[2 * lane], (uint32_t)mine);
+        if ((uint32_t)(mine >> 32)) atomicOr(&pt_[2 * lane + 1], (uint32_t)(mine >> 32));
+        if ((uint32_t)e1) atomicOr(&pt_[2 * lane + 2], (uint32_t)e1);
+        if ((uint32_t)(e1 >> 32)) atomicOr(&pt_[2 * lane + 3], (uint32_t)(e1 >> 32));
+        if ((uint32_t)e2) atomicOr(&pt_[2 * lane + 4], (uint32_t)e2);
+        if ((uint32_t)(e2 >> 32)) atomicOr(&pt_[2 * lane + 5], (uint32_t)(e2 >> 32));
     }
     lds_sync();
-    uint32_t tlo = (uint32_t)lane < nl ? pt_[2 * lane] : 0u, thi = (uint32_t)lane < nl ? pt_[2 * lane + 1] : 0u;
-    const uint32_t c = (uint32_t)__popc(tlo) + (uint32_t)__popc(thi);
+    unsigned long long tm = (uint32_t)lane < nl ? ((unsigned long long)pt_[2 * lane + 1] << 32) | pt_[2 * lane] : 0ull;
+    const uint32_t c = (uint32_t)__popcll(tm);
     const uint32_t incl = wave_inclusive_scan(c);
-    uint32_t slot = incl - c;
+    uint16_t *dst = ptok + (incl - c);
     const uint32_t total = readlane_u32(incl, 63);
-    while (__ballot((tlo | thi) != 0u)) {
+    const uint32_t rel0 = 64u * (uint32_t)lane;
+    while (__ballot(tm != 0ull)) {                        /* four per trip: the exit test costs as much as a position */
         if (PROF) n_list++;
-        if (tlo | thi) {
-            uint32_t b;
-            if (tlo) { b = (uint32_t)__ffs(tlo) - 1u; tlo &= tlo - 1u; }
-            else { b = 32u + (uint32_t)__ffs(thi) - 1u; thi &= thi - 1u; }
-            ptok[slot++] = (uint16_t)(64u * (uint32_t)lane + b);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (tm) {
+                *dst++ = (uint16_t)(rel0 + (uint32_t)__ffsll((long long)tm) - 1u);
+                tm &= tm - 1ull;
+            }
         }
     }
     lds_sync();
@@ -336,7 +391,7 @@ __device__ __forceinline__ uint32_t parse_window(ParseWin &win, uint32_t wb, uin
         pc[0] += tq1 - tq0; pc[1] += tq2 - tq1; pc[2] += tq3 - tq2; pc[3] += tq4 - tq3; pc[4] += tq5 - tq4;
         pc[5] += n_main; pc[6] += n_ext; pc[7] += n_hop; pc[8] += n_ser; pc[9] += n_list;
     }
-    end_ip = endp;
+    end_ip = endp - a0;
     return total;
 }
 
