@@ -37,65 +37,12 @@
  */
 #pragma once
 #include "k4lz4_common.hpp"
+#include "k4lz4_decode_parse.hpp"
 
 namespace k4 {
 
 constexpr int DECODE_STAGE_BYTES = 2048;          /* a batch's output, kept in LDS while its matches resolve */
-constexpr int DECODE_LDS_DWORDS = RING_DWORDS + 5 * 64 + (DECODE_STAGE_BYTES + 64) / 4;   /* ring + 5 descriptor arrays + stage */
-constexpr int MAX_SEQ_PER_ROUND = 22;            /* 64 hypotheses, >= 3 stream bytes per sequence */
-
-/* PARSE's serial part: from hypothesis 0 follow the `next` links while the hypotheses are usable and stay inside
- * the 64-lane window; T collects the real sequences, idx ends on the first position not taken.  A lane's word:
- * bits 0-5 next lane if the chain goes on from here, else the lane itself; bit 7 the chain ends here (hypothesis
- * unusable, or next token outside the window), bit 8 usable, bits 9.. next.  Scalar ISA by hand, and without a branch
- * in the loop-carried path: s_bitset1 and v_readlane take the lane from the low six bits of the word just read, so
- * one v_readlane feeds the next directly, and a lane where the chain ends points at itself, so hopping on is
- * harmless -- 24 hops (a window holds at most 22 sequences) are laid out straight, with an exit test after 8 and 16.
- * The compiler's loop has 14 instructions and two branches per sequence.  The lane the chain stops on is marked before it
- * is known to be usable and unmarked afterwards if it was not. */
-__device__ __forceinline__ uint32_t token_word(bool fast, uint32_t next, int lane)
-{
-    return (fast && next < 64u ? next : (0x80u | (uint32_t)lane)) | (fast ? 0x100u : 0u) | (next << 9);
-}
-__device__ __forceinline__ void follow_tokens(uint32_t word, unsigned long long &T, uint32_t &idx)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t pk = 0;                                        /* a word's low six bits are the next lane: it selects the lane itself */
-    T = 0;
-#define K4_HOP "s_bitset1_b64 %[T], %[pk]\n\ts_nop 2\n\tv_readlane_b32 %[pk], %[word], %[pk]\n\t"
-#define K4_HOP8 K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP
-    asm volatile(
-        K4_HOP8
-        "s_bitcmp1_b32 %[pk], 7\n\t"
-        "s_cbranch_scc1 .Ltok_end%=\n\t"
-        K4_HOP8
-        "s_bitcmp1_b32 %[pk], 7\n\t"
-        "s_cbranch_scc1 .Ltok_end%=\n\t"
-        K4_HOP8
-        ".Ltok_end%=:"
-        : [T] "+s"(T), [pk] "+s"(pk)
-        : [word] "v"(word)
-        : "scc");
-#undef K4_HOP8
-#undef K4_HOP
-    const uint32_t last = 63u - (uint32_t)__builtin_clzll(T);
-    if (pk & 0x100u) {
-        idx = pk >> 9;
-    } else {
-        T &= ~(1ull << last);
-        idx = last;
-    }
-#else
-    T = 0;
-    idx = 0;
-    while (idx < 64u) {
-        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane(word, (int)idx);
-        if (!(pk & 0x100u)) break;
-        T |= 1ull << idx;
-        idx = pk >> 9;
-    }
-#endif
-}
+constexpr int DECODE_LDS_DWORDS = PARSE_LDS_DWORDS + 5 * 64 + (DECODE_STAGE_BYTES + 64) / 4;   /* parser + 5 descriptor arrays + stage */
 
 /* Match copy inside the output block: out[op + i] = out[op - offset + i] with the byte-serial
  * (replicating) semantics of LL64.dec.cs:408-450.  offset >= 1. */
@@ -150,10 +97,13 @@ __device__ __forceinline__ void wave_dict_copy(uint8_t *out, const uint8_t *dict
  * LDS executes in order, so "write the batch, wait for the writes, then advance head" is a release; the reader polls
  * with s_sleep between attempts and gives up (block fails) after PIPE_SPIN_MAX polls instead of hanging.
  */
-constexpr int PIPE_SLOTS = 4;                     /* batches in flight between the two waves (power of two) */
+#ifndef K4_PIPE_SLOTS
+#define K4_PIPE_SLOTS 4
+#endif
+constexpr int PIPE_SLOTS = K4_PIPE_SLOTS;                     /* batches in flight between the two waves (power of two) */
 constexpr int PIPE_DESC = 8 + 8 * PIPE_SLOTS, PIPE_SCRATCH = PIPE_DESC + PIPE_SLOTS * 320, PIPE_STAGE = PIPE_SCRATCH + 128;
 constexpr int PIPE_DWORDS = PIPE_STAGE + (DECODE_STAGE_BYTES + 64) / 4;
-constexpr int DECODE_PAIR_LDS_DWORDS = RING_DWORDS + PIPE_DWORDS;
+constexpr int DECODE_PAIR_LDS_DWORDS = PARSE_LDS_DWORDS + PIPE_DWORDS;
 constexpr uint32_t PIPE_SPIN_MAX = 1u << 24;
 constexpr int PIPE_TIMEOUT = -0x7ffffff0;
 
@@ -204,8 +154,8 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     const bool check_offset = chk_size < 65536;
     const bool prefix64 = dict.mode == 1 && dict.size == 65536u;
     unsigned long long c_parse = 0, c_lit = 0, c_match = 0, n_batch = 0, n_round = 0, n_seq = 0, n_slow = 0;
-    unsigned long long c_hyp = 0, c_chain = 0, c_rules = 0, c_slots = 0, n_spec = 0;   /* PARSE split: speculative rounds */
-    prof_place<PROF>(pc, 8, lane);
+    unsigned long long c_hyp = 0, c_chain = 0, c_wait = 0, n_spec = 0;   /* PARSE split: windows, deriving batches; time spent waiting for the other wave */
+    if (ROLE == 0) prof_place<PROF>(pc, 8, lane);
     const unsigned long long t_begin = prof_now<PROF>();
     if (out_size == 0) {                                   /* LL64.dec.cs:162-168 */
         if (partial) return 0;
@@ -217,9 +167,13 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     }
     if (src_size <= 0) return -1;                          /* :172 */
 
-    StreamRing win;
+    ParseWin win;
     if (ROLE != 2) win.init(lds, in, (uint32_t)src_size, lane);
-    uint32_t *d_lpos = ROLE == 0 ? lds + RING_DWORDS : pipe + PIPE_DESC, *d_llen = d_lpos + 64, *d_out = d_llen + 64,
+    /* the token list of the current window (parse_window): tk_n positions relative to tk_base, tk_i of them used,
+     * the chain goes on at tk_end after the last one */
+    uint32_t tk_n = 0, tk_i = 0, tk_base = 0, tk_end = 0;
+    const uint16_t *ptok = (const uint16_t *)(lds + PARSE_OFF_TOK);
+    uint32_t *d_lpos = ROLE == 0 ? lds + PARSE_LDS_DWORDS : pipe + PIPE_DESC, *d_llen = d_lpos + 64, *d_out = d_llen + 64,
              *d_moff = d_out + 64, *d_mlen = d_moff + 64;
     /* MATCHES sorts destination ranges in two arrays: the descriptor arrays themselves when one wave does it all */
     uint32_t *w_out = ROLE == 0 ? d_out : pipe + PIPE_SCRATCH, *w_end = ROLE == 0 ? d_llen : pipe + PIPE_SCRATCH + 64;
@@ -246,10 +200,13 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             const uint32_t slot = batch_no & (uint32_t)(PIPE_SLOTS - 1);
             meta = pipe + 8 + 8 * slot;
             d_lpos = pipe + PIPE_DESC + 320 * slot; d_llen = d_lpos + 64; d_out = d_llen + 64; d_moff = d_out + 64; d_mlen = d_moff + 64;
+            const unsigned long long tw0 = prof_now<PROF>();
             if (ROLE == 1) {                                /* the slot is free once the other wave has taken batch_no - PIPE_SLOTS */
                 if (batch_no >= (uint32_t)PIPE_SLOTS && !pipe_wait(pipe + 1, batch_no + 1u - (uint32_t)PIPE_SLOTS)) return PIPE_TIMEOUT;
+                if (PROF) c_wait += prof_now<PROF>() - tw0;
             } else {
                 if (!pipe_wait(pipe + 0, batch_no + 1u)) return PIPE_TIMEOUT;
+                if (PROF) c_wait += prof_now<PROF>() - tw0;
                 nseq = (int)uni(meta[0]);
                 op_batch = (int64_t)uni(meta[1]);
                 op = op_batch + (int64_t)uni(meta[2]);
@@ -257,34 +214,53 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 err = (int)uni(meta[4]);                    /* the block's result, valid with `done` */
             }
         }
-        while (ROLE != 2 && nseq <= 64 - MAX_SEQ_PER_ROUND && !done) {
-            /* ---- speculative round: 64 hypotheses "a token starts at ip + lane" ---- */
-            const int64_t lim = shortiend - 1 - ip;        /* hypotheses i < lim satisfy ip + i + 1 < shortiend */
-            if (lim > 0 || iend - RUN_MASK - 1 - ip > 0) {
+        while (ROLE != 2 && nseq < 64 && !done) {
+            /* ---- the next window's token positions, when the list has run out ---- */
+            if (tk_i == tk_n && ip < iend - 16) {
                 const unsigned long long tp0 = prof_now<PROF>();
-                win.ensure((uint32_t)ip + win.a0, lane);
-                const uint32_t q = (uint32_t)ip + win.a0 + (uint32_t)lane;
-                const uint32_t t4 = win.read4(q);
+                tk_base = (uint32_t)ip;
+                tk_n = parse_window(win, tk_base, (uint32_t)(iend - 16), lane, lds, tk_end);
+                tk_i = 0;
+                if (PROF) { c_hyp += prof_now<PROF>() - tp0; n_spec++; }
+            }
+            if (tk_i < tk_n) {
+                /* ---- up to 64 tokens of the list at once: lane i derives the sequence of the i-th ---- */
+                const unsigned long long tp1 = prof_now<PROF>();
+                const uint32_t avail = tk_n - tk_i;
+                uint32_t cnt = avail < 64u - (uint32_t)nseq ? avail : 64u - (uint32_t)nseq;
+                const uint32_t rel = (uint32_t)lane < cnt ? (uint32_t)ptok[tk_i + (uint32_t)lane] : 0u;
+                const uint32_t rel0 = uni(rel);
+                if ((int64_t)tk_base + rel0 != ip) {       /* the list is not where the parser is: drop it */
+                    tk_n = tk_i = 0;
+                    continue;
+                }
+                {   /* all of them inside the ring at once (the scalar parser may have moved it) */
+                    const unsigned long long far = __ballot((uint32_t)lane < cnt && rel - rel0 > 3200u);
+                    if (far) cnt = (uint32_t)ctz64(far);
+                }
+                win.cover((uint32_t)ip + win.a0, tk_base + readlane_u32(rel, (int)cnt - 1) + (uint32_t)PARSE_SLACK + win.a0, lane);
+                const bool act = (uint32_t)lane < cnt;
+                const uint32_t p = tk_base + (act ? rel : rel0);
+                const uint32_t t4 = win.at(p);
                 uint32_t L = (t4 >> 4) & 15u;
                 uint32_t M = t4 & 15u;
                 /* class S: the shortcut (:191-225), literal length in the token.
                  * class G: 15 + one extension byte of literals -> the general literal path (:228-315) */
                 const bool cls_g = L == RUN_MASK;
                 uint32_t hdr = 1u;                          /* token (+ literal-length extension) bytes */
-                bool fast = cls_g ? (int64_t)lane < iend - RUN_MASK - 1 - ip : (int64_t)lane < lim;
+                bool fast = act && (cls_g ? (int64_t)p < iend - RUN_MASK - 1 : (int64_t)p + 1 < shortiend);
                 if (cls_g) {
                     const uint32_t ext = (t4 >> 8) & 0xffu;
                     fast = fast && ext != 255u;
                     L += ext;
                     hdr = 2u;
                     /* the run must leave room for offset + a last sequence (:247) */
-                    fast = fast && (int64_t)ip + lane + hdr + L <= iend - (2 + 1 + LASTLITERALS);
+                    fast = fast && (int64_t)p + hdr + L <= iend - (2 + 1 + LASTLITERALS);
                 }
-                const uint32_t q2 = q + hdr + L;
-                const uint32_t o4 = win.read4(q2);
+                const uint32_t o4 = win.at(p + hdr + L);
                 const uint32_t offset = o4 & 0xffffu;
-                /* where the match-length field ends and the next token starts, relative to ip */
-                uint32_t next = (uint32_t)lane + hdr + L + 2u;
+                /* where the match-length field ends and the next token starts */
+                uint32_t next = p + hdr + L + 2u;
                 uint32_t mlen = M + MINMATCH;
                 fast = fast && offset != 0u;
                 const bool general = cls_g || M == ML_MASK || offset < 8u;   /* not the shortcut's match stage */
@@ -293,19 +269,18 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                     mlen += ext;
                     next += 1u;
                     /* the byte after the extension must stay below iend - LASTLITERALS + 1 */
-                    fast = fast && ext != 255u && (int64_t)ip + next < iend - LASTLITERALS + 1;
+                    fast = fast && ext != 255u && (int64_t)next < iend - LASTLITERALS + 1;
                 }
                 const uint32_t outlen = L + mlen;
-                const uint32_t packed = token_word(fast, next, lane);
-
-                /* follow the true chain from hypothesis 0: one v_readlane per real sequence */
-                unsigned long long T = 0;
-                uint32_t idx = 0;
-                const unsigned long long tp1 = prof_now<PROF>();
-                follow_tokens(packed, T, idx);
-                const unsigned long long tp2 = prof_now<PROF>();
+                /* the list says where the chain went from here: a sequence that ends elsewhere is not this one */
+                const uint32_t succ = (uint32_t)lane + 1u < avail ? tk_base + (uint32_t)ptok[tk_i + (uint32_t)lane + (act ? 1u : 0u)] : tk_end;
+                fast = fast && next == succ;
+                {   /* the first token that needs more, and everything after it, is left to the scalar parser */
+                    const unsigned long long nf = __ballot(act && !fast);
+                    if (nf) cnt = (uint32_t)ctz64(nf);
+                }
+                bool in_t = (uint32_t)lane < cnt;
                 /* output position of every chosen sequence: prefix sum of the chosen lengths */
-                bool in_t = ((T >> lane) & 1ull) != 0;
                 const uint32_t incl = wave_inclusive_scan(in_t ? outlen : 0u);
                 const int64_t v_o64 = op + (int64_t)(incl - (in_t ? outlen : 0u));
                 const uint32_t v_o = (uint32_t)v_o64;
@@ -316,7 +291,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                  * sequence that fails, and everything after it, is left to the scalar parser. */
                 const int64_t mdst_l = v_o64 + L;
                 unsigned long long bad;
-                if (op + (int64_t)__builtin_amdgcn_readlane(incl, 63) <= oend - 64) {
+                if (op + (int64_t)readlane_u32(incl, 63) <= oend - 64) {
                     /* every chosen sequence ends at least 64 bytes before the end of the output: the three
                      * end-of-block rules hold for all of them, only the offset can be wrong */
                     bad = __ballot(in_t && offset > v_o + L);
@@ -324,32 +299,24 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                     bad = __ballot(in_t && ((cls_g ? mdst_l > oend - MFLIMIT : v_o64 > shortoend) || (int64_t)offset > mdst_l ||
                                             (general && mdst_l + (int64_t)mlen > oend - MATCH_SAFEGUARD)));
                 }
-                int64_t cur_op;
                 if (bad) {
-                    const int b = ctz64(bad);
-                    T &= (1ull << b) - 1ull;
-                    idx = (uint32_t)b;
-                    cur_op = op + (int64_t)(__builtin_amdgcn_readlane(incl, b) - __builtin_amdgcn_readlane(outlen, b));
-                    in_t = ((T >> lane) & 1ull) != 0;
-                } else {
-                    cur_op = op + (int64_t)__builtin_amdgcn_readlane(incl, 63);
+                    cnt = (uint32_t)ctz64(bad);
+                    in_t = (uint32_t)lane < cnt;
                 }
-                const unsigned long long tp3 = prof_now<PROF>();
-                if (PROF) { c_hyp += tp1 - tp0; c_chain += tp2 - tp1; c_rules += tp3 - tp2; n_spec++; }
-                if (T) {
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(T >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)T, 0u));
+                if (PROF) c_chain += prof_now<PROF>() - tp1;
+                if (cnt) {
                     if (in_t) {
-                        const uint32_t slot = (uint32_t)nseq + below;
-                        d_lpos[slot] = (uint32_t)ip + (uint32_t)lane + hdr;
+                        const uint32_t slot = (uint32_t)nseq + (uint32_t)lane;
+                        d_lpos[slot] = p + hdr;
                         d_llen[slot] = L;
                         d_out[slot] = v_o;
                         d_moff[slot] = offset;
                         d_mlen[slot] = mlen;
                     }
-                    nseq += __popcll(T);
-                    ip += idx;
-                    op = cur_op;
-                    if (PROF) c_slots += prof_now<PROF>() - tp3;
+                    nseq += (int)cnt;
+                    tk_i += cnt;
+                    ip = (int64_t)readlane_u32(next, (int)cnt - 1);
+                    op += (int64_t)readlane_u32(incl, (int)cnt - 1);
                     continue;
                 }
             }
@@ -466,6 +433,11 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             nseq++;
             op += adv;
             if (last) done = true;
+            if (tk_i < tk_n) {                              /* that was the list's next token: is the list still right? */
+                tk_i++;
+                const uint32_t expect = tk_i < tk_n ? tk_base + uni((uint32_t)ptok[tk_i]) : tk_end;
+                if ((int64_t)expect != ip) tk_n = tk_i = 0;
+            }
         }
         if (ROLE == 1) {                                    /* publish the batch (or the failure) and go on parsing */
             if (lane == 0) {
@@ -479,6 +451,10 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             batch_no++;
             if (err || done) {
                 if (seq) *seq = batch_no;
+                if (PROF && pc && lane == 0) {              /* the parsing wave's half of the pair's record */
+                    pc[0] = prof_now<PROF>() - t_begin; pc[1] = c_hyp; pc[2] = c_chain; pc[3] = c_wait;
+                    pc[4] = batch_no; pc[5] = n_spec; pc[7] = n_slow;
+                }
                 return err ? err : (int)op;
             }
             continue;
@@ -631,6 +607,10 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
         }
         if (ROLE == 2 && done) {                            /* the result the parsing wave arrived at */
             if (seq) *seq = batch_no;
+            if (PROF && pc && lane == 0) {                  /* the copying wave's half */
+                pc[8] = prof_now<PROF>() - t_begin; pc[9] = c_wait; pc[10] = c_lit; pc[11] = c_match;
+                pc[12] = n_batch; pc[13] = n_round; pc[14] = n_seq;
+            }
             return err;
         }
         if (done) break;
@@ -638,7 +618,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     if (PROF && pc && lane == 0) {
         pc[0] = prof_now<PROF>() - t_begin; pc[1] = c_parse; pc[2] = c_lit; pc[3] = c_match;
         pc[4] = n_batch; pc[5] = n_round; pc[6] = n_seq; pc[7] = n_slow;
-        pc[11] = c_hyp; pc[12] = c_chain; pc[13] = c_rules; pc[14] = c_slots; pc[15] = n_spec;
+        pc[11] = c_hyp; pc[12] = c_chain; pc[13] = 0; pc[14] = 0; pc[15] = n_spec;
     }
     prof_place<PROF>(pc, 9, lane);
     return (int)op;
@@ -695,8 +675,11 @@ __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_decode_kernel(Bat
 
 /* ... and with at most half as many blocks as the chip has wave slots, two waves per block: wave 2p parses block p of
  * the workgroup, wave 2p+1 copies (see the queue above).  8 waves per SIMD need <= 64 VGPRs. */
-constexpr int DECODE_PAIRS_PER_WG = 2;     /* measured: 4 pairs per workgroup 233 GiB/s on the bench batch, 2 pairs 242, 1 pair 223 */
-__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k4_decode_pair_kernel(BatchArgs a)
+#ifndef K4_PAIRS_PER_WG
+#define K4_PAIRS_PER_WG 2
+#endif
+constexpr int DECODE_PAIRS_PER_WG = K4_PAIRS_PER_WG;     /* measured: 4 pairs per workgroup 233 GiB/s on the bench batch, 2 pairs 242, 1 pair 223 */
+__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) void k4_decode_pair_kernel(BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
     const int lane = lane_id();
@@ -704,7 +687,7 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
     /* odd workgroups swap the roles, so that a SIMD hosts parsing and copying waves alike */
     const uint32_t pair = wave >> 1, role = (wave ^ blockIdx.x) & 1u;
     const long long slot = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
-    uint32_t *ring = lds[pair], *pipe = lds[pair] + RING_DWORDS;
+    uint32_t *ring = lds[pair], *pipe = lds[pair] + PARSE_LDS_DWORDS;
     if (lane < 8 && role == 0) pipe[lane] = 0u;             /* head, tail */
     __syncthreads();
     if (slot >= a.n) return;
@@ -721,6 +704,34 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
     } else {
         int ret = 0;
         if (run) ret = decode_block<false, 2>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, nullptr, partial, dict, pipe);
+        if (lane == 0) a.outLen[b] = codec_decode_result(src_len, ret, a.flags);
+    }
+}
+
+/* diagnostic twin of the pair kernel: counters [0..7] by the parsing wave (total, windows, deriving, waiting for a free
+ * slot; batches, windows, -, sequences parsed one at a time), [8..14] by the copying wave (total, waiting for a batch,
+ * literals, matches; batches, dependency rounds, sequences) */
+__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) void k4_decode_pair_prof_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
+    const int lane = lane_id();
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t pair = wave >> 1, role = (wave ^ blockIdx.x) & 1u;
+    const long long slot = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
+    uint32_t *ring = lds[pair], *pipe = lds[pair] + PARSE_LDS_DWORDS;
+    if (lane < 8 && role == 0) pipe[lane] = 0u;
+    __syncthreads();
+    if (slot >= a.n) return;
+    const long long b = a.order ? (long long)uni(a.order[slot]) : slot;
+    const int src_len = a.srcLen[b];
+    const int cap = a.dstCap[b];
+    const uint8_t *in = a.src + a.srcOff[b];
+    uint8_t *out = a.dst + a.dstOff[b];
+    if (role == 0) {
+        if (src_len > 0) decode_block<true, 1>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, a.prof + PROF_STRIDE * b, false, DecodeDict{nullptr, 0u, 0}, pipe);
+    } else {
+        int ret = 0;
+        if (src_len > 0) ret = decode_block<true, 2>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, a.prof + PROF_STRIDE * b, false, DecodeDict{nullptr, 0u, 0}, pipe);
         if (lane == 0) a.outLen[b] = codec_decode_result(src_len, ret, a.flags);
     }
 }

@@ -257,10 +257,7 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
                                     dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, a);
             break;
         case KIND_DECODE:
-            if (a.prof && getenv("K4LZ4_PROF_PAIR"))
-                hipLaunchKernelGGL(k4::k4_decode_pair_prof_kernel, dim3((unsigned)((cnt + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
-                                   dim3(128 * k4::DECODE_PAIRS_PER_WG), 0, stream, a);
-            else if (a.prof) hipLaunchKernelGGL(k4::k4_decode_prof_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
+            if (a.prof) hipLaunchKernelGGL(k4::k4_decode_prof_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
             else if (cnt > 24 * (int64_t)ctx->cu_count)   /* more blocks than can be resident (6 waves x 4 SIMDs per CU) */
                 hipLaunchKernelGGL(k4::k4_decode_dense_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
             else if (cnt <= 16 * (int64_t)ctx->cu_count && !getenv("K4LZ4_NO_PAIR"))

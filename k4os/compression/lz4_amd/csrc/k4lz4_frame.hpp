@@ -106,7 +106,7 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t pair = wave >> 1, role = (wave ^ blockIdx.x) & 1u;   /* as in k4_decode_pair_kernel */
     const long long s = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
-    uint32_t *ring = lds[pair], *pipe = lds[pair] + PARSE_LDS_DWORDS;
+    uint32_t *ring = lds[pair], *pipe = lds[pair] + RING_DWORDS;
     if (lane < 8 && role == 0) pipe[lane] = 0u;
     __syncthreads();
     if (s >= a.n) return;

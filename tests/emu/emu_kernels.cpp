@@ -172,49 +172,6 @@ int k4emu_allow_copy(const uint8_t *src, const uint64_t *srcOff, const int32_t *
     return 0;
 }
 
-/* the instrumented twin of the decoder: counters[PROF_STRIDE * i + ..] per block ([4] batches, [6] sequences, [7] of them
- * through the one-at-a-time parser, [15] windows) -- the cycle counters read 0 under the emulator */
-int k4emu_decode_prof_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
-                            const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n,
-                            unsigned long long *counters, int threads)
-{
-    k4::BatchArgs a{};
-    a.src = src; a.srcOff = srcOff; a.srcLen = srcLen; a.dst = dst; a.dstOff = dstOff; a.dstCap = dstCap;
-    a.outLen = outLen; a.n = n; a.accel = 1; a.prof = counters;
-    if (n <= 0) return 0;
-    unsigned grid = (unsigned)((n + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
-    k4emu::launch_fn(dim3(grid), dim3(64 * k4::DECODE_WAVES_PER_WG), [=] { k4::k4_decode_prof_kernel(a); }, threads);
-    return 0;
-}
-
-/* the decoder's window parser alone (k4lz4_decode_parse.hpp): every token position it lists for one block, window after
- * window, until it stops (returns the count; *end = where it stopped, *windows = windows used) */
-int k4emu_parse_tokens(const uint8_t *src, int len, uint32_t *tokens, int max_tokens, uint32_t *end, uint32_t *windows)
-{
-    int count = 0;
-    if (len <= 16) { *end = 0; *windows = 0; return 0; }
-    k4emu::launch_fn(dim3(1), dim3(64), [&] {
-        __shared__ uint32_t lds[k4::PARSE_LDS_DWORDS];
-        const int lane = k4::lane_id();
-        k4::ParseWin win;
-        win.init(lds, src, (uint32_t)len, lane);
-        uint32_t ip = 0, n = 0, w = 0;
-        const uint16_t *ptok = (const uint16_t *)(lds + k4::PARSE_OFF_TOK);
-        while (ip + 16u < (uint32_t)len) {
-            uint32_t e = 0;
-            const uint32_t k = k4::parse_window(win, ip, (uint32_t)len - 16u, lane, lds, e);
-            w++;
-            if (k == 0) break;
-            if (lane == 0) for (uint32_t i = 0; i < k && (int)(n + i) < max_tokens; i++) tokens[n + i] = ip + ptok[i];
-            n += k;
-            ip = e;
-            k4::wave_sync();
-        }
-        if (lane == 0) { count = (int)n; *end = ip; *windows = w; }
-    }, 1);
-    return count;
-}
-
 int k4emu_decode_chain_batch(const uint8_t *src, const uint64_t *blkOff, const uint32_t *blkLen, const uint64_t *firstBlk,
                              const uint32_t *nBlk, const int32_t *blockSize, const uint8_t *chained, uint8_t *dst,
                              const uint64_t *dstOff, const uint64_t *dstCap, long long *outLen, long long n, int threads)

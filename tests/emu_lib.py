@@ -139,26 +139,6 @@ class Emu:
         assert rc == 0
         return out
 
-    def decode_prof_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, threads=0):
-        """the instrumented decoder: (outLen, counters[n, 16])"""
-        out = np.full(len(src_len), -12345, dtype=np.int32)
-        counters = np.zeros((len(src_len), 16), dtype=np.uint64)
-        self.lib.k4emu_decode_prof_batch.argtypes = [_u8p, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
-                                                     C.c_void_p, C.c_int]
-        rc = self.lib.k4emu_decode_prof_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst), dst_off.ctypes.data,
-                                              dst_cap.ctypes.data, out.ctypes.data, len(src_len), counters.ctypes.data, threads)
-        assert rc == 0
-        return out, counters
-
-    def parse_tokens(self, comp):
-        """token positions the decoder's window parser lists for one compressed block: (positions, stop position, windows)"""
-        comp = np.ascontiguousarray(comp, np.uint8)
-        tok = np.zeros(max(16, comp.size), np.uint32)
-        end = C.c_uint32(0); win = C.c_uint32(0)
-        self.lib.k4emu_parse_tokens.argtypes = [_u8p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-        n = self.lib.k4emu_parse_tokens(self._p(comp), comp.size, tok.ctypes.data, tok.size, C.byref(end), C.byref(win))
-        return tok[:n].copy(), int(end.value), int(win.value)
-
     def lane_copy(self, src, soff, dst, doff, length, mode):
         self.lib.k4emu_lane_copy.argtypes = [_u8p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
         rc = self.lib.k4emu_lane_copy(self._p(src), soff.ctypes.data, self._p(dst), doff.ctypes.data, length.ctypes.data,

@@ -551,71 +551,3 @@ def test_lane_run_copies_every_length_and_alignment(emu, mode):
             n = int(length[l])
             want[int(doff[l]):int(doff[l]) + n] = src[int(soff[l]):int(soff[l]) + n]
         assert np.array_equal(dst, want), (trial, int(np.argmax(dst != want)))
-
-
-def _token_positions(comp):
-    """the reference's walk over a valid block (LL64.dec.cs:177-336): position of every token"""
-    c = comp.tolist()
-    n, p, out = len(c), 0, []
-    while p < n:
-        out.append(p)
-        t = c[p]; L = t >> 4; q = p + 1
-        if L == 15:
-            while True:
-                e = c[q]; q += 1; L += e
-                if e != 255:
-                    break
-        q += L
-        if q >= n:          # last sequence: literals only
-            break
-        q += 2
-        if (t & 15) == 15:
-            while True:
-                e = c[q]; q += 1
-                if e != 255:
-                    break
-        p = q
-    return out
-
-
-def test_window_parser_lists_exactly_the_real_tokens(emu, oracle):
-    """parse_window's list is advisory for the decoder, but on valid blocks it must be the real chain -- every token
-    below the end zone, nothing else -- or the decoder silently falls back to its one-token-at-a-time parser"""
-    rng = np.random.default_rng(5)
-    blocks = [corpus.class_bytes(name, 40000, 7) for name in corpus.SILESIA_NAMES]
-    blocks += [corpus.lorem(30000), corpus.repeated(0xAA, 70000), corpus.random_bytes(20000, 3)]
-    # long literal runs and long matches next to dense tokens; 0xFF-heavy literals
-    blocks += [np.concatenate([rng.integers(0, 256, 3000, dtype=np.uint8), corpus.lorem(2000), np.zeros(2500, np.uint8),
-                               np.full(900, 255, np.uint8), corpus.lorem(1500), rng.integers(0, 256, 700, dtype=np.uint8)])]
-    blocks += [np.concatenate([np.full(400, 255, np.uint8), rng.integers(250, 256, 5000, dtype=np.uint8), corpus.lorem(3000)])]
-    for i, b in enumerate(blocks):
-        comp = np.frombuffer(oracle.encode(b), np.uint8)
-        every = _token_positions(comp)
-        want = [p for p in every if p < comp.size - 16]
-        got, end, windows = emu.parse_tokens(comp)
-        # the parser may stop early only on a token it does not follow (length runs of 24+ bytes, the block's last
-        # sequence, which has no offset)
-        assert got.tolist() == want[:len(got)], f"block {i}"
-        if len(got) < len(want):
-            assert end == want[len(got)], f"block {i}: stopped at {end}, next real token {want[len(got)]}"
-            p = want[len(got)]
-            assert p == every[-1] or (comp[p] >> 4 == 15 and (comp[p + 1:p + 25] == 255).all()), f"block {i}: stopped at a token it should follow"
-        # and it gets there in about one window per PARSE_NL * 64 stream bytes, not one per token
-        assert windows <= comp.size // 1500 + 3 + (len(want) - len(got) > 0), f"block {i}: {windows} windows for {comp.size} bytes"
-
-
-def test_decoder_takes_its_sequences_from_the_token_list(emu, oracle):
-    """the one-token-at-a-time parser is for the tokens the list leaves to it (long lengths, the end of a block), not
-    the way the decoder normally works: count what went through it"""
-    blocks = [corpus.class_bytes(name, 65536, 7) for name in corpus.SILESIA_NAMES] + [corpus.lorem(50000)]
-    comp = [np.frombuffer(oracle.encode(b), np.uint8) for b in blocks]
-    src, soff, slen = pack(comp)
-    dst, doff, dcap = arena([b.size for b in blocks])
-    out, c = emu.decode_prof_batch(src, soff, slen, dst, doff, dcap)
-    for i, b in enumerate(blocks):
-        assert out[i] == b.size and dst[int(doff[i]):int(doff[i]) + b.size].tobytes() == b.tobytes()
-        nseq, nslow, windows = int(c[i, 6]), int(c[i, 7]), int(c[i, 15])
-        long_runs = sum(1 for p in _token_positions(comp[i]) if comp[i][p] >> 4 == 15 and comp[i][p + 1] == 255)
-        long_matches = 0   # (ML field 15 followed by 255: counted with the slack below)
-        assert nslow <= long_runs + long_matches + nseq // 50 + 12, f"block {i}: {nslow} of {nseq} sequences parsed one at a time"
-        assert windows <= comp[i].size // 1500 + 3 + nslow, f"block {i}: {windows} windows"
