@@ -116,7 +116,7 @@ constexpr int PARSE_SLACK = 296;               /* bytes past the window that are
 constexpr int PARSE_EXT_TRIPS = 32;            /* steps a chain takes past its own segment before it gives up */
 constexpr int PARSE_TOK_MAX = PARSE_NL * 22;   /* a sequence has at least 3 stream bytes */
 /* LDS of the parser, in dwords: ring (+ mirror) | main marks (2 per lane) | real-token bit set | entry offsets | token list */
-constexpr int PARSE_OFF_MARK = PARSE_RING_DW + 2, PARSE_OFF_TRUE = PARSE_OFF_MARK + 128, PARSE_OFF_RIN = PARSE_OFF_TRUE + 128,
+constexpr int PARSE_OFF_MARK = PARSE_RING_DW + 2, PARSE_OFF_TRUE = PARSE_OFF_MARK + 128, PARSE_OFF_RIN = PARSE_OFF_TRUE + 136,
               PARSE_OFF_TOK = PARSE_OFF_RIN + 64, PARSE_LDS_DWORDS = PARSE_OFF_TOK + (PARSE_TOK_MAX + 1) / 2;
 typedef StreamWin<PARSE_RING_DW> ParseWin;
 
@@ -209,9 +209,9 @@ __device__ __forceinline__ uint32_t walk_lanes(uint32_t word, uint32_t from, uns
  * chain goes on after them (the first position not in the list).  n == 0: the token at wb is left to the scalar
  * parser.  clim = iend - 16: chains only visit positions below it.  `area` = this wave's PARSE_LDS_DWORDS.
  */
-template <bool PROF = false>
+template <bool PROF = false, bool LIST = true>
 __device__ __forceinline__ uint32_t parse_window(ParseWin &win, uint32_t wb, uint32_t clim, int lane, uint32_t *area, uint32_t &end_ip,
-                                                 unsigned long long *pc = nullptr)
+                                                 unsigned long long *pc = nullptr, unsigned long long *bits = nullptr)
 {
     /* diagnostics (PROF): pc[0..4] cycles of cover / MAIN / EXT / WALK / LIST, pc[5..9] their loop trips (WALK: hops, then
      * tokens followed one at a time) */
@@ -375,6 +375,11 @@ __device__ __forceinline__ uint32_t parse_window(ParseWin &win, uint32_t wb, uin
     uint16_t *dst = ptok + (incl - c);
     const uint32_t total = readlane_u32(incl, 63);
     const uint32_t rel0 = 64u * (uint32_t)lane;
+    if (!LIST) {                                          /* the caller works from the segments' bit sets themselves */
+        *bits = tm;
+        end_ip = endp - a0;
+        return total;
+    }
     while (__ballot(tm != 0ull)) {                        /* four per trip: the exit test costs as much as a position */
         if (PROF) n_list++;
 #pragma unroll
