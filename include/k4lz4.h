@@ -22,7 +22,14 @@
  *   - There is NO CPU fallback: without a usable gfx950 device every compute entry point fails
  *     with K4LZ4_E_NO_DEVICE.
  *   - A k4lz4_ctx is bound to one GPU and may be used by one host thread at a time; different
- *     contexts are independent (reentrant like the reference's static API).
+ *     contexts are independent (reentrant like the reference's static API).  The context owns device
+ *     scratch (dispatch order, hash tables, HC work areas) that every call reuses: calls on ONE context
+ *     are therefore serialised on the device even when they are given different streams (the second
+ *     call's stream waits for the first call's work); use one context per stream for concurrency.
+ *   - Trouble that is not a property of a block's data (a decoder wave pair timing out on its partner,
+ *     an HC scratch reservation that was too small) is never reported through outLen alone: the blocks
+ *     concerned say "failed" AND the next synchronising call on the context (every host-pointer call,
+ *     k4lz4_synchronize) returns K4LZ4_E_HIP / K4LZ4_E_NOMEM with the reason in k4lz4_last_error().
  */
 #ifndef K4LZ4_H
 #define K4LZ4_H
@@ -76,8 +83,15 @@ K4LZ4_API void k4lz4_ctx_destroy(k4lz4_ctx *ctx);
 /* ctx may be NULL: last error of the calling thread's implicit context / of ctx creation */
 K4LZ4_API const char *k4lz4_last_error(const k4lz4_ctx *ctx);
 K4LZ4_API int k4lz4_ctx_device(const k4lz4_ctx *ctx);
-/* blocks until everything this ctx enqueued on `stream` (NULL = default stream) has finished */
+/* blocks until everything this ctx enqueued on `stream` (NULL = default stream) has finished; returns the call-level
+ * status of that work (see "Trouble that is not a property of a block's data" above) */
 K4LZ4_API int k4lz4_synchronize(k4lz4_ctx *ctx, void *stream);
+/* HC levels (L03_HC and up) need work areas proportional to the batch: 36 bytes per input byte.  A device-resident call
+ * does not know its batch's size on the host, so by default it reads it back -- ONE synchronisation per 4096 blocks.
+ * After this call, device-resident HC encodes / pickles on ctx whose blocks total at most totalSrcBytes (per call) and are
+ * at most longestBlock bytes each only enqueue, like every other *_device call; a batch that exceeds the reservation is
+ * not encoded (outLen = failure, K4LZ4_E_NOMEM at the next synchronising call).  (0, 0) removes the reservation. */
+K4LZ4_API int k4lz4_ctx_reserve_hc(k4lz4_ctx *ctx, int64_t totalSrcBytes, int32_t longestBlock);
 
 /* LZ4Codec.MaximumOutputSize (LZ4Codec.cs:30-31) == LL.LZ4_compressBound (Engine/LL.tools.cs:38-40).
  * Pure host arithmetic. */
@@ -94,7 +108,8 @@ K4LZ4_API int k4lz4_compress_bound(int n);
 K4LZ4_API int k4lz4_last_status(void);
 /* LLxx.LZ4_compress_fast (Engine/LLxx.cs:65-75) */
 K4LZ4_API int k4lz4_compress_fast(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap, int acceleration);
-/* LLxx.LZ4_compress_HC (Engine/LLxx.cs:94-103) */
+/* LLxx.LZ4_compress_HC (Engine/LLxx.cs:94-103); level >= K4LZ4_L03_HC (LZ4Level has nothing between FAST and L03_HC, and
+ * LZ4Codec routes lower values to the fast encoder, LZ4Codec.cs:48-50): lower values fail with K4LZ4_E_ARG */
 K4LZ4_API int k4lz4_compress_hc(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap, int level);
 /* LLxx.LZ4_decompress_safe (Engine/LLxx.cs:17-26) */
 K4LZ4_API int k4lz4_decompress_safe(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap);

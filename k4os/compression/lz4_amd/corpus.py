@@ -275,3 +275,27 @@ def variable_messages(n_msgs: int, seed: int = 4, lo: int = 1024, hi: int = 4 <<
             chunk = np.tile(src, -(-int(ln) // src.size))[:ln]
         out[o:o + ln] = chunk
     return out, offs[:-1].astype(np.uint64), lens.astype(np.int32)
+
+
+def config4_lengths(n_msgs: int = 100000, seed: int = 4, lo: int = 1024, hi: int = 4 << 20) -> np.ndarray:
+    """BASELINE.json configs[3]: the message lengths of the whole batch (log-uniform in [lo, hi]); every rank computes the
+    same vector and takes its byte-balanced range of it (sharding.byte_balanced_ranges)."""
+    rng = np.random.default_rng(seed)
+    return np.exp(rng.uniform(np.log(lo), np.log(hi), size=n_msgs)).astype(np.int64)
+
+
+def config4_share(lens_all: np.ndarray, lo: int, hi: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Messages [lo, hi) of the configs[3] batch: content alternates random / text-like by GLOBAL message index, cut out of
+    8 MiB of material at an index-dependent position, so any split of the batch into ranges produces the same bytes.
+    Returns (packed bytes, uint64 offsets, int32 lengths)."""
+    lens = lens_all[lo:hi].astype(np.int32)
+    off = np.concatenate(([0], np.cumsum(lens.astype(np.int64))))[:-1].astype(np.uint64)
+    total = int(lens.astype(np.int64).sum())
+    text = class_bytes("dickens", 8 << 20, 5)
+    rnd = random_bytes(8 << 20, 6)
+    data = np.empty(max(total, 1), np.uint8)
+    for i in range(lens.size):
+        srcbuf = rnd if ((lo + i) & 1) == 0 else text
+        st = ((lo + i) * 7919) % (srcbuf.size - int(lens[i]))
+        data[int(off[i]):int(off[i]) + int(lens[i])] = srcbuf[st:st + int(lens[i])]
+    return data[:total] if total else data[:0], off, lens

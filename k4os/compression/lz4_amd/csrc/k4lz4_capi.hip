@@ -49,6 +49,18 @@ struct k4lz4_ctx {
     uint8_t *d_hc_hash = nullptr; size_t d_hc_hash_cap = 0;   /* HC: per-block hash tables of one launch chunk */
     uint8_t *d_hc_work = nullptr; size_t d_hc_work_cap = 0;   /* HC: prev[] / cand[] of one launch chunk */
     uint8_t *d_hc_meta = nullptr; size_t d_hc_meta_cap = 0;   /* HC: work offsets, pickle slots */
+    /* The scratch above is shared by all calls on this context but ordered only by the stream a call runs on: the end of
+     * every launch is recorded here and the next launch on a DIFFERENT stream waits for it before it touches the scratch
+     * (calls on one context are serialised across streams). */
+    hipEvent_t ev_busy = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool busy = false;
+    /* k4lz4_ctx_reserve_hc: HC levels sized without asking the device (0 = not reserved) */
+    uint64_t hc_res_total = 0; uint32_t hc_res_longest = 0;
+    /* diagnostic switches, read once at creation: K4LZ4_SPLIT_PCT (1..100, share of an encode batch on the LDS-table kernel),
+     * K4LZ4_NO_PAIR (decode with one wave per block) */
+    int split_pct = -1;
+    bool no_pair = false;
 };
 
 namespace {
@@ -90,20 +102,35 @@ int check_level(k4lz4_ctx *ctx, int level)
 
 int grow(k4lz4_ctx *ctx, uint8_t **p, size_t *cap, size_t need, bool pinned);
 
+/* after a synchronisation: did a kernel of this device report call-level trouble (k4_dev_status)?  Reads and clears it. */
+int take_device_status(k4lz4_ctx *ctx)
+{
+    uint32_t v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(k4::k4_dev_status), sizeof v) != hipSuccess) { (void)hipGetLastError(); return K4LZ4_OK; }
+    if (v == 0) return K4LZ4_OK;
+    const uint32_t zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(k4::k4_dev_status), &zero, sizeof zero);
+    if (v & k4::DEV_STATUS_HC_SCRATCH)
+        return fail(ctx, K4LZ4_E_NOMEM, "HC scratch reserved with k4lz4_ctx_reserve_hc was too small for the batch: its blocks were not encoded");
+    return fail(ctx, K4LZ4_E_HIP, "a decoder wave gave up waiting for its partner wave (scheduling time-out, not corrupt data): the affected blocks report failure");
+}
+
 /* HC levels: layout -> (sync for the scratch size) -> hash-table clear -> chain kernel -> parse kernel.
  * `pickle`: the same around the LZ4Pickler envelope (encoder slot = envelope + 5, cap U - 1). */
+/* hostLen: the blocks' lengths when the caller has them on the host (host-pointer calls), else nullptr */
 int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
               const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level, int flags,
-              hipStream_t stream)
+              hipStream_t stream, const int32_t *hostLen)
 {
     const int64_t chunk_max = 4096;   /* 128 KiB of hash table per block in flight */
     for (int64_t first = 0; first < n; first += chunk_max) {
         const int64_t cnt = std::min<int64_t>(chunk_max, n - first);
-        /* the scratch of the previous chunk / call must be idle before it is resized or reused */
-        K4_HIP(ctx, hipStreamSynchronize(stream));
-        int rc = grow(ctx, &ctx->d_hc_hash, &ctx->d_hc_hash_cap, (size_t)cnt << (k4::HC_HASH_LOG + 2), false);
+        /* scratch that has to grow is freed first: what still runs on it must be finished (same-stream reuse needs no wait) */
+        const size_t need_hash = (size_t)cnt << (k4::HC_HASH_LOG + 2), need_meta = (size_t)(cnt + 2) * 8 + (size_t)cnt * 16 + 64;
+        if (need_hash > ctx->d_hc_hash_cap || need_meta > ctx->d_hc_meta_cap) K4_HIP(ctx, hipStreamSynchronize(stream));
+        int rc = grow(ctx, &ctx->d_hc_hash, &ctx->d_hc_hash_cap, need_hash, false);
         if (rc != K4LZ4_OK) return rc;
-        rc = grow(ctx, &ctx->d_hc_meta, &ctx->d_hc_meta_cap, (size_t)(cnt + 2) * 8 + (size_t)cnt * 16 + 64, false);
+        rc = grow(ctx, &ctx->d_hc_meta, &ctx->d_hc_meta_cap, need_meta, false);
         if (rc != K4LZ4_OK) return rc;
         unsigned long long *d_woff = (unsigned long long *)ctx->d_hc_meta;
         uint64_t *d_encoff = (uint64_t *)(d_woff + cnt + 2);
@@ -121,12 +148,37 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
             hipLaunchKernelGGL(k4::k4_pickle_prep_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, a, d_encoff, d_enccap);
             h.dstOff = d_encoff; h.dstCap = d_enccap; h.outLen = d_enclen; h.flags = K4LZ4_FLAG_RAW_RETURN;
         }
-        hipLaunchKernelGGL(k4::k4_hc_layout_kernel, dim3(1), dim3(256), 0, stream, h);
+        /* How much work area, and how long the longest block is: from the host's copy of the lengths, from the
+         * reservation (k4lz4_ctx_reserve_hc), or -- the only case that synchronises -- from the device. */
         unsigned long long tail[2] = {0, 0};   /* total work bytes, longest block */
-        K4_HIP(ctx, hipMemcpyAsync(tail, d_woff + cnt, 16, hipMemcpyDeviceToHost, stream));
-        K4_HIP(ctx, hipStreamSynchronize(stream));
-        rc = grow(ctx, &ctx->d_hc_work, &ctx->d_hc_work_cap, (size_t)tail[0] + 256, false);
-        if (rc != K4LZ4_OK) return rc;
+        bool ask_device = false;
+        if (hostLen) {
+            for (int64_t i = 0; i < cnt; i++) {
+                const int32_t len = hostLen[first + i];
+                if (len > 0) {
+                    tail[0] += (((unsigned long long)len + 3u) & ~3ull) * 36u;
+                    tail[1] = std::max<unsigned long long>(tail[1], (unsigned long long)len);
+                }
+            }
+        } else if (ctx->hc_res_total) {
+            tail[0] = (ctx->hc_res_total + 4u * (unsigned long long)cnt) * 36u;
+            tail[1] = ctx->hc_res_longest;
+            h.workCap = tail[0]; h.maxLen = ctx->hc_res_longest;
+        } else {
+            ask_device = true;
+        }
+        if (!ask_device && (size_t)tail[0] + 256 > ctx->d_hc_work_cap) K4_HIP(ctx, hipStreamSynchronize(stream));
+        if (!ask_device) {
+            rc = grow(ctx, &ctx->d_hc_work, &ctx->d_hc_work_cap, (size_t)tail[0] + 256, false);
+            if (rc != K4LZ4_OK) return rc;
+        }
+        hipLaunchKernelGGL(k4::k4_hc_layout_kernel, dim3(1), dim3(256), 0, stream, h);
+        if (ask_device) {
+            K4_HIP(ctx, hipMemcpyAsync(tail, d_woff + cnt, 16, hipMemcpyDeviceToHost, stream));
+            K4_HIP(ctx, hipStreamSynchronize(stream));
+            rc = grow(ctx, &ctx->d_hc_work, &ctx->d_hc_work_cap, (size_t)tail[0] + 256, false);
+            if (rc != K4LZ4_OK) return rc;
+        }
         h.work = ctx->d_hc_work;
         K4_HIP(ctx, hipMemsetAsync(ctx->d_hc_hash, 0, (size_t)cnt << (k4::HC_HASH_LOG + 2), stream));
         hipLaunchKernelGGL(k4::k4_hc_chain_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
@@ -156,15 +208,32 @@ struct DictArgs {
 };
 
 /* enqueue the kernels for n blocks; all pointers are device pointers */
+int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                 const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level, int flags,
+                 hipStream_t stream, const DictArgs *dd, const int32_t *hostLen);
+
 int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
            const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level, int flags,
-           hipStream_t stream, const DictArgs *dd = nullptr)
+           hipStream_t stream, const DictArgs *dd = nullptr, const int32_t *hostLen = nullptr)
 {
     if (n == 0) return K4LZ4_OK;
+    /* the context's scratch (dispatch order, global hash tables, HC work areas) may still be in use by a call that was
+     * enqueued on another stream */
+    if (ctx->busy && ctx->last_stream != stream) K4_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_busy, 0));
+    const int rc = launch_inner(ctx, kind, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, stream, dd, hostLen);
+    if (hipEventRecord(ctx->ev_busy, stream) == hipSuccess) { ctx->busy = true; ctx->last_stream = stream; }
+    else (void)hipGetLastError();
+    return rc;
+}
+
+int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                 const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level, int flags,
+                 hipStream_t stream, const DictArgs *dd, const int32_t *hostLen)
+{
     const int64_t chunk_max = 1 << 24;   /* blocks per launch (grid.x * blockDim.x must stay < 2^32) */
     const bool encode_like = kind == KIND_ENCODE || kind == KIND_PICKLE;
     if (encode_like && level >= K4LZ4_L03_HC) {
-        const int rc = launch_hc(ctx, kind == KIND_PICKLE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, stream);
+        const int rc = launch_hc(ctx, kind == KIND_PICKLE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, stream, hostLen);
         if (rc != K4LZ4_OK || kind != KIND_ENCODE || !(flags & K4LZ4_FLAG_ALLOW_COPY)) return rc;
         for (int64_t first = 0; first < n; first += chunk_max) {
             const int64_t cnt = std::min<int64_t>(chunk_max, n - first);
@@ -223,13 +292,12 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
                 /* measured on MI355X (profiles/r02_split_sweep.txt): best when the LDS-table kernel gets one full
                  * residency of the chip (8 blocks per CU) or about 48 % of a larger batch; one block more
                  * than a residency starts a second pass and costs 20 % */
-                const char *pct_env = getenv("K4LZ4_SPLIT_PCT");
                 const int64_t lds_slots = 8 * (int64_t)ctx->cu_count;
-                const int64_t n_lds = pct_env ? std::max<int64_t>(1, cnt * atoi(pct_env) / 100)
-                                              : std::min<int64_t>(cnt, std::max<int64_t>(lds_slots, cnt * 48 / 100));
+                const int64_t n_lds = ctx->split_pct > 0 ? std::min<int64_t>(cnt, std::max<int64_t>(1, cnt * ctx->split_pct / 100))
+                                                         : std::min<int64_t>(cnt, std::max<int64_t>(lds_slots, cnt * 48 / 100));
                 const int64_t n_g = cnt - n_lds;
                 const int64_t gchunk = 8192;
-                if ((size_t)std::min(n_g, gchunk) * 16384 > ctx->d_gtab_cap) {
+                if (n_g > 0 && (size_t)std::min(n_g, gchunk) * 16384 > ctx->d_gtab_cap) {
                     K4_HIP(ctx, hipStreamSynchronize(ctx->aux));
                     int rc2 = grow(ctx, &ctx->d_gtab, &ctx->d_gtab_cap, (size_t)std::min(n_g, gchunk) * 16384, false);
                     if (rc2 != K4LZ4_OK) return rc2;
@@ -260,7 +328,7 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
             if (a.prof) hipLaunchKernelGGL(k4::k4_decode_prof_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
             else if (cnt > 24 * (int64_t)ctx->cu_count)   /* more blocks than can be resident (6 waves x 4 SIMDs per CU) */
                 hipLaunchKernelGGL(k4::k4_decode_dense_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
-            else if (cnt <= 16 * (int64_t)ctx->cu_count && !getenv("K4LZ4_NO_PAIR"))
+            else if (cnt <= 16 * (int64_t)ctx->cu_count && !ctx->no_pair)
                 /* at most half the chip's wave slots (8 per SIMD at 64 VGPRs) are needed: two waves per block, one
                  * parsing ahead of the one that copies */
                 hipLaunchKernelGGL(k4::k4_decode_pair_kernel, dim3((unsigned)((cnt + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
@@ -271,7 +339,7 @@ int launch(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff
             hipLaunchKernelGGL(k4::k4_pickle_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a);
             break;
         case KIND_UNPICKLE:
-            if (cnt <= 64 * (int64_t)ctx->cu_count && !getenv("K4LZ4_NO_PAIR"))
+            if (cnt <= 64 * (int64_t)ctx->cu_count && !ctx->no_pair)
                 hipLaunchKernelGGL(k4::k4_unpickle_pair_kernel, dim3((unsigned)((cnt + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
                                    dim3(128 * k4::DECODE_PAIRS_PER_WG), 0, stream, a);
             else hipLaunchKernelGGL(k4::k4_unpickle_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
@@ -390,11 +458,12 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
             ddev = DictArgs{base, d_dictoff, d_dictlen, d_mode};
         }
     }
-    rc = launch(ctx, kind, ctx->d_src, d_soff, d_slen, ctx->d_dst, d_doff, d_cap, d_out, n, level, flags, st, &ddev);
+    rc = launch(ctx, kind, ctx->d_src, d_soff, d_slen, ctx->d_dst, d_doff, d_cap, d_out, n, level, flags, st, &ddev, srcLen);
     if (rc != K4LZ4_OK) return rc;
     K4_HIP(ctx, hipMemcpyAsync(outLen, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     if (dtotal) K4_HIP(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_dst, (size_t)dtotal, hipMemcpyDeviceToHost, st));
     K4_HIP(ctx, hipStreamSynchronize(st));
+    if ((rc = take_device_status(ctx)) != K4LZ4_OK) return rc;
     for (int64_t i = 0; i < n; i++) {
         const int32_t got = outLen[i];
         const int32_t stored = (got < 0 && (flags & K4LZ4_FLAG_ALLOW_COPY) && kind == KIND_ENCODE) ? -got : got;   /* raw blocks come back as -length */
@@ -494,6 +563,9 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_busy, hipEventDisableTiming);
+    if (const char *pct = getenv("K4LZ4_SPLIT_PCT")) { const int v = atoi(pct); ctx->split_pct = v < 1 ? 1 : (v > 100 ? 100 : v); }
+    ctx->no_pair = getenv("K4LZ4_NO_PAIR") != nullptr;
     if (e != hipSuccess) { delete ctx; return hip_fail(nullptr, e, "hipStreamCreate"); }
     *out = ctx;
     return K4LZ4_OK;
@@ -507,6 +579,7 @@ void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_busy) (void)hipEventDestroy(ctx->ev_busy);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
     if (ctx->d_dict) (void)hipFree(ctx->d_dict);
     if (ctx->d_src) (void)hipFree(ctx->d_src);
@@ -529,6 +602,15 @@ int k4lz4_synchronize(k4lz4_ctx *ctx, void *stream)
     if (!ctx) return fail(nullptr, K4LZ4_E_ARG, "ctx is NULL");
     K4_HIP(ctx, hipSetDevice(ctx->device));
     K4_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return take_device_status(ctx);
+}
+
+int k4lz4_ctx_reserve_hc(k4lz4_ctx *ctx, int64_t totalSrcBytes, int32_t longestBlock)
+{
+    if (!ctx) return fail(nullptr, K4LZ4_E_ARG, "ctx is NULL");
+    if (totalSrcBytes < 0 || longestBlock < 0) return fail(ctx, K4LZ4_E_ARG, "negative reservation");
+    ctx->hc_res_total = (uint64_t)totalSrcBytes;
+    ctx->hc_res_longest = (uint32_t)longestBlock;
     return K4LZ4_OK;
 }
 
@@ -543,7 +625,13 @@ int k4lz4_compress_fast(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap
 
 int k4lz4_compress_hc(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap, int level)
 {
-    return single(KIND_ENCODE, src, dst, srcLen, dstCap, level < K4LZ4_L03_HC ? K4LZ4_L03_HC : level);
+    /* LZ4Level has no value between L00_FAST and L03_HC and LZ4Codec never passes one (LZ4Codec.cs:48-50); the upstream
+     * meaning of levels below 3 (default 9 / two attempts, LL64.high.cs:1155-1160) is not implemented: refuse, do not guess */
+    if (level < K4LZ4_L03_HC) {
+        tl_status = fail(nullptr, K4LZ4_E_ARG, "k4lz4_compress_hc: level must be L03_HC (3) or higher");
+        return 0;
+    }
+    return single(KIND_ENCODE, src, dst, srcLen, dstCap, level);
 }
 
 int k4lz4_decompress_safe(const uint8_t *src, uint8_t *dst, int srcLen, int dstCap)
@@ -724,7 +812,7 @@ int k4lz4_decode_chain_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const ui
     K4_HIP(ctx, hipSetDevice(ctx->device));
     k4::ChainArgs a{src, blkOff, blkLen, firstBlk, nBlk, blockSize, chained, dst, dstOff, dstCap, (long long *)outLen, nStreams};
     const unsigned grid = (unsigned)((nStreams + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
-    if (nStreams <= 16 * (int64_t)ctx->cu_count && !getenv("K4LZ4_NO_PAIR"))    /* room for two waves per stream */
+    if (nStreams <= 16 * (int64_t)ctx->cu_count && !ctx->no_pair)    /* room for two waves per stream */
         hipLaunchKernelGGL(k4::k4_decode_chain_pair_kernel, dim3((unsigned)((nStreams + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
                            dim3(128 * k4::DECODE_PAIRS_PER_WG), 0, (hipStream_t)stream, a);
     else
@@ -794,6 +882,7 @@ int k4lz4_decode_chain_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t 
     K4_HIP(ctx, hipMemcpyAsync(outLen, d_out, (size_t)nStreams * 8, hipMemcpyDeviceToHost, st));
     if (dtotal) K4_HIP(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_dst, (size_t)dtotal, hipMemcpyDeviceToHost, st));
     K4_HIP(ctx, hipStreamSynchronize(st));
+    if ((rc = take_device_status(ctx)) != K4LZ4_OK) return rc;
     for (int64_t i = 0; i < nStreams; i++)
         if (outLen[i] > 0 && (uint64_t)outLen[i] <= dstCap[i]) memcpy(dst + dstOff[i], ctx->h_stage + h_doff[(size_t)i], (size_t)outLen[i]);
     return K4LZ4_OK;

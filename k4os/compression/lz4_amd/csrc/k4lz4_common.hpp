@@ -83,6 +83,13 @@ __device__ __forceinline__ void wave_sync()
 
 constexpr int PROF_STRIDE = 16;
 
+/* Call-level trouble that is not a property of any block's data: bit 0 = a wave of a decoder pair gave up waiting for
+ * its partner (scheduling, never corrupt input), bit 1 = the HC scratch reserved for an asynchronous call was too small.
+ * The host reads and clears it whenever it synchronises (k4lz4_synchronize, every host-pointer call) and reports
+ * K4LZ4_E_HIP -- the affected blocks' outLen only say "failed". */
+__device__ uint32_t k4_dev_status;
+enum : uint32_t { DEV_STATUS_PIPE_TIMEOUT = 1u, DEV_STATUS_HC_SCRATCH = 2u };
+
 /* placement record of the diagnostic kernels: [8] start, [9] end (100 MHz real-time counter), [10] HW_ID */
 template <bool PROF> __device__ __forceinline__ void prof_place(unsigned long long *pc, int slot, int lane)
 {

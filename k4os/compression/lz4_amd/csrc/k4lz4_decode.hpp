@@ -182,6 +182,7 @@ __device__ __forceinline__ bool pipe_wait(const uint32_t *p, uint32_t want)
         if (pipe_load(p) >= want) return true;
         __builtin_amdgcn_s_sleep(1);
     }
+    atomicOr(&k4_dev_status, (uint32_t)DEV_STATUS_PIPE_TIMEOUT);   /* reported at call level: not this block's fault */
     return false;
 }
 

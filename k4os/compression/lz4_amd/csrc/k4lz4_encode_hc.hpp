@@ -64,7 +64,16 @@ struct HcArgs {
     uint8_t *work;             /* prev[] and cand[] of every block */
     unsigned int posBase;      /* k4_hc_cand_kernel: first position covered by blockIdx.y == 0 */
     unsigned long long *workOff;   /* n + 2: byte offset of block i's work area, [n] = total, [n+1] = longest block (k4_hc_layout_kernel) */
+    unsigned long long workCap;    /* bytes behind `work` when the launch was sized without asking the device (0 = sized from [n]) */
+    unsigned int maxLen;           /* the longest block the launch was sized for (same case) */
 };
+
+/* a launch sized from a reservation (k4lz4_ctx_reserve_hc) whose batch turned out bigger: nothing is touched, every block
+ * fails and the context's status word says why */
+__device__ __forceinline__ bool hc_scratch_ok(const HcArgs &a)
+{
+    return a.workCap == 0ull || (a.workOff[a.n] <= a.workCap && a.workOff[a.n + 1] <= (unsigned long long)a.maxLen);
+}
 
 __device__ __forceinline__ uint32_t hc_hash(uint32_t v) { return (v * 2654435761u) >> (MINMATCH * 8 - HC_HASH_LOG); }
 constexpr uint32_t HC_FLEN_CAP = 4 + 32;   /* precomputed match lengths are exact below this value */
@@ -98,7 +107,11 @@ __global__ __launch_bounds__(256) void k4_hc_layout_kernel(HcArgs a)
         a.workOff[i] = base;
         base += hc_work_bytes(a.srcLen[i]);
     }
-    if (t == 255) a.workOff[a.n] = base;
+    if (t == 255) {
+        a.workOff[a.n] = base;
+        if (a.workCap != 0ull && base > a.workCap) atomicOr(&k4_dev_status, (uint32_t)DEV_STATUS_HC_SCRATCH);
+    }
+    if (t == 0 && a.workCap != 0ull && a.workOff[a.n + 1] > (unsigned long long)a.maxLen) atomicOr(&k4_dev_status, (uint32_t)DEV_STATUS_HC_SCRATCH);
 }
 
 /* ---- kernel 1: chains ------------------------------------------------------------------- */
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(64) void k4_hc_chain_kernel(HcArgs a)
     const int lane = lane_id();
     const long long b = (long long)blockIdx.x;
     const int len = a.srcLen[b];
-    if (len < MFLIMIT + 1) return;                         /* no search happens (LL64.high.cs:549) */
+    if (len < MFLIMIT + 1 || !hc_scratch_ok(a)) return;    /* no search happens (LL64.high.cs:549) */
     const uint32_t U = (uint32_t)len;
     const uint8_t *src = a.src + a.srcOff[b];
     uint32_t *tab = a.hash + (size_t)b * (1u << HC_HASH_LOG);
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(256) void k4_hc_cand_kernel(HcArgs a)
 {
     const long long b = (long long)blockIdx.x;
     const int len = a.srcLen[b];
-    if (len < MFLIMIT + 1) return;
+    if (len < MFLIMIT + 1 || !hc_scratch_ok(a)) return;
     const uint32_t U = (uint32_t)len;
     const uint32_t npos = U - 3u;
     const uint32_t first = a.posBase + (uint32_t)blockIdx.y * (uint32_t)HC_CAND_POS_PER_WG;
@@ -979,7 +992,7 @@ __global__ __launch_bounds__(64) void k4_hc_parse_kernel(HcArgs a)
     const int src_len = a.srcLen[b];
     const int cap = a.dstCap[b];
     int ret = 0;
-    if (src_len > 0 || (a.flags & FLAG_RAW_RETURN)) {
+    if ((src_len > 0 || (a.flags & FLAG_RAW_RETURN)) && hc_scratch_ok(a)) {
         const uint32_t *prev = (const uint32_t *)(a.work + a.workOff[b]);
         const uint32_t al = ((uint32_t)(src_len > 0 ? src_len : 0) + 3u) & ~3u;
         const uint32_t *cand = prev + al;
@@ -1006,7 +1019,7 @@ __global__ __launch_bounds__(64) void k4_hc_parse_opt_kernel(HcArgs a)
     const int src_len = a.srcLen[b];
     const int cap = a.dstCap[b];
     int ret = 0;
-    if (src_len > 0 || (a.flags & FLAG_RAW_RETURN)) {
+    if ((src_len > 0 || (a.flags & FLAG_RAW_RETURN)) && hc_scratch_ok(a)) {
         const uint32_t *prev = (const uint32_t *)(a.work + a.workOff[b]);
         ret = hc_parse_block_opt(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.level, prev, opt_lds, lane);
     }

@@ -1,0 +1,178 @@
+"""BASELINE.json configs[2], [3], [4] at FULL size against the oracle (the -m gpu suite's other files cover them at reduced
+size).  The compressed inputs of the decode run come from the oracle, not from the GPU encoder, so the path is never
+compared with itself.  Budget on the GPU box: about a minute each (host-side oracle work included)."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from k4os.compression.lz4_amd import LZ4Codec, LZ4Level, corpus, make_arena
+from k4os.compression.lz4_amd._native import FLAG_RAW_RETURN
+from k4os.compression.lz4_amd.sharding import byte_balanced_ranges
+
+pytestmark = pytest.mark.gpu
+THREADS = os.cpu_count() or 8
+
+
+def test_config2_decode_only_1m_blocks_of_4k_oracle_encoded(oracle):
+    """configs[2]: 1 048 576 pre-compressed 4 KiB blocks, decode-only, both variants of SURVEY.md 8(d): the text-like mix
+    and random bytes.  Every block's size and every output byte is checked (on the device) against the source."""
+    import torch
+    from k4os.compression.lz4_amd.device import DeviceBatch, DeviceCodec
+    n, bs = 1 << 20, 4096
+    dc = DeviceCodec(0)
+    for variant in ("silesia-like", "random"):
+        if variant == "random":
+            blocks = np.random.default_rng(7).integers(0, 256, size=(n, bs), dtype=np.uint8)
+        else:
+            blocks = corpus.silesia_like_blocks(n, bs, seed=3, unique_bytes_per_class=1 << 24)
+        lens = np.full(n, bs, np.int32)
+        off = np.arange(n, dtype=np.uint64) * bs
+        caps = np.full(n, LZ4Codec.MaximumOutputSize(bs), np.int32)
+        ref, ref_off = make_arena(caps)
+        clen = oracle.encode_batch(blocks.reshape(-1), off, lens, ref, ref_off, caps, threads=THREADS)   # the ORACLE's streams
+        assert (clen > 0).all()
+        comp = DeviceBatch.from_host(ref, ref_off, clen, dc.device)
+        back = DeviceBatch.empty_slots(lens, dc.device, fill=0xCD)
+        dlen = dc.decode(comp, back)
+        torch.cuda.synchronize()
+        assert bool((dlen == bs).all().item()), variant
+        want = torch.from_numpy(blocks.reshape(-1)).to(dc.device)
+        assert torch.equal(back.data[:n * bs], want), variant
+        assert bool((back.data[n * bs:] == 0xCD).all().item())
+        del comp, back, want
+        torch.cuda.empty_cache()
+
+
+def test_config3_pickle_one_ranks_share_every_envelope_vs_oracle(oracle):
+    """configs[3]: rank 0's byte-balanced share of the 100 000-message batch (1 KiB - 4 MiB, random / text alternating):
+    EVERY envelope the GPU writes equals oracle.pickle of the message; every message comes back from Unpickle."""
+    import torch
+    from k4os.compression.lz4_amd.device import DeviceBatch, DeviceCodec
+    lens_all = corpus.config4_lengths()
+    lo, hi = byte_balanced_ranges(lens_all, 8)[0]
+    data, off, lens = corpus.config4_share(lens_all, lo, hi)
+    n = lens.size
+    dc = DeviceCodec(0)
+    src = DeviceBatch.from_host(data, off, lens, dc.device)
+    env = DeviceBatch.empty_slots(lens.astype(np.int64) + 5, dc.device, fill=0xCD)
+    plen = dc.pickle(src, env)
+    psrc = DeviceBatch(env.data, env.off, plen)
+    sizes = dc.unpickle_sizes(psrc)
+    back = DeviceBatch.empty_slots(lens, dc.device)
+    ulen = dc.unpickle(psrc, back)
+    torch.cuda.synchronize()
+    assert bool((sizes == torch.from_numpy(lens).to(dc.device)).all().item())
+    assert bool((ulen == sizes).all().item())
+    boff = back.off.cpu().numpy()
+    packed = bool(np.array_equal(boff, off.view(np.int64))) if (lens % 16 == 0).all() else False
+    bh = back.data.cpu().numpy()
+    eh, eoff, pl = env.data.cpu().numpy(), env.off.cpu().numpy(), plen.cpu().numpy()
+
+    def check(i):
+        m = data[int(off[i]):int(off[i]) + int(lens[i])]
+        return eh[eoff[i]:eoff[i] + pl[i]].tobytes() == oracle.pickle(m) and bh[boff[i]:boff[i] + lens[i]].tobytes() == m.tobytes()
+
+    with ThreadPoolExecutor(THREADS) as pool:
+        bad = [i for i, ok in enumerate(pool.map(check, range(n))) if not ok]
+    assert not bad, f"{len(bad)} of {n} messages differ, first {bad[:5]} (packed={packed})"
+
+
+def test_config4_hc_l03_all_4096_blocks_vs_oracle(oracle):
+    """configs[4]: L03_HC over the 4096 x 64 KiB batch: every block's bytes and the ratio equal the oracle's"""
+    import torch
+    from k4os.compression.lz4_amd.device import DeviceBatch, DeviceCodec
+    n, bs = 4096, 65536
+    blocks = corpus.silesia_like_blocks(n, bs, seed=2)
+    lens = np.full(n, bs, np.int32)
+    off = np.arange(n, dtype=np.uint64) * bs
+    caps = np.full(n, LZ4Codec.MaximumOutputSize(bs), np.int32)
+    ref, ref_off = make_arena(caps)
+    want = oracle.encode_batch(blocks.reshape(-1), off, lens, ref, ref_off, caps, level=3, threads=THREADS)
+    dc = DeviceCodec(0)
+    src = DeviceBatch.from_host(blocks.reshape(-1), off, lens, dc.device)
+    comp = DeviceBatch.empty_slots(caps, dc.device, fill=0xCD)
+    clen = dc.encode(src, comp, level=LZ4Level.L03_HC)
+    torch.cuda.synchronize()
+    clen_h = clen.cpu().numpy()
+    assert np.array_equal(clen_h, want)
+    assert int(clen_h.sum()) == int(want.sum())            # the ratio, exactly
+    ch, coff = comp.data.cpu().numpy(), comp.off.cpu().numpy()
+    for i in range(n):
+        assert ch[coff[i]:coff[i] + clen_h[i]].tobytes() == ref[int(ref_off[i]):int(ref_off[i]) + int(want[i])].tobytes(), i
+
+
+def test_hc_device_call_with_reservation_only_enqueues_and_a_small_one_fails_loudly(oracle):
+    """k4lz4_ctx_reserve_hc: device-resident HC encodes sized from the reservation give the same bytes; a batch bigger
+    than the reservation is not encoded and the context says so at the next synchronising call (never a silent -1)."""
+    import torch
+    from k4os.compression.lz4_amd import _native
+    from k4os.compression.lz4_amd.device import DeviceBatch, DeviceCodec
+    blocks = corpus.silesia_like_blocks(96, 65536, seed=5)
+    n = blocks.shape[0]
+    lens = np.full(n, 65536, np.int32)
+    off = np.arange(n, dtype=np.uint64) * 65536
+    dc = DeviceCodec(0)
+    src = DeviceBatch.from_host(blocks.reshape(-1), off, lens, dc.device)
+    caps = np.full(n, LZ4Codec.MaximumOutputSize(65536), np.int32)
+    comp = DeviceBatch.empty_slots(caps, dc.device, fill=0xCD)
+    dc.ctx.check(dc.lib.k4lz4_ctx_reserve_hc(dc.ctx.handle, n * 65536, 65536))
+    clen = dc.encode(src, comp, level=LZ4Level.L06_HC)
+    dc.ctx.check(dc.lib.k4lz4_synchronize(dc.ctx.handle, None))
+    torch.cuda.synchronize()
+    ch, coff, cl = comp.data.cpu().numpy(), comp.off.cpu().numpy(), clen.cpu().numpy()
+    for i in range(n):
+        r, w = oracle.compress_hc(blocks[i], 6)
+        assert cl[i] == r and ch[coff[i]:coff[i] + r].tobytes() == w[:r].tobytes(), i
+    # too small: half the bytes
+    dc.ctx.check(dc.lib.k4lz4_ctx_reserve_hc(dc.ctx.handle, n * 65536 // 2, 65536))
+    clen2 = dc.encode(src, comp, level=LZ4Level.L03_HC)
+    torch.cuda.synchronize()
+    rc = dc.lib.k4lz4_synchronize(dc.ctx.handle, None)
+    assert rc == _native.E_NOMEM and b"reserve" in dc.lib.k4lz4_last_error(dc.ctx.handle)
+    assert (clen2.cpu().numpy() == -1).all()
+    dc.ctx.check(dc.lib.k4lz4_ctx_reserve_hc(dc.ctx.handle, 0, 0))
+    clen3 = dc.encode(src, comp, level=LZ4Level.L03_HC)      # sized by asking the device again
+    torch.cuda.synchronize()
+    dc.ctx.check(dc.lib.k4lz4_synchronize(dc.ctx.handle, None))
+    assert (clen3.cpu().numpy() > 0).all()
+
+
+def test_one_context_two_streams_do_not_race_on_its_scratch(oracle):
+    """the context's dispatch-order / hash-table scratch is shared by all calls: two calls in a row on different streams
+    must give the results of two calls in a row on one stream"""
+    import torch
+    from k4os.compression.lz4_amd.device import DeviceBatch, DeviceCodec
+    dc = DeviceCodec(0)
+    sets = []
+    for seed in (11, 12):
+        blocks = corpus.silesia_like_blocks(1536, 65536, seed=seed)
+        n = blocks.shape[0]
+        lens = np.full(n, 65536, np.int32)
+        off = np.arange(n, dtype=np.uint64) * 65536
+        src = DeviceBatch.from_host(blocks.reshape(-1), off, lens, dc.device)
+        comp = DeviceBatch.empty_slots(np.full(n, LZ4Codec.MaximumOutputSize(65536)), dc.device)
+        sets.append((blocks, src, comp, dc.new_out_len(n)))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(dc.device), torch.cuda.Stream(dc.device)]
+    for rep in range(3):
+        for (blocks, src, comp, clen), st in zip(sets, streams):
+            with torch.cuda.stream(st):
+                dc.encode(src, comp, clen)
+    torch.cuda.synchronize()
+    for blocks, src, comp, clen in sets:
+        cl, ch, coff = clen.cpu().numpy(), comp.data.cpu().numpy(), comp.off.cpu().numpy()
+        for i in range(0, blocks.shape[0], 5):
+            assert ch[coff[i]:coff[i] + cl[i]].tobytes() == oracle.encode(blocks[i]), i
+
+
+def test_compress_hc_refuses_levels_below_3():
+    from k4os.compression.lz4_amd import _native
+    lib = _native.load_library()
+    data = corpus.lorem(1000)
+    dst = np.zeros(2000, np.uint8)
+    assert lib.k4lz4_compress_hc(data.ctypes.data, dst.ctypes.data, data.size, dst.size, 1) == 0
+    assert lib.k4lz4_last_status() == _native.E_ARG
+    assert lib.k4lz4_compress_hc(data.ctypes.data, dst.ctypes.data, data.size, dst.size, 3) > 0
+    assert lib.k4lz4_last_status() == 0

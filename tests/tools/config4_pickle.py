@@ -16,20 +16,11 @@ from oracle_lib import Oracle
 n_total = int(os.environ.get("K4_MSGS", "100000"))
 world = int(os.environ.get("K4_WORLD", "8"))
 rank = int(os.environ.get("K4_RANK", "0"))
-rng = np.random.default_rng(4)
-lens_all = np.exp(rng.uniform(np.log(1024), np.log(4 << 20), size=n_total)).astype(np.int64)
+lens_all = corpus.config4_lengths(n_total)
 lo, hi = byte_balanced_ranges(lens_all, world)[rank]
-lens = lens_all[lo:hi].astype(np.int32)
+data, off, lens = corpus.config4_share(lens_all, lo, hi)
 n = lens.size
-off = np.concatenate(([0], np.cumsum(lens.astype(np.int64))))[:-1].astype(np.uint64)
 total = int(lens.astype(np.int64).sum())
-text = corpus.class_bytes("dickens", 8 << 20, 5)
-rnd = corpus.random_bytes(8 << 20, 6)
-data = np.empty(total, np.uint8)
-for i in range(n):
-    srcbuf = rnd if ((lo + i) & 1) == 0 else text
-    st = ((lo + i) * 7919) % (srcbuf.size - int(lens[i]))
-    data[int(off[i]):int(off[i]) + int(lens[i])] = srcbuf[st:st + int(lens[i])]
 dc = DeviceCodec(0)
 src = DeviceBatch.from_host(data, off, lens, dc.device)
 env = DeviceBatch.empty_slots(lens.astype(np.int64) + 5, dc.device)
