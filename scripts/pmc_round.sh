@@ -1,5 +1,8 @@
 #!/bin/bash
-# rocprofv3 PMC passes over the bench workload (separate passes: SQ 8 slots, TCC FETCH/WRITE apart).
+# rocprofv3 PMC passes over the bench workload (separate passes: SQ 8 slots, TCC FETCH/WRITE apart), plus the same two TCC
+# passes over scripts/ubench/pmc_calib (kernels of known byte counts) so that FETCH_SIZE / WRITE_SIZE can be turned into
+# bytes for THIS access pattern.  Writes profiles-ready files under gpurun_out/<tag>/ and pmc_traffic.json with the hash of
+# the kernel sources it was measured on (bench.py refuses traffic figures from other sources).
 # Usage: scripts/pmc_round.sh [tag]
 TAG=${1:-pmc}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
@@ -8,9 +11,14 @@ export TMPDIR=/tmp
 cd /tmp
 CMD="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify"
 run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $OUT/$name -o $name -- $CMD > $OUT/$name.log 2>&1; }
+cal() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $OUT/$name -o $name -- $GRAFT_REPO_ROOT/scripts/ubench/pmc_calib > $OUT/$name.log 2>&1; }
 run sq1 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES
 run sq2 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run grbm GRBM_GUI_ACTIVE
-ls -R $OUT | head -40
+cal calfetch FETCH_SIZE
+cal calwrite WRITE_SIZE
+cd $GRAFT_REPO_ROOT
+python scripts/pmc_summary.py gpurun_out/$TAG gpurun_out/$TAG/pmc_traffic.json > gpurun_out/$TAG/pmc_summary.txt 2>&1
+tail -30 gpurun_out/$TAG/pmc_summary.txt
