@@ -33,6 +33,58 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E
 
 
+def strong(args):
+    """ONE batch sharded over the ranks (SURVEY.md 8e / BASELINE.json configs[3]): rank r pickles + unpickles the byte-balanced
+    range r of the --messages batch in its own HBM; the int32 envelope-size vector is all-gathered over RCCL (the only
+    collective); rank 0 checks the gathered vector against the oracle on a sample drawn from EVERY rank's range."""
+    import torch
+    import torch.distributed as dist
+    from k4os.compression.lz4_amd import corpus
+    from k4os.compression.lz4_amd.device import DevicePickleBackend
+    from k4os.compression.lz4_amd.sharding import sharded_pickle_roundtrip
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    lens_all = corpus.config4_lengths(args.messages)
+    backend = DevicePickleBackend(local_rank)
+    ranges, sizes, mine = sharded_pickle_roundtrip(backend, lens_all, rank, world)
+    t = torch.tensor([mine["pickle_s"], mine["unpickle_s"], 0.0 if mine["roundtrip_ok"] else 1.0], dtype=torch.float64,
+                     device=backend.dc.device if world > 1 else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t_p, t_u, bad = (float(v) for v in t.tolist())
+    if rank == 0:
+        from oracle_lib import Oracle
+        oracle = Oracle()
+        sizes_h = sizes.cpu().numpy()
+        rng = np.random.default_rng(1)
+        sample = sorted({int(i) for lo, hi in ranges if hi > lo for i in rng.integers(lo, hi, size=8)})
+        equal = all(len(oracle.pickle(corpus.config4_share(lens_all, i, i + 1)[0])) == int(sizes_h[i]) for i in sample)
+        total = int(np.asarray(lens_all, dtype=np.int64).sum())
+        print(json.dumps({
+            "metric": "GiB/s LZ4Pickler.Pickle + Unpickle over ONE batch of variable-length messages, byte-balanced over the GPUs",
+            "value": round(total / 2 ** 30 / (t_p + t_u), 3), "unit": "GiB/s", "n_gpus": world, "steps": 1, "warmup": 1,
+            "ms_per_step": round((t_p + t_u) * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[3]: {args.messages} messages 1 KiB-4 MiB (log-uniform), random / text alternating, "
+                                   f"{total} bytes, split into {world} contiguous byte-balanced ranges", "messages": args.messages,
+                       "bytes_per_rank": [int(np.asarray(lens_all[lo:hi], dtype=np.int64).sum()) for lo, hi in ranges],
+                       "pickle_GiBs": round(total / 2 ** 30 / t_p, 3), "unpickle_GiBs": round(total / 2 ** 30 / t_u, 3),
+                       "envelope_bytes_total": int(sizes_h.astype(np.int64).sum())},
+            "roundtrip_ok_all_ranks": bad == 0.0, "size_vector_sample_equals_oracle": equal, "sampled_messages": len(sample)}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -42,7 +94,13 @@ def main():
     ap.add_argument("--block-size", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="ONE configs[3] batch (LZ4Pickler over --messages variable-length messages) split over the ranks by bytes; "
+                         "not the headline metric, reported as its own line")
+    ap.add_argument("--messages", type=int, default=100000)
     args = ap.parse_args()
+    if args.strong:
+        return strong(args)
 
     import torch
     import torch.distributed as dist

@@ -132,3 +132,43 @@ class DeviceCodec:
                                                  _dp(out_len), src.n, _dp(counters), C.c_void_p(self._stream()))
         self.ctx.check(rc)
         return out_len, counters
+
+
+class DevicePickleBackend:
+    """per-rank work of sharding.sharded_pickle_roundtrip on one GPU: HBM-resident Pickle + Unpickle of a share of messages"""
+
+    def __init__(self, device: int):
+        self.dc = DeviceCodec(device)
+
+    def pickle_unpickle(self, data: np.ndarray, off: np.ndarray, lens: np.ndarray):
+        import time
+        dc = self.dc
+        n = int(lens.size)
+        if n == 0:
+            return torch.zeros(0, dtype=torch.int32, device=dc.device), 0.0, 0.0, True
+        src = DeviceBatch.from_host(data, off, lens, dc.device)
+        env = DeviceBatch.empty_slots(lens.astype(np.int64) + 5, dc.device)
+        plen = dc.new_out_len(n)
+        back = DeviceBatch.empty_slots(lens, dc.device)
+        ulen = dc.new_out_len(n)
+        dc.pickle(src, env, plen)                      # warm-up (scratch allocation)
+        torch.cuda.synchronize(dc.device)
+        t = time.perf_counter(); dc.pickle(src, env, plen); torch.cuda.synchronize(dc.device); t_p = time.perf_counter() - t
+        psrc = DeviceBatch(env.data, env.off, plen)
+        dc.unpickle(psrc, back, ulen)
+        torch.cuda.synchronize(dc.device)
+        t = time.perf_counter(); dc.unpickle(psrc, back, ulen); torch.cuda.synchronize(dc.device); t_u = time.perf_counter() - t
+        ok = bool((ulen == torch.from_numpy(lens).to(dc.device)).all().item())
+        if ok:                                         # every byte back, compared on the device
+            boff = back.off.cpu().numpy()
+            want = torch.from_numpy(np.ascontiguousarray(data)).to(dc.device)
+            pos = 0
+            if all(int(boff[i]) == int(off[i]) for i in range(0, n, max(1, n // 64))) and int(boff[-1]) == int(off[-1]):
+                ok = bool(torch.equal(back.data[:want.numel()], want))
+            else:                                      # slots are 16-byte aligned: compare message by message
+                for i in range(n):
+                    ln = int(lens[i])
+                    if not torch.equal(back.data[int(boff[i]):int(boff[i]) + ln], want[int(off[i]):int(off[i]) + ln]):
+                        ok = False
+                        break
+        return plen, t_p, t_u, ok

@@ -47,3 +47,20 @@ def gather_sizes(local_sizes, ranges: Sequence[Tuple[int, int]], group=None):
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([p[:c] for p, c in zip(parts, counts)]) if counts else pad
+
+
+def sharded_pickle_roundtrip(backend, lens_all, rank: int, world: int, group=None):
+    """ONE batch over `world` ranks (BASELINE.json configs[3]): rank r takes the byte-balanced range r of the
+    batch's messages, pickles and unpickles it in its own memory, and the only thing exchanged is the int32 vector of
+    envelope sizes (all_gather).  `backend.pickle_unpickle(data, off, lens)` does the per-rank work and returns
+    (envelope sizes as an int32 torch tensor on the backend's device, pickle seconds, unpickle seconds, round trip ok).
+    Returns (ranges, gathered sizes for the WHOLE batch, this rank's timings dict)."""
+    import numpy as np
+    from . import corpus
+    ranges = byte_balanced_ranges(lens_all, world)
+    lo, hi = ranges[rank]
+    data, off, lens = corpus.config4_share(np.asarray(lens_all), lo, hi)
+    sizes, t_p, t_u, ok = backend.pickle_unpickle(data, off, lens)
+    full = gather_sizes(sizes, ranges, group)
+    return ranges, full, {"messages": int(hi - lo), "bytes": int(lens.astype(np.int64).sum()), "pickle_s": t_p, "unpickle_s": t_u,
+                          "roundtrip_ok": bool(ok)}
