@@ -1,0 +1,89 @@
+// LZ4Codec.Batch.cs -- the batch surface beside LZ4Codec.Encode / Decode (LZ4Codec.cs:40-115): n independent blocks, one call,
+// one kernel launch.  Per-block results follow Encode / Decode: > 0 bytes written, 0 for an empty source, -1 failure.
+// Compile-unverified.
+using System;
+using K4os.Compression.LZ4.Engine;
+
+namespace K4os.Compression.LZ4
+{
+	public static partial class LZ4Codec
+	{
+		/// <summary>Compresses n independent blocks. Block i is source[sourceOffsets[i] .. +sourceLengths[i]) and goes to
+		/// target[targetOffsets[i] .. +targetLengths[i]); encodedLengths[i] is what Encode(...) would return for it.</summary>
+		public static unsafe void EncodeBatch(
+			ReadOnlySpan<byte> source, ReadOnlySpan<ulong> sourceOffsets, ReadOnlySpan<int> sourceLengths,
+			Span<byte> target, ReadOnlySpan<ulong> targetOffsets, ReadOnlySpan<int> targetLengths,
+			Span<int> encodedLengths, LZ4Level level = LZ4Level.L00_FAST)
+		{
+			var n = ValidateBatch(source.Length, sourceOffsets, sourceLengths, target.Length, targetOffsets, targetLengths, encodedLengths.Length);
+			if (n == 0) return;
+			var ctx = NativeContext.Current;
+			fixed (byte* s = source, t = target)
+			fixed (ulong* so = sourceOffsets, to = targetOffsets)
+			fixed (int* sl = sourceLengths, tl = targetLengths, ol = encodedLengths)
+				LLNative.ThrowIfFailed(LLNative.k4lz4_encode_batch(ctx, s, so, sl, t, to, tl, ol, n, (int) level, 0), ctx);
+		}
+
+		/// <summary>Decompresses n independent blocks; decodedLengths[i] is what Decode(...) would return (-1: corrupt / too small).</summary>
+		public static unsafe void DecodeBatch(
+			ReadOnlySpan<byte> source, ReadOnlySpan<ulong> sourceOffsets, ReadOnlySpan<int> sourceLengths,
+			Span<byte> target, ReadOnlySpan<ulong> targetOffsets, ReadOnlySpan<int> targetLengths,
+			Span<int> decodedLengths)
+		{
+			var n = ValidateBatch(source.Length, sourceOffsets, sourceLengths, target.Length, targetOffsets, targetLengths, decodedLengths.Length);
+			if (n == 0) return;
+			var ctx = NativeContext.Current;
+			fixed (byte* s = source, t = target)
+			fixed (ulong* so = sourceOffsets, to = targetOffsets)
+			fixed (int* sl = sourceLengths, tl = targetLengths, ol = decodedLengths)
+				LLNative.ThrowIfFailed(LLNative.k4lz4_decode_batch(ctx, s, so, sl, t, to, tl, ol, n, 0), ctx);
+		}
+
+		/// <summary>Convenience form: every block compressed into a fresh array (null where Encode would return -1 cannot happen:
+		/// each target has MaximumOutputSize bytes).</summary>
+		public static unsafe byte[][] EncodeBatch(byte[][] blocks, LZ4Level level = LZ4Level.L00_FAST)
+		{
+			if (blocks is null) throw new ArgumentNullException(nameof(blocks));
+			var n = blocks.Length;
+			var result = new byte[n][];
+			if (n == 0) return result;
+			var srcOff = new ulong[n]; var srcLen = new int[n]; var dstOff = new ulong[n]; var dstCap = new int[n]; var outLen = new int[n];
+			ulong st = 0, dt = 0;
+			for (var i = 0; i < n; i++)
+			{
+				if (blocks[i] is null) throw new ArgumentNullException($"{nameof(blocks)}[{i}]");
+				srcOff[i] = st; srcLen[i] = blocks[i].Length; st += (ulong) blocks[i].Length;
+				dstOff[i] = dt; dstCap[i] = MaximumOutputSize(blocks[i].Length); dt += (ulong) dstCap[i];
+			}
+			var src = new byte[Math.Max(1UL, st)];
+			var dst = new byte[Math.Max(1UL, dt)];
+			for (var i = 0; i < n; i++) Buffer.BlockCopy(blocks[i], 0, src, (int) srcOff[i], srcLen[i]);
+			EncodeBatch(src, srcOff, srcLen, dst, dstOff, dstCap, outLen, level);
+			for (var i = 0; i < n; i++)
+			{
+				if (outLen[i] < 0) throw new InvalidOperationException($"block {i} did not fit into MaximumOutputSize bytes"); // cannot happen
+				result[i] = new byte[outLen[i]];
+				Buffer.BlockCopy(dst, (int) dstOff[i], result[i], 0, outLen[i]);
+			}
+			return result;
+		}
+
+		// the checks Encode/Decode make per call (Internal/Extensions.cs:37-52), once per batch
+		private static long ValidateBatch(
+			int sourceLength, ReadOnlySpan<ulong> sourceOffsets, ReadOnlySpan<int> sourceLengths,
+			int targetLength, ReadOnlySpan<ulong> targetOffsets, ReadOnlySpan<int> targetLengths, int results)
+		{
+			var n = sourceOffsets.Length;
+			if (sourceLengths.Length != n || targetOffsets.Length != n || targetLengths.Length != n || results != n)
+				throw new ArgumentException("batch vectors differ in length");
+			for (var i = 0; i < n; i++)
+			{
+				if (sourceLengths[i] < 0 || sourceOffsets[i] + (ulong) sourceLengths[i] > (ulong) sourceLength)
+					throw new ArgumentException($"block {i}: source range outside the buffer");
+				if (targetLengths[i] < 0 || targetOffsets[i] + (ulong) targetLengths[i] > (ulong) targetLength)
+					throw new ArgumentException($"block {i}: target range outside the buffer");
+			}
+			return n;
+		}
+	}
+}
