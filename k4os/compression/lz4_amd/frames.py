@@ -297,10 +297,21 @@ class LZ4Frame:
                 raise InvalidDataException("Content length does not match the frame header")
         return [o.tobytes() for o in outs]
 
+    # What a frame's metadata may make the decoder allocate.  The reference's reader holds ONE block-sized buffer at a time
+    # (LZ4FrameReader.async.cs:108-136); a batch decoder sizes an arena up front, so the size must come from what the input
+    # can actually produce, not from what the header claims: an LZ4 block never decodes to more than 255 bytes per input
+    # byte (a match costs at least 3 bytes + 1 per 255 bytes of length), and launches are cut at an arena budget.
+    ARENA_BUDGET = 1 << 30
+
+    @staticmethod
+    def _block_cap(block_size: int, stored: int) -> int:
+        return int(min(block_size, 255 * stored + 32))
+
     @staticmethod
     def _decode_streams(bufs, infos, ctx) -> List[np.ndarray]:
-        """frames of independent blocks: all their blocks as ONE batch (LZ4BlockDecoder per block, parallel);
-        frames of chained blocks: one in-order stream per frame (LZ4ChainDecoder, k4lz4_decode_chain_batch)"""
+        """frames of independent blocks: all their blocks as batches (LZ4BlockDecoder per block, parallel) of at most
+        ARENA_BUDGET bytes of output slots each; frames of chained blocks: one in-order stream per frame (LZ4ChainDecoder,
+        k4lz4_decode_chain_batch)"""
         res: List[Optional[np.ndarray]] = [None] * len(infos)
         indep = [f for f, i in enumerate(infos) if not i.descriptor.Chaining]
         chain = [f for f, i in enumerate(infos) if i.descriptor.Chaining]
@@ -311,18 +322,24 @@ class LZ4Frame:
                 for k, (o, l) in enumerate(zip(i.block_off, i.block_len)):
                     if not (l & 0x80000000):
                         blocks.append(b[o:o + l])
-                        caps.append(i.descriptor.BlockSize)
+                        caps.append(LZ4Frame._block_cap(i.descriptor.BlockSize, l))
                         where.append((f, k))
             decoded = {}
-            if blocks:
-                src, soff, slen = pack_blocks(blocks)
-                cap = np.array(caps, np.int32)
+            lo = 0
+            while lo < len(blocks):
+                hi, room = lo, LZ4Frame.ARENA_BUDGET
+                while hi < len(blocks) and (hi == lo or caps[hi] <= room):
+                    room -= caps[hi]
+                    hi += 1
+                src, soff, slen = pack_blocks(blocks[lo:hi])
+                cap = np.array(caps[lo:hi], np.int32)
                 dst, doff = make_arena(cap)
                 out = LZ4Codec.DecodeBatchPacked(src, soff, slen, dst, doff, cap, ctx=ctx)
-                for (f, k), n, o in zip(where, out, doff):
+                for (f, k), n, o in zip(where[lo:hi], out, doff):
                     if n < 0:
                         raise InvalidDataException("LZ4 block does not decode")      # LZ4BlockDecoder.cs:50-52
-                    decoded[(f, k)] = dst[int(o):int(o) + int(n)]
+                    decoded[(f, k)] = dst[int(o):int(o) + int(n)].copy()             # (the arena goes away with this launch)
+                lo = hi
             for f in indep:
                 i, b = infos[f], bufs[f]
                 parts = [decoded[(f, k)] if not (l & 0x80000000) else b[o:o + (l & 0x7FFFFFFF)]
@@ -341,8 +358,10 @@ class LZ4Frame:
                 blk_len += i.block_len
             bsize = np.array([i.descriptor.BlockSize for i in ci], np.int32)
             chained = np.ones(nf, np.uint8)
-            caps = np.array([len(i.block_off) * i.descriptor.BlockSize if i.descriptor.ContentLength is None
-                             else min(i.descriptor.ContentLength, len(i.block_off) * i.descriptor.BlockSize) for i in ci], np.uint64)
+            produced = [sum(LZ4Frame._block_cap(i.descriptor.BlockSize, l & 0x7FFFFFFF) if not (l & 0x80000000) else (l & 0x7FFFFFFF)
+                            for l in i.block_len) for i in ci]          # what the blocks can produce, not what the header claims
+            caps = np.array([p if i.descriptor.ContentLength is None else min(i.descriptor.ContentLength, p)
+                             for i, p in zip(ci, produced)], np.uint64)
             doff = np.zeros(nf, np.uint64)
             if nf > 1:
                 doff[1:] = np.cumsum(caps[:-1])

@@ -292,3 +292,37 @@ def test_block_encoder_topup_bookkeeping():
         dec.Inject(np.zeros(2000, np.uint8))
     assert dec.Peek(-100).tobytes() == data[400:500].tobytes()
     assert list(EncoderAction) == [EncoderAction.None_, EncoderAction.Loaded, EncoderAction.Encoded, EncoderAction.Copied]
+
+
+def test_frame_decode_arena_follows_the_input_not_the_header(oracle, monkeypatch):
+    """A frame that claims 4 MiB blocks but holds thousands of tiny ones must not make the decoder size its arena from the
+    claim (N x 4 MiB): slots follow what the stored bytes can produce (255 per input byte at most) and launches are cut at a
+    byte budget.  The kernels are replaced by the oracle here (no GPU): this is about the host's index work."""
+    seen = []
+
+    def fake_decode(src, soff, slen, dst, doff, cap, flags=0, ctx=None):
+        seen.append((len(slen), int(np.asarray(cap, np.int64).sum())))
+        out = np.empty(len(slen), np.int32)
+        for i in range(len(slen)):
+            r, d = oracle.decompress_safe(src[int(soff[i]):int(soff[i]) + int(slen[i])], int(cap[i]))
+            out[i] = r if r > 0 else -1
+            if r > 0:
+                dst[int(doff[i]):int(doff[i]) + r] = d[:r]
+        return out
+
+    monkeypatch.setattr(LZ4Codec, "DecodeBatchPacked", staticmethod(fake_decode))
+    pieces = [np.tile(corpus.lorem(37 + (i % 11)), 8 + i % 5) for i in range(3000)]
+    records = []
+    for p in pieces:
+        c = oracle.encode(p)
+        records.append((c, False) if len(c) < p.size else (p.tobytes(), True))
+    desc = F.LZ4Descriptor(None, False, False, False, None, 4 << 20)          # BD = 7: 4 MiB blocks, independent
+    import xxhash
+    frame = F.assemble_frame(desc, xxhash.xxh32(F.frame_header(desc)).intdigest(), [r[0] for r in records], [r[1] for r in records], None, None)
+    info = F.parse_frame(np.frombuffer(frame, np.uint8))
+    monkeypatch.setattr(F.LZ4Frame, "ARENA_BUDGET", 1 << 20)
+    outs = F.LZ4Frame._decode_streams([np.frombuffer(frame, np.uint8)], [info], None)
+    assert outs[0].tobytes() == b"".join(p.tobytes() for p in pieces)
+    assert len(seen) > 1 and all(total <= (1 << 20) for _, total in seen)     # several launches, each under the budget
+    assert sum(total for _, total in seen) < 255 * len(frame) + 32 * len(pieces)   # nowhere near 3000 x 4 MiB
+    assert F.LZ4Frame._block_cap(4 << 20, 10) == 255 * 10 + 32 and F.LZ4Frame._block_cap(65536, 60000) == 65536
