@@ -18,7 +18,11 @@
 #include <atomic>
 #include <memory>
 #include <new>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../../include/k4lz4.h"
@@ -57,10 +61,69 @@ struct k4lz4_ctx {
     bool busy = false;
     /* k4lz4_ctx_reserve_hc: HC levels sized without asking the device (0 = not reserved) */
     uint64_t hc_res_total = 0; uint32_t hc_res_longest = 0;
+    /* host-pointer calls of some size stage through two pinned buffers per direction, filled / emptied by a few threads while
+     * the DMA engine moves the previous chunk; d_pack takes the produced bytes packed next to each other */
+    uint8_t *h_in[2] = {nullptr, nullptr}; size_t h_in_cap[2] = {0, 0};
+    uint8_t *h_out[2] = {nullptr, nullptr}; size_t h_out_cap[2] = {0, 0};
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    uint8_t *d_pack = nullptr; size_t d_pack_cap = 0;
+    struct Pool *pool = nullptr;
     /* diagnostic switches, read once at creation: K4LZ4_SPLIT_PCT (1..100, share of an encode batch on the LDS-table kernel),
      * K4LZ4_NO_PAIR (decode with one wave per block) */
     int split_pct = -1;
     bool no_pair = false;
+};
+
+/* a few helper threads for the staging copies of big host-pointer calls (memcpy between the caller's pageable memory and
+ * the pinned buffers is what limits such calls, not PCIe) */
+struct Pool {
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::function<void(int)> job;
+    int parts = 0, next = 0, pending = 0;
+    unsigned long long gen = 0;
+    bool stop = false;
+    explicit Pool(int nthreads)
+    {
+        for (int t = 0; t < nthreads; t++) workers.emplace_back([this] { run(); });
+    }
+    ~Pool()
+    {
+        { std::lock_guard<std::mutex> g(m); stop = true; }
+        cv_work.notify_all();
+        for (auto &w : workers) w.join();
+    }
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv_work.wait(lk, [this] { return stop || next < parts; });
+            if (stop) return;
+            const int i = next++;
+            lk.unlock();
+            job(i);
+            lk.lock();
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+    /* f(0) .. f(parts - 1), the caller takes part as well */
+    void parallel(int nparts, const std::function<void(int)> &f)
+    {
+        if (nparts <= 1 || workers.empty()) { for (int i = 0; i < nparts; i++) f(i); return; }
+        std::unique_lock<std::mutex> lk(m);
+        job = f; parts = nparts; next = 0; pending = nparts; gen++;
+        cv_work.notify_all();
+        while (next < parts) {
+            const int i = next++;
+            lk.unlock();
+            f(i);
+            lk.lock();
+            if (--pending == 0) cv_done.notify_all();
+        }
+        cv_done.wait(lk, [this] { return pending == 0; });
+        parts = 0;
+    }
 };
 
 namespace {
@@ -376,6 +439,107 @@ int check_batch_args(k4lz4_ctx *ctx, const void *src, const void *srcOff, const 
     return K4LZ4_OK;
 }
 
+constexpr size_t STAGE_CHUNK = (size_t)16 << 20;
+
+Pool *pool_of(k4lz4_ctx *ctx)
+{
+    if (!ctx->pool) {
+        unsigned hw = std::thread::hardware_concurrency();
+        const int nthreads = (int)std::min<unsigned>(7u, hw > 2 ? hw / 2 - 1 : 0u);
+        ctx->pool = new (std::nothrow) Pool(nthreads);
+    }
+    return ctx->pool;
+}
+
+/* memcpy split over the helper threads */
+void parallel_copy(k4lz4_ctx *ctx, uint8_t *d, const uint8_t *s, size_t nbytes)
+{
+    Pool *p = pool_of(ctx);
+    const int parts = p ? (int)std::min<size_t>(p->workers.size() + 1, std::max<size_t>(1, nbytes >> 20)) : 1;
+    if (parts <= 1) { memcpy(d, s, nbytes); return; }
+    const size_t per = ((nbytes / (size_t)parts) + 63) & ~(size_t)63;
+    p->parallel(parts, [=](int i) {
+        const size_t lo = per * (size_t)i;
+        if (lo < nbytes) memcpy(d + lo, s + lo, std::min(per, nbytes - lo));
+    });
+}
+
+/* caller's (pageable) memory -> device: small transfers directly, big ones through two pinned buffers so that the copy into
+ * the buffer for chunk k+1 runs while the DMA engine moves chunk k */
+int staged_upload(k4lz4_ctx *ctx, uint8_t *d_dst, const uint8_t *h_src, size_t nbytes, hipStream_t st)
+{
+    if (nbytes < 2 * STAGE_CHUNK) {
+        K4_HIP(ctx, hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, st));
+        return K4LZ4_OK;
+    }
+    int rc;
+    for (int b = 0; b < 2; b++)
+        if ((rc = grow(ctx, &ctx->h_in[b], &ctx->h_in_cap[b], STAGE_CHUNK, true)) != K4LZ4_OK) return rc;
+    bool used[2] = {false, false};
+    int b = 0;
+    for (size_t pos = 0; pos < nbytes; pos += STAGE_CHUNK, b ^= 1) {
+        const size_t len = std::min(STAGE_CHUNK, nbytes - pos);
+        if (used[b]) K4_HIP(ctx, hipEventSynchronize(ctx->ev_in[b]));   /* the DMA out of this buffer two chunks ago */
+        parallel_copy(ctx, ctx->h_in[b], h_src + pos, len);
+        K4_HIP(ctx, hipMemcpyAsync(d_dst + pos, ctx->h_in[b], len, hipMemcpyHostToDevice, st));
+        K4_HIP(ctx, hipEventRecord(ctx->ev_in[b], st));
+        used[b] = true;
+    }
+    return K4LZ4_OK;
+}
+
+/* device -> the caller's slots: block i's stored[i] bytes sit at d_from + from_off[i]; chunks of whole blocks come over
+ * into a pinned buffer while the previous chunk is scattered into the slots by the helper threads */
+int staged_download(k4lz4_ctx *ctx, uint8_t *dst, const uint64_t *dstOff, const uint8_t *d_from, const uint64_t *from_off,
+                    const int32_t *stored, int64_t n, hipStream_t st)
+{
+    struct Chunk { int64_t first, last; uint64_t lo, hi; };
+    std::vector<Chunk> chunks;
+    size_t biggest = 0;
+    for (int64_t i = 0; i < n;) {
+        while (i < n && stored[i] <= 0) i++;
+        if (i >= n) break;
+        Chunk c{i, i, from_off[i], from_off[i] + (uint64_t)stored[i]};
+        for (int64_t j = i + 1; j < n; j++) {
+            if (stored[j] <= 0) { c.last = j; continue; }
+            const uint64_t hi = from_off[j] + (uint64_t)stored[j];
+            if (hi - c.lo > STAGE_CHUNK) break;
+            c.last = j; c.hi = hi;
+        }
+        biggest = std::max(biggest, (size_t)(c.hi - c.lo));
+        chunks.push_back(c);
+        i = c.last + 1;
+    }
+    if (chunks.empty()) return K4LZ4_OK;
+    int rc;
+    for (int b = 0; b < 2; b++)
+        if ((rc = grow(ctx, &ctx->h_out[b], &ctx->h_out_cap[b], biggest + 64, true)) != K4LZ4_OK) return rc;
+    auto scatter = [&](const Chunk &c, const uint8_t *buf) {
+        const int64_t cnt = c.last - c.first + 1;
+        Pool *p = pool_of(ctx);
+        const int parts = p && (c.hi - c.lo) >= ((uint64_t)2 << 20) ? (int)std::min<int64_t>((int64_t)p->workers.size() + 1, cnt) : 1;
+        auto body = [&, parts](int part) {
+            const int64_t a = c.first + cnt * part / parts, e = c.first + cnt * (part + 1) / parts;
+            for (int64_t i = a; i < e; i++)
+                if (stored[i] > 0) memcpy(dst + dstOff[i], buf + (from_off[i] - c.lo), (size_t)stored[i]);
+        };
+        if (parts <= 1) body(0); else p->parallel(parts, body);
+    };
+    for (size_t k = 0; k < chunks.size(); k++) {
+        const int b = (int)(k & 1);
+        K4_HIP(ctx, hipMemcpyAsync(ctx->h_out[b], d_from + chunks[k].lo, (size_t)(chunks[k].hi - chunks[k].lo), hipMemcpyDeviceToHost, st));
+        K4_HIP(ctx, hipEventRecord(ctx->ev_out[b], st));
+        if (k > 0) {                                      /* the previous chunk has arrived by now, or soon: scatter it while this one flies */
+            K4_HIP(ctx, hipEventSynchronize(ctx->ev_out[b ^ 1]));
+            scatter(chunks[k - 1], ctx->h_out[b ^ 1]);
+        }
+    }
+    const int lastb = (int)((chunks.size() - 1) & 1);
+    K4_HIP(ctx, hipEventSynchronize(ctx->ev_out[lastb]));
+    scatter(chunks.back(), ctx->h_out[lastb]);
+    return K4LZ4_OK;
+}
+
 /* host-pointer batch: stage, run, scatter */
 int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
              uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level,
@@ -413,7 +577,6 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
     if ((rc = grow(ctx, &ctx->d_src, &ctx->d_src_cap, span + 64, false)) != K4LZ4_OK) return rc;
     if ((rc = grow(ctx, &ctx->d_dst, &ctx->d_dst_cap, (size_t)dtotal + 64, false)) != K4LZ4_OK) return rc;
     if ((rc = grow(ctx, &ctx->d_meta, &ctx->d_meta_cap, meta_bytes + 64, false)) != K4LZ4_OK) return rc;
-    if ((rc = grow(ctx, &ctx->h_stage, &ctx->h_stage_cap, (size_t)dtotal + 64, true)) != K4LZ4_OK) return rc;
 
     uint64_t *d_soff = (uint64_t *)ctx->d_meta;
     uint64_t *d_doff = d_soff + n;
@@ -421,7 +584,7 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
     int32_t *d_cap = d_slen + n;
     int32_t *d_out = d_cap + n;
     hipStream_t st = ctx->stream;
-    if (span) K4_HIP(ctx, hipMemcpyAsync(ctx->d_src, src + lo, span, hipMemcpyHostToDevice, st));
+    if (span && (rc = staged_upload(ctx, ctx->d_src, src + lo, span, st)) != K4LZ4_OK) return rc;
     K4_HIP(ctx, hipMemcpyAsync(d_soff, h_soff.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
     K4_HIP(ctx, hipMemcpyAsync(d_doff, h_doff.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
     K4_HIP(ctx, hipMemcpyAsync(d_slen, srcLen, (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -461,15 +624,36 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
     rc = launch(ctx, kind, ctx->d_src, d_soff, d_slen, ctx->d_dst, d_doff, d_cap, d_out, n, level, flags, st, &ddev, srcLen);
     if (rc != K4LZ4_OK) return rc;
     K4_HIP(ctx, hipMemcpyAsync(outLen, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    if (dtotal) K4_HIP(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_dst, (size_t)dtotal, hipMemcpyDeviceToHost, st));
     K4_HIP(ctx, hipStreamSynchronize(st));
     if ((rc = take_device_status(ctx)) != K4LZ4_OK) return rc;
+    /* what each block produced; those bytes are packed next to each other on the device (when that saves a tenth or more of
+     * the transfer) and come back through the pinned buffers in chunks cut at block boundaries; exactly outLen[i] bytes land
+     * in each caller slot */
+    const bool raw_negative = (flags & K4LZ4_FLAG_ALLOW_COPY) && kind == KIND_ENCODE;
+    std::vector<uint64_t> h_poff((size_t)n);
+    std::vector<int32_t> stored((size_t)n);
+    uint64_t used = 0;
     for (int64_t i = 0; i < n; i++) {
         const int32_t got = outLen[i];
-        const int32_t stored = (got < 0 && (flags & K4LZ4_FLAG_ALLOW_COPY) && kind == KIND_ENCODE) ? -got : got;   /* raw blocks come back as -length */
-        if (stored > 0 && stored <= h_cap[(size_t)i]) memcpy(dst + dstOff[i], ctx->h_stage + h_doff[(size_t)i], (size_t)stored);
+        int32_t sv = (got < 0 && raw_negative) ? -got : got;   /* raw blocks come back as -length */
+        if (sv < 0 || sv > h_cap[(size_t)i]) sv = 0;
+        stored[(size_t)i] = sv;
+        h_poff[(size_t)i] = used;
+        used += ((uint64_t)sv + 15u) & ~(uint64_t)15u;
     }
-    return K4LZ4_OK;
+    const uint8_t *d_from = ctx->d_dst;
+    const uint64_t *from_off = h_doff.data();
+    if (n > 1 && used + (used >> 3) < dtotal) {
+        if ((rc = grow(ctx, &ctx->d_pack, &ctx->d_pack_cap, (size_t)used + 64, false)) != K4LZ4_OK) return rc;
+        uint64_t *d_poff = d_soff;                           /* the source offsets are no longer needed */
+        K4_HIP(ctx, hipMemcpyAsync(d_poff, h_poff.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k4::k4_compact_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ctx->d_dst, d_doff, d_out, ctx->d_pack,
+                           d_poff, (long long)n, raw_negative ? 1 : 0);
+        K4_HIP(ctx, hipGetLastError());
+        d_from = ctx->d_pack;
+        from_off = h_poff.data();
+    }
+    return staged_download(ctx, dst, dstOff, d_from, from_off, stored.data(), n, st);
 }
 
 int run_device(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
@@ -564,6 +748,10 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_busy, hipEventDisableTiming);
+    for (int b = 0; b < 2 && e == hipSuccess; b++) {
+        e = hipEventCreateWithFlags(&ctx->ev_in[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_out[b], hipEventDisableTiming);
+    }
     if (const char *pct = getenv("K4LZ4_SPLIT_PCT")) { const int v = atoi(pct); ctx->split_pct = v < 1 ? 1 : (v > 100 ? 100 : v); }
     ctx->no_pair = getenv("K4LZ4_NO_PAIR") != nullptr;
     if (e != hipSuccess) { delete ctx; return hip_fail(nullptr, e, "hipStreamCreate"); }
@@ -580,6 +768,14 @@ void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev_busy) (void)hipEventDestroy(ctx->ev_busy);
+    for (int b = 0; b < 2; b++) {
+        if (ctx->ev_in[b]) (void)hipEventDestroy(ctx->ev_in[b]);
+        if (ctx->ev_out[b]) (void)hipEventDestroy(ctx->ev_out[b]);
+        if (ctx->h_in[b]) (void)hipHostFree(ctx->h_in[b]);
+        if (ctx->h_out[b]) (void)hipHostFree(ctx->h_out[b]);
+    }
+    if (ctx->d_pack) (void)hipFree(ctx->d_pack);
+    delete ctx->pool;
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
     if (ctx->d_dict) (void)hipFree(ctx->d_dict);
     if (ctx->d_src) (void)hipFree(ctx->d_src);

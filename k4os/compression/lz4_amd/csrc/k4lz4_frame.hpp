@@ -38,6 +38,20 @@ __global__ __launch_bounds__(256) void k4_allow_copy_kernel(BatchArgs a)
     if (lane == 0) a.outLen[b] = got;
 }
 
+/* host-pointer calls: the bytes each block produced, moved next to each other (dst + dstOff[b], 16-byte aligned positions)
+ * so that only they travel back over PCIe, not the slots' worst-case capacities.  outLen < 0 with `raw_negative` = a block
+ * stored raw by FLAG_ALLOW_COPY (-length bytes). */
+__global__ __launch_bounds__(256) void k4_compact_kernel(const uint8_t *src, const uint64_t *srcOff, const int32_t *outLen, uint8_t *dst,
+                                                         const uint64_t *dstOff, long long n, int raw_negative)
+{
+    const int lane = lane_id();
+    const long long b = (long long)blockIdx.x * 4 + (long long)uni(threadIdx.x >> 6);
+    if (b >= n) return;
+    int len = outLen[b];
+    if (len < 0 && raw_negative) len = -len;
+    if (len > 0) wave_copy(dst + dstOff[b], src + srcOff[b], (uint32_t)len, lane);
+}
+
 struct ChainArgs {
     const uint8_t *src;          /* stored blocks, packed */
     const uint64_t *blkOff;      /* per block: offset of its payload in src */

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from k4os.compression.lz4_amd import LZ4Codec, corpus, make_arena
 
-n, bs = 2048, 65536
+n, bs = int(os.environ.get("K4_BLOCKS", "4096")), 65536
 blocks = corpus.silesia_like_blocks(n, bs, seed=2)
 src = blocks.reshape(-1)
 off = np.arange(n, dtype=np.uint64) * bs
