@@ -11,8 +11,8 @@
  *   LZ4HC_Insert, LZ4HC_countBack, pattern helpers     Engine/LL.high.cs:91-122,:209-264,
  *                                                      Engine/x64/LL64.high.cs:37-68
  *   LZ4HC_encodeSequence                               Engine/x64/LL64.high.cs:435-510
- * Levels 10..12 (LZ4HC_compress_optimal, :802-1122) are outside the hot path and
- * return 0 here.
+ * Levels 10..12 (LZ4HC_compress_optimal, :802-1122, with LZ4HC_FindLongerMatch and the chain swap :172-206) are
+ * restated further down in this file as well.
  *
  * Parity pin: byte equality with the system liblz4.so.1 (1.9.3) LZ4_compress_HC on the
  * reproducible fixtures (tests/test_oracle_pins.py); the reference's HC goldens
