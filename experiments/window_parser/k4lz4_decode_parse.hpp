@@ -115,9 +115,14 @@ constexpr int PARSE_NL = 52;                   /* segments (chains) per window: 
 constexpr int PARSE_SLACK = 296;               /* bytes past the window that are kept in the ring */
 constexpr int PARSE_EXT_TRIPS = 32;            /* steps a chain takes past its own segment before it gives up */
 constexpr int PARSE_TOK_MAX = PARSE_NL * 22;   /* a sequence has at least 3 stream bytes */
-/* LDS of the parser, in dwords: ring (+ mirror) | main marks (2 per lane) | real-token bit set | entry offsets | token list */
-constexpr int PARSE_OFF_MARK = PARSE_RING_DW + 2, PARSE_OFF_TRUE = PARSE_OFF_MARK + 128, PARSE_OFF_RIN = PARSE_OFF_TRUE + 136,
-              PARSE_OFF_TOK = PARSE_OFF_RIN + 64, PARSE_LDS_DWORDS = PARSE_OFF_TOK + (PARSE_TOK_MAX + 1) / 2;
+/* LDS of the parser, in dwords: ring (+ mirror) | main marks (2 per lane) | real-token bit set | entry offsets.  The result --
+ * the window's token list -- is written over the last three once they have served: one BYTE per token, its distance
+ * from the token before it (255 = 255 or more: the caller knows where that token is by other means or not at all). */
+constexpr int PARSE_OFF_MARK = PARSE_RING_DW + 2, PARSE_OFF_TRUE = PARSE_OFF_MARK + 128, PARSE_OFF_RIN = PARSE_OFF_TRUE + 128,
+              PARSE_LDS_DWORDS = PARSE_OFF_RIN + 64, PARSE_OFF_LIST = PARSE_OFF_MARK;
+static_assert(2 * PARSE_NL + 6 <= 128, "the real-token bit set has two dwords per segment plus the extension marks' reach");
+static_assert(PARSE_TOK_MAX <= 4 * (PARSE_LDS_DWORDS - PARSE_OFF_LIST), "the token list fits over the parser's scratch");
+constexpr uint32_t PARSE_FAR = 255u;
 typedef StreamWin<PARSE_RING_DW> ParseWin;
 
 /*
@@ -205,8 +210,9 @@ __device__ __forceinline__ uint32_t walk_lanes(uint32_t word, uint32_t from, uns
 
 /*
  * One window: the token positions of the chain that starts at stream position wb (a real token), as far as the
- * window reaches.  Returns their number n; ptok[0..n) = positions relative to wb, ascending; end_ip = where the
- * chain goes on after them (the first position not in the list).  n == 0: the token at wb is left to the scalar
+ * window reaches.  Returns their number n; list[k] (bytes at area + PARSE_OFF_LIST) = distance of token k from token
+ * k - 1 (list[0] = 0: the first token is at wb; PARSE_FAR = that far or more); end_ip = where the chain goes on after
+ * them (the first position not in the list).  n == 0: the token at wb is left to the scalar
  * parser.  clim = iend - 16: chains only visit positions below it.  `area` = this wave's PARSE_LDS_DWORDS.
  */
 template <bool PROF = false, bool LIST = true>
@@ -217,7 +223,7 @@ __device__ __forceinline__ uint32_t parse_window(ParseWin &win, uint32_t wb, uin
      * tokens followed one at a time) */
     unsigned long long tq0 = prof_now<PROF>(), n_main = 0, n_ext = 0, n_hop = 0, n_ser = 0, n_list = 0;
     uint32_t *pm = area + PARSE_OFF_MARK, *pt_ = area + PARSE_OFF_TRUE, *prin = area + PARSE_OFF_RIN;
-    uint16_t *ptok = (uint16_t *)(area + PARSE_OFF_TOK);
+    uint8_t *plist = (uint8_t *)(area + PARSE_OFF_LIST);
     const uint32_t *ring = win.ring;
     /* everything below in aligned coordinates (stream position + a0) */
     const uint32_t a0 = win.a0, W = wb + a0, CL = clim + a0, LEN = win.len + a0;
@@ -372,20 +378,33 @@ __device__ __forceinline__ uint32_t parse_window(ParseWin &win, uint32_t wb, uin
     unsigned long long tm = (uint32_t)lane < nl ? ((unsigned long long)pt_[2 * lane + 1] << 32) | pt_[2 * lane] : 0ull;
     const uint32_t c = (uint32_t)__popcll(tm);
     const uint32_t incl = wave_inclusive_scan(c);
-    uint16_t *dst = ptok + (incl - c);
     const uint32_t total = readlane_u32(incl, 63);
-    const uint32_t rel0 = 64u * (uint32_t)lane;
     if (!LIST) {                                          /* the caller works from the segments' bit sets themselves */
         *bits = tm;
         end_ip = endp - a0;
         return total;
     }
-    while (__ballot(tm != 0ull)) {                        /* four per trip: the exit test costs as much as a position */
+    /* the token before this lane's first one: the last token of the nearest lane below that has any */
+    const uint32_t rel0 = 64u * (uint32_t)lane;
+    uint32_t last1 = tm ? rel0 + 64u - (uint32_t)__clzll((long long)tm) : 0u;   /* position + 1 of this lane's last token */
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)last1, (unsigned)sh);
+        if (lane >= sh && o > last1) last1 = o;
+    }
+    uint32_t prev = (uint32_t)__shfl_up((int)last1, 1u);   /* (lane 0: its own, unused) */
+    prev = lane == 0 ? 0u : prev;                          /* position + 1 of the token before, 0 = none */
+    lds_sync();                                            /* every lane has its bits: the list may now go over them */
+    uint8_t *dst = plist + (incl - c);
+    while (__ballot(tm != 0ull)) {                         /* four per trip: the exit test costs as much as a position */
         if (PROF) n_list++;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (tm) {
-                *dst++ = (uint16_t)(rel0 + (uint32_t)__ffsll((long long)tm) - 1u);
+                const uint32_t pos = rel0 + (uint32_t)__ffsll((long long)tm) - 1u;
+                const uint32_t d = prev ? pos + 1u - prev : 0u;
+                *dst++ = (uint8_t)(d < PARSE_FAR ? d : PARSE_FAR);
+                prev = pos + 1u;
                 tm &= tm - 1ull;
             }
         }

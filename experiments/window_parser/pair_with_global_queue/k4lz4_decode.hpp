@@ -38,11 +38,66 @@
 #pragma once
 #include "k4lz4_common.hpp"
 #include "k4lz4_decode_parse.hpp"
+#include <type_traits>
 
 namespace k4 {
 
 constexpr int DECODE_STAGE_BYTES = 2048;          /* a batch's output, kept in LDS while its matches resolve */
-constexpr int DECODE_LDS_DWORDS = PARSE_LDS_DWORDS + 5 * 64 + (DECODE_STAGE_BYTES + 64) / 4;   /* parser + 5 descriptor arrays + stage */
+constexpr int DECODE_LDS_DWORDS = RING_DWORDS + 5 * 64 + (DECODE_STAGE_BYTES + 64) / 4;   /* ring + 5 descriptor arrays + stage */
+constexpr int MAX_SEQ_PER_ROUND = 22;            /* 64 hypotheses, >= 3 stream bytes per sequence */
+
+/* PARSE's serial part: from hypothesis 0 follow the `next` links while the hypotheses are usable and stay inside
+ * the 64-lane window; T collects the real sequences, idx ends on the first position not taken.  A lane's word:
+ * bits 0-5 next lane if the chain goes on from here, else the lane itself; bit 7 the chain ends here (hypothesis
+ * unusable, or next token outside the window), bit 8 usable, bits 9.. next.  Scalar ISA by hand, and without a branch
+ * in the loop-carried path: s_bitset1 and v_readlane take the lane from the low six bits of the word just read, so
+ * one v_readlane feeds the next directly, and a lane where the chain ends points at itself, so hopping on is
+ * harmless -- 24 hops (a window holds at most 22 sequences) are laid out straight, with an exit test after 8 and 16.
+ * The compiler's loop has 14 instructions and two branches per sequence.  The lane the chain stops on is marked before it
+ * is known to be usable and unmarked afterwards if it was not. */
+__device__ __forceinline__ uint32_t token_word(bool fast, uint32_t next, int lane)
+{
+    return (fast && next < 64u ? next : (0x80u | (uint32_t)lane)) | (fast ? 0x100u : 0u) | (next << 9);
+}
+__device__ __forceinline__ void follow_tokens(uint32_t word, unsigned long long &T, uint32_t &idx)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t pk = 0;                                        /* a word's low six bits are the next lane: it selects the lane itself */
+    T = 0;
+#define K4_HOP "s_bitset1_b64 %[T], %[pk]\n\ts_nop 2\n\tv_readlane_b32 %[pk], %[word], %[pk]\n\t"
+#define K4_HOP8 K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP
+    asm volatile(
+        K4_HOP8
+        "s_bitcmp1_b32 %[pk], 7\n\t"
+        "s_cbranch_scc1 .Ltok_end%=\n\t"
+        K4_HOP8
+        "s_bitcmp1_b32 %[pk], 7\n\t"
+        "s_cbranch_scc1 .Ltok_end%=\n\t"
+        K4_HOP8
+        ".Ltok_end%=:"
+        : [T] "+s"(T), [pk] "+s"(pk)
+        : [word] "v"(word)
+        : "scc");
+#undef K4_HOP8
+#undef K4_HOP
+    const uint32_t last = 63u - (uint32_t)__builtin_clzll(T);
+    if (pk & 0x100u) {
+        idx = pk >> 9;
+    } else {
+        T &= ~(1ull << last);
+        idx = last;
+    }
+#else
+    T = 0;
+    idx = 0;
+    while (idx < 64u) {
+        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane(word, (int)idx);
+        if (!(pk & 0x100u)) break;
+        T |= 1ull << idx;
+        idx = pk >> 9;
+    }
+#endif
+}
 
 /* Match copy inside the output block: out[op + i] = out[op - offset + i] with the byte-serial
  * (replicating) semantics of LL64.dec.cs:408-450.  offset >= 1. */
@@ -90,20 +145,35 @@ __device__ __forceinline__ void wave_dict_copy(uint8_t *out, const uint8_t *dict
  * Two wavefronts per block (k4_decode_pair_kernel): a decoder wave spends ~85 % of its cycles waiting on its own
  * dependent chains, so PARSE (wave A) and LITERALS/MATCHES (wave B) of one block run side by side, batch k+1 being
  * parsed while batch k is copied.  The waves share a PIPE_SLOTS-deep queue of batch descriptors in LDS:
- *   pipe[0] head  batches published by A      pipe[1] tail  batches taken by B
+ *   pipe[0] head  batches published by A      pipe[1] tail  batches taken by B      pipe[2..3] address of the descriptor slots
  *   pipe[8 + 8 * slot ..]  nseq, output position of the batch, its byte count, last-batch flag, the block's result
- *   pipe[PIPE_DESC + 320 * slot ..]  the five descriptor arrays
- *   pipe[PIPE_SCRATCH ..]  B's two sort arrays, pipe[PIPE_STAGE ..] B's output stage
+ *   queue[320 * slot ..]   the five descriptor arrays (global memory)
+ *   pipe[PIPE_STAGE ..]    B's output stage (and, before it is filled, its two sort arrays)
  * LDS executes in order, so "write the batch, wait for the writes, then advance head" is a release; the reader polls
  * with s_sleep between attempts and gives up (block fails) after PIPE_SPIN_MAX polls instead of hanging.
  */
 #ifndef K4_PIPE_SLOTS
-#define K4_PIPE_SLOTS 4
+#define K4_PIPE_SLOTS 16
 #endif
-constexpr int PIPE_SLOTS = K4_PIPE_SLOTS;                     /* batches in flight between the two waves (power of two) */
-constexpr int PIPE_DESC = 8 + 8 * PIPE_SLOTS, PIPE_SCRATCH = PIPE_DESC + PIPE_SLOTS * 320, PIPE_STAGE = PIPE_SCRATCH + 128;
-constexpr int PIPE_DWORDS = PIPE_STAGE + (DECODE_STAGE_BYTES + 64) / 4;
-constexpr int DECODE_PAIR_LDS_DWORDS = PARSE_LDS_DWORDS + PIPE_DWORDS;
+constexpr int PIPE_SLOTS = K4_PIPE_SLOTS;                    /* batches in flight between the two waves (power of two): more than a window yields */
+/* The slots' descriptor arrays (5 x 64 dwords per batch) live in GLOBAL memory, in context scratch (PAIR_QUEUE_DWORDS per
+ * pair; pipe[2..3] hold the pair's address): the window parser delivers a dozen batches at a time and then is silent for a
+ * whole window, a queue that bridges that does not fit beside 16 pairs' other LDS.  Head / tail and the per-batch words
+ * stay in LDS; the waves are in one workgroup, so "store, wait for the stores, advance head" still publishes.
+ * B's two sort arrays live in its output stage: the stage is only filled after they have been searched. */
+constexpr int PIPE_META = 8, PIPE_SCRATCH = PIPE_META + 8 * PIPE_SLOTS, PIPE_STAGE = PIPE_SCRATCH;
+/* behind the stage: two arrays in which wave A sorts a batch's match destinations to find, for every match, the matches of
+ * the batch that write into its source (the sixth descriptor word: first lane | one past the last lane << 8) -- B, whose
+ * time is the block's time, only has to turn the interval into a mask */
+constexpr int PIPE_DEPSORT = PIPE_STAGE + (DECODE_STAGE_BYTES + 64) / 4;
+constexpr int PIPE_DWORDS = PIPE_DEPSORT + 128;
+constexpr int PAIR_SLOT_DWORDS = 384;             /* lpos, llen, out, moff, mlen, dependency interval */
+constexpr int PAIR_QUEUE_DWORDS = PIPE_SLOTS * PAIR_SLOT_DWORDS;
+/* wave A parses with the window parser (k4lz4_decode_parse.hpp): its LDS comes first.  16 pairs per CU -- every block of a
+ * 4096-block batch resident at once -- need a pair to stay within 10 KiB. */
+constexpr int PAIR_PARSE_DWORDS = PARSE_LDS_DWORDS;
+constexpr int DECODE_PAIR_LDS_DWORDS = PAIR_PARSE_DWORDS + PIPE_DWORDS;
+static_assert(DECODE_PAIR_LDS_DWORDS * 4 * 16 <= 160 * 1024, "16 decoder pairs per CU");
 constexpr uint32_t PIPE_SPIN_MAX = 1u << 24;
 constexpr int PIPE_TIMEOUT = -0x7ffffff0;
 
@@ -125,13 +195,23 @@ __device__ __forceinline__ void pipe_store(uint32_t *p, uint32_t v, int lane)
 #endif
     lds_sync();
 }
-/* poll until *p - base >= want (counters only grow); false after PIPE_SPIN_MAX polls */
+/* first words of a pair's LDS queue: head = tail = 0, then the address of its descriptor slots in the context's scratch */
+__device__ __forceinline__ uint32_t pair_queue_word(uint32_t *gq, long long pair_index, int word)
+{
+    const uint64_t addr = (uint64_t)(gq + (size_t)pair_index * (size_t)PAIR_QUEUE_DWORDS);
+    return word == 2 ? (uint32_t)addr : word == 3 ? (uint32_t)(addr >> 32) : 0u;
+}
+
+/* poll until *p >= want (counters only grow); false after PIPE_SPIN_MAX polls.  The first polls come quickly -- the partner is
+ * usually about to deliver -- the later ones leave the issue slots to the waves that have something to do. */
 __device__ __forceinline__ bool pipe_wait(const uint32_t *p, uint32_t want)
 {
     for (uint32_t spin = 0; spin < PIPE_SPIN_MAX; spin++) {
         if (pipe_load(p) >= want) return true;
-        __builtin_amdgcn_s_sleep(1);
+        if (spin < 8u) __builtin_amdgcn_s_sleep(1);
+        else __builtin_amdgcn_s_sleep(8);
     }
+    atomicOr(&k4_dev_status, (uint32_t)DEV_STATUS_PIPE_TIMEOUT);   /* reported at call level: not this block's fault */
     return false;
 }
 
@@ -154,7 +234,8 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     const bool check_offset = chk_size < 65536;
     const bool prefix64 = dict.mode == 1 && dict.size == 65536u;
     unsigned long long c_parse = 0, c_lit = 0, c_match = 0, n_batch = 0, n_round = 0, n_seq = 0, n_slow = 0;
-    unsigned long long c_hyp = 0, c_chain = 0, c_wait = 0, n_spec = 0;   /* PARSE split: windows, deriving batches; time spent waiting for the other wave */
+    unsigned long long c_hyp = 0, c_chain = 0, c_rules = 0, c_slots = 0, n_spec = 0;   /* PARSE split: speculative rounds */
+    unsigned long long c_wait = 0, c_win = 0, c_derive = 0, n_win = 0;                 /* pair kernels: waiting for the partner; windows, deriving */
     if (ROLE == 0) prof_place<PROF>(pc, 8, lane);
     const unsigned long long t_begin = prof_now<PROF>();
     if (out_size == 0) {                                   /* LL64.dec.cs:162-168 */
@@ -167,13 +248,17 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     }
     if (src_size <= 0) return -1;                          /* :172 */
 
-    ParseWin win;
+    /* ROLE 1 finds its tokens a window at a time (parse_window); ROLE 0 has no LDS to spare for that and keeps the
+     * speculative 64-hypotheses round */
+    using Win = typename std::conditional<ROLE == 1, ParseWin, StreamRing>::type;
+    Win win;
     if (ROLE != 2) win.init(lds, in, (uint32_t)src_size, lane);
-    /* the token list of the current window (parse_window): tk_n positions relative to tk_base, tk_i of them used,
-     * the chain goes on at tk_end after the last one */
-    uint32_t tk_n = 0, tk_i = 0, tk_base = 0, tk_end = 0;
-    const uint16_t *ptok = (const uint16_t *)(lds + PARSE_OFF_TOK);
-    uint32_t *d_lpos = ROLE == 0 ? lds + PARSE_LDS_DWORDS : pipe + PIPE_DESC, *d_llen = d_lpos + 64, *d_out = d_llen + 64,
+    /* ROLE 1: the current window's token list (parse_window): tk_n tokens, tk_i of them handed on; the chain goes on at
+     * tk_end after the last one */
+    uint32_t tk_n = 0, tk_i = 0, tk_end = 0;
+    const uint8_t *tk_list = (const uint8_t *)(lds + PARSE_OFF_LIST);
+    uint32_t *const queue = ROLE == 0 ? nullptr : (uint32_t *)(((uint64_t)uni(pipe[3]) << 32) | (uint64_t)uni(pipe[2]));
+    uint32_t *d_lpos = ROLE == 0 ? lds + RING_DWORDS : queue, *d_llen = d_lpos + 64, *d_out = d_llen + 64,
              *d_moff = d_out + 64, *d_mlen = d_moff + 64;
     /* MATCHES sorts destination ranges in two arrays: the descriptor arrays themselves when one wave does it all */
     uint32_t *w_out = ROLE == 0 ? d_out : pipe + PIPE_SCRATCH, *w_end = ROLE == 0 ? d_llen : pipe + PIPE_SCRATCH + 64;
@@ -199,7 +284,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
         if (ROLE != 0) {
             const uint32_t slot = batch_no & (uint32_t)(PIPE_SLOTS - 1);
             meta = pipe + 8 + 8 * slot;
-            d_lpos = pipe + PIPE_DESC + 320 * slot; d_llen = d_lpos + 64; d_out = d_llen + 64; d_moff = d_out + 64; d_mlen = d_moff + 64;
+            d_lpos = queue + PAIR_SLOT_DWORDS * slot; d_llen = d_lpos + 64; d_out = d_llen + 64; d_moff = d_out + 64; d_mlen = d_moff + 64;
             const unsigned long long tw0 = prof_now<PROF>();
             if (ROLE == 1) {                                /* the slot is free once the other wave has taken batch_no - PIPE_SLOTS */
                 if (batch_no >= (uint32_t)PIPE_SLOTS && !pipe_wait(pipe + 1, batch_no + 1u - (uint32_t)PIPE_SLOTS)) return PIPE_TIMEOUT;
@@ -214,53 +299,139 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 err = (int)uni(meta[4]);                    /* the block's result, valid with `done` */
             }
         }
-        while (ROLE != 2 && nseq < 64 && !done) {
-            /* ---- the next window's token positions, when the list has run out ---- */
-            if (tk_i == tk_n && ip < iend - 16) {
-                const unsigned long long tp0 = prof_now<PROF>();
-                tk_base = (uint32_t)ip;
-                tk_n = parse_window(win, tk_base, (uint32_t)(iend - 16), lane, lds, tk_end);
-                tk_i = 0;
-                if (PROF) { c_hyp += prof_now<PROF>() - tp0; n_spec++; }
+        while (ROLE != 2 && (ROLE == 1 ? nseq < 64 : nseq <= 64 - MAX_SEQ_PER_ROUND) && !done) {
+            if constexpr (ROLE == 1) {
+                /* ---- the next window's tokens, when the last one's are used up ---- */
+                if (tk_i == tk_n && ip < iend - 16) {
+                    const unsigned long long tq = prof_now<PROF>();
+                    tk_n = parse_window<false, true>(win, (uint32_t)ip, (uint32_t)(iend - 16), lane, lds, tk_end);
+                    tk_i = 0;
+                    if (PROF) { c_win += prof_now<PROF>() - tq; n_win++; }
+                }
+                const unsigned long long td = prof_now<PROF>();
+                if (tk_i < tk_n) {
+                    /* ---- up to 64 of them at once: lane i derives the sequence of the i-th.  The list holds distances: the
+                     * first token of the batch is where the parser is (ip), a prefix sum places the others; a distance the
+                     * list could not hold ends the batch before it ---- */
+                    const uint32_t avail = tk_n - tk_i;
+                    const uint32_t want = avail < 64u - (uint32_t)nseq ? avail : 64u - (uint32_t)nseq;
+                    const uint32_t dist = (uint32_t)lane != 0u && (uint32_t)lane < want ? (uint32_t)tk_list[tk_i + (uint32_t)lane] : 0u;
+                    uint32_t cnt = want;
+                    {
+                        const unsigned long long farm = __ballot(dist == PARSE_FAR);
+                        if (farm) cnt = (uint32_t)ctz64(farm);
+                    }
+                    const uint32_t rel = wave_inclusive_scan((uint32_t)lane < cnt ? dist : 0u);
+                    {   /* all of them inside the ring at once (the scalar parser may have moved it) */
+                        const unsigned long long wide = __ballot((uint32_t)lane < cnt && rel > 3200u);
+                        if (wide) cnt = (uint32_t)ctz64(wide);
+                    }
+                    const uint32_t base_s = (uint32_t)ip;
+                    win.cover(base_s + win.a0, base_s + readlane_u32(rel, (int)cnt - 1) + (uint32_t)PARSE_SLACK + win.a0, lane);
+                    /* where the chain goes after lane i's token: the next token of the list, else the window's end */
+                    const uint32_t dnext = (uint32_t)lane + 1u < avail ? (uint32_t)tk_list[tk_i + (uint32_t)lane + 1u] : 0u;
+                    const bool act = (uint32_t)lane < cnt;
+                    const uint32_t p = base_s + (act ? rel : 0u);
+                    const uint32_t t4 = win.at(p);
+                    uint32_t L = (t4 >> 4) & 15u;
+                    uint32_t M = t4 & 15u;
+                    /* class S: the shortcut (:191-225), literal length in the token.
+                     * class G: 15 + one extension byte of literals -> the general literal path (:228-315) */
+                    const bool cls_g = L == RUN_MASK;
+                    uint32_t hdr = 1u;                      /* token (+ literal-length extension) bytes */
+                    bool fast = act && (cls_g ? (int64_t)p < iend - RUN_MASK - 1 : (int64_t)p + 1 < shortiend);
+                    if (cls_g) {
+                        const uint32_t ext = (t4 >> 8) & 0xffu;
+                        fast = fast && ext != 255u;
+                        L += ext;
+                        hdr = 2u;
+                        /* the run must leave room for offset + a last sequence (:247) */
+                        fast = fast && (int64_t)p + hdr + L <= iend - (2 + 1 + LASTLITERALS);
+                    }
+                    const uint32_t o4 = win.at(p + hdr + L);
+                    const uint32_t offset = o4 & 0xffffu;
+                    uint32_t next = p + hdr + L + 2u;       /* where the match-length field ends and the next token starts */
+                    uint32_t mlen = M + MINMATCH;
+                    fast = fast && offset != 0u;
+                    const bool general = cls_g || M == ML_MASK || offset < 8u;   /* not the shortcut's match stage */
+                    if (M == ML_MASK) {                    /* one extension byte (:326-334) */
+                        const uint32_t ext = (o4 >> 16) & 0xffu;
+                        mlen += ext;
+                        next += 1u;
+                        /* the byte after the extension must stay below iend - LASTLITERALS + 1 */
+                        fast = fast && ext != 255u && (int64_t)next < iend - LASTLITERALS + 1;
+                    }
+                    const uint32_t outlen = L + mlen;
+                    /* the window says where the chain went from here: a sequence that ends elsewhere is not this one (a
+                     * distance of PARSE_FAR says nothing: sequences that long are not of the fast kind anyway) */
+                    const uint32_t succ = (uint32_t)lane + 1u < avail ? p + dnext : tk_end;
+                    fast = fast && next == succ && dnext != PARSE_FAR;
+                    {   /* the first token that needs more, and everything after it, is left to the scalar parser */
+                        const unsigned long long nf = __ballot(act && !fast);
+                        if (nf) cnt = (uint32_t)ctz64(nf);
+                    }
+                    bool in_t = (uint32_t)lane < cnt;
+                    const uint32_t incl = wave_inclusive_scan(in_t ? outlen : 0u);
+                    const int64_t v_o64 = op + (int64_t)(incl - (in_t ? outlen : 0u));
+                    const uint32_t v_o = (uint32_t)v_o64;
+                    /* position-dependent rules, as in the speculative round below */
+                    const int64_t mdst_l = v_o64 + L;
+                    unsigned long long bad;
+                    if (op + (int64_t)readlane_u32(incl, 63) <= oend - 64) {
+                        bad = __ballot(in_t && offset > v_o + L);
+                    } else {
+                        bad = __ballot(in_t && ((cls_g ? mdst_l > oend - MFLIMIT : v_o64 > shortoend) || (int64_t)offset > mdst_l ||
+                                                (general && mdst_l + (int64_t)mlen > oend - MATCH_SAFEGUARD)));
+                    }
+                    if (bad) {
+                        cnt = (uint32_t)ctz64(bad);
+                        in_t = (uint32_t)lane < cnt;
+                    }
+                    if (cnt) {
+                        if (in_t) {
+                            const uint32_t slot = (uint32_t)nseq + (uint32_t)lane;
+                            d_lpos[slot] = p + hdr;
+                            d_llen[slot] = L;
+                            d_out[slot] = v_o;
+                            d_moff[slot] = offset;
+                            d_mlen[slot] = mlen;
+                        }
+                        nseq += (int)cnt;
+                        tk_i += cnt;
+                        if (PROF) c_derive += prof_now<PROF>() - td;
+                        ip = (int64_t)readlane_u32(next, (int)cnt - 1);
+                        op += (int64_t)readlane_u32(incl, (int)cnt - 1);
+                        continue;
+                    }
+                }
             }
-            if (tk_i < tk_n) {
-                /* ---- up to 64 tokens of the list at once: lane i derives the sequence of the i-th ---- */
-                const unsigned long long tp1 = prof_now<PROF>();
-                const uint32_t avail = tk_n - tk_i;
-                uint32_t cnt = avail < 64u - (uint32_t)nseq ? avail : 64u - (uint32_t)nseq;
-                const uint32_t rel = (uint32_t)lane < cnt ? (uint32_t)ptok[tk_i + (uint32_t)lane] : 0u;
-                const uint32_t rel0 = uni(rel);
-                if ((int64_t)tk_base + rel0 != ip) {       /* the list is not where the parser is: drop it */
-                    tk_n = tk_i = 0;
-                    continue;
-                }
-                {   /* all of them inside the ring at once (the scalar parser may have moved it) */
-                    const unsigned long long far = __ballot((uint32_t)lane < cnt && rel - rel0 > 3200u);
-                    if (far) cnt = (uint32_t)ctz64(far);
-                }
-                win.cover((uint32_t)ip + win.a0, tk_base + readlane_u32(rel, (int)cnt - 1) + (uint32_t)PARSE_SLACK + win.a0, lane);
-                const bool act = (uint32_t)lane < cnt;
-                const uint32_t p = tk_base + (act ? rel : rel0);
-                const uint32_t t4 = win.at(p);
+            /* ---- speculative round: 64 hypotheses "a token starts at ip + lane" ---- */
+            const int64_t lim = shortiend - 1 - ip;        /* hypotheses i < lim satisfy ip + i + 1 < shortiend */
+            if constexpr (ROLE != 1) if (lim > 0 || iend - RUN_MASK - 1 - ip > 0) {
+                const unsigned long long tp0 = prof_now<PROF>();
+                win.ensure((uint32_t)ip + win.a0, lane);
+                const uint32_t q = (uint32_t)ip + win.a0 + (uint32_t)lane;
+                const uint32_t t4 = win.read4(q);
                 uint32_t L = (t4 >> 4) & 15u;
                 uint32_t M = t4 & 15u;
                 /* class S: the shortcut (:191-225), literal length in the token.
                  * class G: 15 + one extension byte of literals -> the general literal path (:228-315) */
                 const bool cls_g = L == RUN_MASK;
                 uint32_t hdr = 1u;                          /* token (+ literal-length extension) bytes */
-                bool fast = act && (cls_g ? (int64_t)p < iend - RUN_MASK - 1 : (int64_t)p + 1 < shortiend);
+                bool fast = cls_g ? (int64_t)lane < iend - RUN_MASK - 1 - ip : (int64_t)lane < lim;
                 if (cls_g) {
                     const uint32_t ext = (t4 >> 8) & 0xffu;
                     fast = fast && ext != 255u;
                     L += ext;
                     hdr = 2u;
                     /* the run must leave room for offset + a last sequence (:247) */
-                    fast = fast && (int64_t)p + hdr + L <= iend - (2 + 1 + LASTLITERALS);
+                    fast = fast && (int64_t)ip + lane + hdr + L <= iend - (2 + 1 + LASTLITERALS);
                 }
-                const uint32_t o4 = win.at(p + hdr + L);
+                const uint32_t q2 = q + hdr + L;
+                const uint32_t o4 = win.read4(q2);
                 const uint32_t offset = o4 & 0xffffu;
-                /* where the match-length field ends and the next token starts */
-                uint32_t next = p + hdr + L + 2u;
+                /* where the match-length field ends and the next token starts, relative to ip */
+                uint32_t next = (uint32_t)lane + hdr + L + 2u;
                 uint32_t mlen = M + MINMATCH;
                 fast = fast && offset != 0u;
                 const bool general = cls_g || M == ML_MASK || offset < 8u;   /* not the shortcut's match stage */
@@ -269,18 +440,19 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                     mlen += ext;
                     next += 1u;
                     /* the byte after the extension must stay below iend - LASTLITERALS + 1 */
-                    fast = fast && ext != 255u && (int64_t)next < iend - LASTLITERALS + 1;
+                    fast = fast && ext != 255u && (int64_t)ip + next < iend - LASTLITERALS + 1;
                 }
                 const uint32_t outlen = L + mlen;
-                /* the list says where the chain went from here: a sequence that ends elsewhere is not this one */
-                const uint32_t succ = (uint32_t)lane + 1u < avail ? tk_base + (uint32_t)ptok[tk_i + (uint32_t)lane + (act ? 1u : 0u)] : tk_end;
-                fast = fast && next == succ;
-                {   /* the first token that needs more, and everything after it, is left to the scalar parser */
-                    const unsigned long long nf = __ballot(act && !fast);
-                    if (nf) cnt = (uint32_t)ctz64(nf);
-                }
-                bool in_t = (uint32_t)lane < cnt;
+                const uint32_t packed = token_word(fast, next, lane);
+
+                /* follow the true chain from hypothesis 0: one v_readlane per real sequence */
+                unsigned long long T = 0;
+                uint32_t idx = 0;
+                const unsigned long long tp1 = prof_now<PROF>();
+                follow_tokens(packed, T, idx);
+                const unsigned long long tp2 = prof_now<PROF>();
                 /* output position of every chosen sequence: prefix sum of the chosen lengths */
+                bool in_t = ((T >> lane) & 1ull) != 0;
                 const uint32_t incl = wave_inclusive_scan(in_t ? outlen : 0u);
                 const int64_t v_o64 = op + (int64_t)(incl - (in_t ? outlen : 0u));
                 const uint32_t v_o = (uint32_t)v_o64;
@@ -291,7 +463,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                  * sequence that fails, and everything after it, is left to the scalar parser. */
                 const int64_t mdst_l = v_o64 + L;
                 unsigned long long bad;
-                if (op + (int64_t)readlane_u32(incl, 63) <= oend - 64) {
+                if (op + (int64_t)__builtin_amdgcn_readlane(incl, 63) <= oend - 64) {
                     /* every chosen sequence ends at least 64 bytes before the end of the output: the three
                      * end-of-block rules hold for all of them, only the offset can be wrong */
                     bad = __ballot(in_t && offset > v_o + L);
@@ -299,30 +471,39 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                     bad = __ballot(in_t && ((cls_g ? mdst_l > oend - MFLIMIT : v_o64 > shortoend) || (int64_t)offset > mdst_l ||
                                             (general && mdst_l + (int64_t)mlen > oend - MATCH_SAFEGUARD)));
                 }
+                int64_t cur_op;
                 if (bad) {
-                    cnt = (uint32_t)ctz64(bad);
-                    in_t = (uint32_t)lane < cnt;
+                    const int b = ctz64(bad);
+                    T &= (1ull << b) - 1ull;
+                    idx = (uint32_t)b;
+                    cur_op = op + (int64_t)(__builtin_amdgcn_readlane(incl, b) - __builtin_amdgcn_readlane(outlen, b));
+                    in_t = ((T >> lane) & 1ull) != 0;
+                } else {
+                    cur_op = op + (int64_t)__builtin_amdgcn_readlane(incl, 63);
                 }
-                if (PROF) c_chain += prof_now<PROF>() - tp1;
-                if (cnt) {
+                const unsigned long long tp3 = prof_now<PROF>();
+                if (PROF) { c_hyp += tp1 - tp0; c_chain += tp2 - tp1; c_rules += tp3 - tp2; n_spec++; }
+                if (T) {
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(T >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)T, 0u));
                     if (in_t) {
-                        const uint32_t slot = (uint32_t)nseq + (uint32_t)lane;
-                        d_lpos[slot] = p + hdr;
+                        const uint32_t slot = (uint32_t)nseq + below;
+                        d_lpos[slot] = (uint32_t)ip + (uint32_t)lane + hdr;
                         d_llen[slot] = L;
                         d_out[slot] = v_o;
                         d_moff[slot] = offset;
                         d_mlen[slot] = mlen;
                     }
-                    nseq += (int)cnt;
-                    tk_i += cnt;
-                    ip = (int64_t)readlane_u32(next, (int)cnt - 1);
-                    op += (int64_t)readlane_u32(incl, (int)cnt - 1);
+                    nseq += __popcll(T);
+                    ip += idx;
+                    op = cur_op;
+                    if (PROF) c_slots += prof_now<PROF>() - tp3;
                     continue;
                 }
             }
 
             /* ---- scalar parser: one sequence, the reference's order of checks ---- */
             if (PROF) n_slow++;
+            const int64_t ip_token = ip;
             uint32_t w = win.fetch((uint32_t)ip, lane);
             const uint32_t token = w & 0xffu;
             ip++;
@@ -433,13 +614,42 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             nseq++;
             op += adv;
             if (last) done = true;
-            if (tk_i < tk_n) {                              /* that was the list's next token: is the list still right? */
-                tk_i++;
-                const uint32_t expect = tk_i < tk_n ? tk_base + uni((uint32_t)ptok[tk_i]) : tk_end;
-                if ((int64_t)expect != ip) tk_n = tk_i = 0;
+            if constexpr (ROLE == 1) {
+                if (tk_i < tk_n) {                          /* that was the window's next token: do its other tokens still stand? */
+                    tk_i++;
+                    /* the list gives the next token's distance from this one; a distance it could not hold is taken on trust
+                     * (the next batch starts at ip and checks every sequence it derives), the window's end likewise is
+                     * where the chain was seen to go */
+                    const uint32_t d = tk_i < tk_n ? uni((uint32_t)tk_list[tk_i]) : 0u;
+                    const int64_t expect = tk_i < tk_n ? (d == PARSE_FAR ? ip : ip_token + (int64_t)d) : (int64_t)tk_end;
+                    if (expect != ip) tk_n = tk_i = 0u;
+                }
             }
         }
         if (ROLE == 1) {                                    /* publish the batch (or the failure) and go on parsing */
+            if (!err && nseq > 0) {
+                /* which matches of the batch write into each match's source: destination ranges are sorted by lane, one
+                 * binary search per end of the source range (LL64.dec.cs has no such step: it copies in order) */
+                uint32_t *s_out = pipe + PIPE_DEPSORT, *s_end = s_out + 64;
+                wave_sync();                                /* (lane 0 may have written descriptors of the careful kind) */
+                const bool minep = lane < nseq;
+                const uint32_t q_llen = minep ? d_llen[lane] : 0u, q_out = minep ? d_out[lane] : 0u, q_moff = minep ? d_moff[lane] : 0u,
+                               q_mlen = minep ? d_mlen[lane] : 0u;
+                const uint32_t mdst = q_out + q_llen, mend = mdst + q_mlen, msrc = mdst - q_moff;
+                const uint32_t send = msrc + q_mlen < mdst ? msrc + q_mlen : mdst;
+                s_out[lane] = minep ? mdst : 0xffffffffu;
+                s_end[lane] = minep ? mend : 0xffffffffu;
+                lds_sync();
+                uint32_t lo = 0, hi = 0;
+#pragma unroll
+                for (uint32_t step = 32; step != 0; step >>= 1) {
+                    if (s_end[lo + step - 1u] <= msrc) lo += step;
+                    if (s_out[hi + step - 1u] < send) hi += step;
+                }
+                const uint32_t hi_c = hi < (uint32_t)lane ? hi : (uint32_t)lane;
+                d_mlen[64 + lane] = lo | (hi_c << 8);
+                lds_sync();
+            }
             if (lane == 0) {
                 meta[0] = err ? 0u : (uint32_t)nseq;
                 meta[1] = (uint32_t)op_batch;
@@ -447,13 +657,17 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 meta[3] = (err || done) ? 1u : 0u;
                 meta[4] = (uint32_t)(err ? err : (int)op);
             }
+            wave_sync();
+#ifndef K4_HOST_EMU
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* the descriptors are in memory before the batch is announced */
+#endif
             pipe_store(pipe + 0, batch_no + 1u, lane);
             batch_no++;
             if (err || done) {
                 if (seq) *seq = batch_no;
                 if (PROF && pc && lane == 0) {              /* the parsing wave's half of the pair's record */
-                    pc[0] = prof_now<PROF>() - t_begin; pc[1] = c_hyp; pc[2] = c_chain; pc[3] = c_wait;
-                    pc[4] = batch_no; pc[5] = n_spec; pc[7] = n_slow;
+                    pc[0] = prof_now<PROF>() - t_begin; pc[1] = c_win; pc[2] = c_derive; pc[3] = c_wait;
+                    pc[4] = batch_no; pc[5] = n_win; pc[7] = n_slow;
                 }
                 return err ? err : (int)op;
             }
@@ -467,7 +681,13 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
         const uint32_t v_out = mine ? d_out[lane] : 0u;
         const uint32_t v_moff = mine ? d_moff[lane] : 0u;
         const uint32_t v_mlen = mine ? d_mlen[lane] : 0u;
+        const uint32_t v_dep = ROLE == 2 && mine ? d_mlen[64 + lane] : 0u;
         if (ROLE == 2) {                                    /* the descriptors are in registers: the slot may be refilled */
+#ifndef K4_HOST_EMU
+            /* (in registers: a use of the five values makes the compiler wait for exactly these loads, not for the stores
+             * of the batch before, which may still be on their way) */
+            asm volatile("" :: "v"(v_lpos), "v"(v_llen), "v"(v_out), "v"(v_moff), "v"(v_mlen), "v"(v_dep) : "memory");
+#endif
             pipe_store(pipe + 1, batch_no + 1u, lane);
             batch_no++;
         }
@@ -490,19 +710,25 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             LaneRun L, M;
             lane_run_load(L, in + v_lpos, mine ? v_llen : 0u, (uint32_t)src_size - v_lpos);
             lane_run_load(M, out + msrc, before, (uint32_t)out_size - msrc);
-            /* dependencies among the matches of the batch, as below */
-            const uint32_t send = msrc + v_mlen < mdst ? msrc + v_mlen : mdst;
-            lds_sync();
-            w_out[lane] = mine ? mdst : 0xffffffffu;
-            w_end[lane] = mine ? mend : 0xffffffffu;
-            lds_sync();
-            uint32_t lo = 0, hi = 0;
+            /* dependencies among the matches of the batch: lanes [lo, hi_c) -- searched here (one wave does it all) or by the
+             * parsing wave */
+            uint32_t lo = 0, hi_c = 0;
+            if (ROLE == 2) {
+                lo = v_dep & 255u; hi_c = v_dep >> 8;
+            } else {
+                const uint32_t send = msrc + v_mlen < mdst ? msrc + v_mlen : mdst;
+                lds_sync();
+                w_out[lane] = mine ? mdst : 0xffffffffu;
+                w_end[lane] = mine ? mend : 0xffffffffu;
+                lds_sync();
+                uint32_t hi = 0;
 #pragma unroll
-            for (uint32_t step = 32; step != 0; step >>= 1) {
-                if (w_end[lo + step - 1u] <= msrc) lo += step;
-                if (w_out[hi + step - 1u] < send) hi += step;
+                for (uint32_t step = 32; step != 0; step >>= 1) {
+                    if (w_end[lo + step - 1u] <= msrc) lo += step;
+                    if (w_out[hi + step - 1u] < send) hi += step;
+                }
+                hi_c = hi < (uint32_t)lane ? hi : (uint32_t)lane;
             }
-            const uint32_t hi_c = hi < (uint32_t)lane ? hi : (uint32_t)lane;
             unsigned long long deps = 0;
             const bool later = has_m && before < v_mlen;            /* some source bytes are this batch's output */
             if (later && lo < hi_c) deps = ((hi_c >= 64u ? 0ull : (1ull << hi_c)) - 1ull) & ~((1ull << lo) - 1ull);
@@ -558,20 +784,25 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             const uint32_t mend = mdst + v_mlen;
             const uint32_t msrc = mdst - v_moff;
             const uint32_t send = msrc + v_mlen < mdst ? msrc + v_mlen : mdst;   /* source bytes below own output */
-            /* destination ranges sorted by lane: publish [mdst, mend) (sentinel for idle lanes) */
-            wave_sync();
-            w_out[lane] = mine ? mdst : 0xffffffffu;
-            w_end[lane] = mine ? mend : 0xffffffffu;
-            wave_sync();
-            /* first lane whose match ends above msrc, first lane whose match starts at/after send */
-            uint32_t lo = 0, hi = 0;
+            /* the lanes [lo, hi_c) whose matches write into this one's source: from the parsing wave, or searched here --
+             * destination ranges sorted by lane (sentinel for idle lanes), first lane whose match ends above msrc, first
+             * lane whose match starts at / after send */
+            uint32_t lo = 0, hi_c = 0;
+            if (ROLE == 2) {
+                lo = v_dep & 255u; hi_c = v_dep >> 8;
+            } else {
+                wave_sync();
+                w_out[lane] = mine ? mdst : 0xffffffffu;
+                w_end[lane] = mine ? mend : 0xffffffffu;
+                wave_sync();
+                uint32_t hi = 0;
 #pragma unroll
-            for (uint32_t step = 32; step != 0; step >>= 1) {
-                if (w_end[lo + step - 1u] <= msrc) lo += step;
-                if (w_out[hi + step - 1u] < send) hi += step;
+                for (uint32_t step = 32; step != 0; step >>= 1) {
+                    if (w_end[lo + step - 1u] <= msrc) lo += step;
+                    if (w_out[hi + step - 1u] < send) hi += step;
+                }
+                hi_c = hi < (uint32_t)lane ? hi : (uint32_t)lane;
             }
-            /* dependencies: lanes [lo, hi) below this lane */
-            const uint32_t hi_c = hi < (uint32_t)lane ? hi : (uint32_t)lane;
             unsigned long long deps = 0;
             if (has && lo < hi_c) deps = ((hi_c >= 64u ? 0ull : (1ull << hi_c)) - 1ull) & ~((1ull << lo) - 1ull);
             /* a match that starts before the block (dictionary) waits for everything below it and is
@@ -618,9 +849,9 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     if (PROF && pc && lane == 0) {
         pc[0] = prof_now<PROF>() - t_begin; pc[1] = c_parse; pc[2] = c_lit; pc[3] = c_match;
         pc[4] = n_batch; pc[5] = n_round; pc[6] = n_seq; pc[7] = n_slow;
-        pc[11] = c_hyp; pc[12] = c_chain; pc[13] = 0; pc[14] = 0; pc[15] = n_spec;
+        pc[11] = c_hyp; pc[12] = c_chain; pc[13] = c_rules; pc[14] = c_slots; pc[15] = n_spec;
     }
-    prof_place<PROF>(pc, 9, lane);
+    if (ROLE == 0) prof_place<PROF>(pc, 9, lane);
     return (int)op;
 }
 
@@ -675,11 +906,8 @@ __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_decode_kernel(Bat
 
 /* ... and with at most half as many blocks as the chip has wave slots, two waves per block: wave 2p parses block p of
  * the workgroup, wave 2p+1 copies (see the queue above).  8 waves per SIMD need <= 64 VGPRs. */
-#ifndef K4_PAIRS_PER_WG
-#define K4_PAIRS_PER_WG 2
-#endif
-constexpr int DECODE_PAIRS_PER_WG = K4_PAIRS_PER_WG;     /* measured: 4 pairs per workgroup 233 GiB/s on the bench batch, 2 pairs 242, 1 pair 223 */
-__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) void k4_decode_pair_kernel(BatchArgs a)
+constexpr int DECODE_PAIRS_PER_WG = 2;     /* measured: 4 pairs per workgroup 233 GiB/s on the bench batch, 2 pairs 242, 1 pair 223 */
+__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k4_decode_pair_kernel(BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
     const int lane = lane_id();
@@ -687,8 +915,8 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) void k4_decode_pair_kern
     /* odd workgroups swap the roles, so that a SIMD hosts parsing and copying waves alike */
     const uint32_t pair = wave >> 1, role = (wave ^ blockIdx.x) & 1u;
     const long long slot = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
-    uint32_t *ring = lds[pair], *pipe = lds[pair] + PARSE_LDS_DWORDS;
-    if (lane < 8 && role == 0) pipe[lane] = 0u;             /* head, tail */
+    uint32_t *ring = lds[pair], *pipe = lds[pair] + PAIR_PARSE_DWORDS;
+    if (lane < 8 && role == 0) pipe[lane] = pair_queue_word(a.gq, slot, lane);   /* head, tail, the queue's address */
     __syncthreads();
     if (slot >= a.n) return;
     const long long b = a.order ? (long long)uni(a.order[slot]) : slot;
@@ -708,9 +936,9 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) void k4_decode_pair_kern
     }
 }
 
-/* diagnostic twin of the pair kernel: counters [0..7] by the parsing wave (total, windows, deriving, waiting for a free
- * slot; batches, windows, -, sequences parsed one at a time), [8..14] by the copying wave (total, waiting for a batch,
- * literals, matches; batches, dependency rounds, sequences) */
+/* diagnostic twin of the pair kernel (K4LZ4_PROF_PAIR=1 + k4lz4_profile_batch_device): counters [0..7] by the parsing wave
+ * (total, windows, deriving, waiting for a free slot; batches, windows, -, sequences parsed one at a time), [8..14] by the
+ * copying wave (total, waiting for a batch, literals, matches; batches, dependency rounds, sequences) */
 __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) void k4_decode_pair_prof_kernel(BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
@@ -718,11 +946,11 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) void k4_decode_pair_prof
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t pair = wave >> 1, role = (wave ^ blockIdx.x) & 1u;
     const long long slot = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
-    uint32_t *ring = lds[pair], *pipe = lds[pair] + PARSE_LDS_DWORDS;
-    if (lane < 8 && role == 0) pipe[lane] = 0u;
+    uint32_t *ring = lds[pair], *pipe = lds[pair] + PAIR_PARSE_DWORDS;
+    if (lane < 8 && role == 0) pipe[lane] = pair_queue_word(a.gq, slot, lane);
     __syncthreads();
     if (slot >= a.n) return;
-    const long long b = a.order ? (long long)uni(a.order[slot]) : slot;
+    const long long b = slot;
     const int src_len = a.srcLen[b];
     const int cap = a.dstCap[b];
     const uint8_t *in = a.src + a.srcOff[b];
