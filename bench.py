@@ -249,9 +249,9 @@ def main():
         alg_bytes = sum_u + sum_c + 12 * n          # U read + C written (+12 B metadata) per block
         enc_avg, dec_avg = float(enc_ms.mean()), float(dec_ms.mean())
 
-        # HBM traffic per launch: rocprofv3 PMC passes (scripts/pmc_round.sh: FETCH_SIZE and WRITE_SIZE in separate passes,
-        # KiB -> bytes, scaled by factors measured in the same session on kernels of known byte counts in these access
-        # patterns, scripts/ubench/pmc_calib.hip).  The file names the kernel sources it was measured on; figures from other
+        # HBM traffic per launch: rocprofv3 PMC passes (scripts/pmc_round.sh: the L2's DRAM read and write requests in 32-byte units,
+        # separate passes; the same two counters reproduce the known byte counts of scripts/ubench/pmc_calib.hip exactly, which
+        # FETCH_SIZE / WRITE_SIZE do not).  The file names the kernel sources it was measured on; figures from other
         # sources (or for another workload) are not reported: traffic = null.
         traffic = {}
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -17,6 +17,13 @@ run sq2 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_ACTIVE_
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run grbm GRBM_GUI_ACTIVE
+# the L2's requests to DRAM counted in 32-byte units: on the calibration kernels these two reproduce the known byte counts
+# exactly (1 GiB streamed = 33 554 768 x 32 B read, 33 554 432 x 32 B written; a scattered 16-byte read costs a 128-byte
+# line, a scattered 2-byte write a 32-byte sector), which FETCH_SIZE / WRITE_SIZE do not
+run dramrd TCC_EA0_RDREQ_DRAM_32B_sum
+run dramwr TCC_EA0_WRREQ_WRITE_DRAM_32B_sum
+cal caldramrd TCC_EA0_RDREQ_DRAM_32B_sum
+cal caldramwr TCC_EA0_WRREQ_WRITE_DRAM_32B_sum
 cal calfetch FETCH_SIZE
 cal calwrite WRITE_SIZE
 cd $GRAFT_REPO_ROOT

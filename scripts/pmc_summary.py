@@ -46,24 +46,37 @@ def per_kernel(kind, counter, prefix):
 
 
 GiB = float(1 << 30)
-known = {"calib_stream_read16": GiB, "calib_scatter_read16": GiB / 4 * 4, "calib_stream_write16": GiB, "calib_scatter_write2": GiB / 4 * 4}
-useful = {"calib_stream_read16": GiB, "calib_scatter_read16": GiB / 4, "calib_stream_write16": GiB, "calib_scatter_write2": GiB / 64 / 2}
-cal_f, cal_w = per_kernel("calfetch", "FETCH_SIZE", "calib_"), per_kernel("calwrite", "WRITE_SIZE", "calib_")
-factors = {}
-for k, v in list(cal_f.items()) + list(cal_w.items()):
-    if v > 0 and k in known and ("read" in k) == (k in cal_f):
-        factors[k] = round(known[k] / v, 4)      # real bytes moved (whole 64 B lines for the scattered kernels) per reported byte
-print("calibration: reported bytes", {k: int(v) for k, v in {**cal_f, **cal_w}.items()}, "-> factors (line bytes / reported)", factors)
-fetch, write = per_kernel("fetch", "FETCH_SIZE", "k4::"), per_kernel("write", "WRITE_SIZE", "k4::")
-f_stream, f_scatter = factors.get("calib_stream_read16", 1.0), factors.get("calib_scatter_read16", 1.0)
-w_stream, w_scatter = factors.get("calib_stream_write16", 1.0), factors.get("calib_scatter_write2", 1.0)
-out = {}
-for k in set(fetch) | set(write):
-    scattered = k == "k4_encode_fast_gtab_kernel"      # 2-byte table accesses, a line each; everything else moves 16 B pieces
-    out[k] = int(fetch.get(k, 0.0) * (f_scatter if scattered else f_stream) + write.get(k, 0.0) * (w_scatter if scattered else w_stream))
+
+
+def per_kernel_raw(kind, counter, prefix):
+    return {k: v / 1024.0 for k, v in per_kernel(kind, counter, prefix).items()}     # (per_kernel scales KiB counters by 1024)
+
+
+# what the calibration kernels are known to move: bytes read / written per launch, counting what a scattered access really
+# costs at the memory side (a 128-byte line per 16-byte read, a 32-byte sector per 2-byte write)
+known_rd = {"calib_stream_read16": GiB, "calib_scatter_read16": GiB / 4 / 16 * 128}
+known_wr = {"calib_stream_write16": GiB, "calib_scatter_write2": GiB / 4 / 16 * 32}
+cal_rd = per_kernel_raw("caldramrd", "TCC_EA0_RDREQ_DRAM_32B_sum", "calib_")
+cal_wr = per_kernel_raw("caldramwr", "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", "calib_")
+check = {}
+for k, want in known_rd.items():
+    if cal_rd.get(k):
+        check[k] = round(32.0 * cal_rd[k] / want, 4)
+for k, want in known_wr.items():
+    if cal_wr.get(k):
+        check[k] = round(32.0 * cal_wr[k] / want, 4)
+print("calibration (32 B x DRAM request counters / known bytes, 1.0 = exact):", check)
+cal_fetch, cal_write = per_kernel("calfetch", "FETCH_SIZE", "calib_"), per_kernel("calwrite", "WRITE_SIZE", "calib_")
+print("for comparison, FETCH_SIZE / WRITE_SIZE on the same kernels (reported bytes / known bytes):",
+      {k: round(cal_fetch[k] / known_rd[k], 3) for k in known_rd if cal_fetch.get(k)},
+      {k: round(cal_write[k] / known_wr[k], 3) for k in known_wr if cal_write.get(k)})
+rd = per_kernel_raw("dramrd", "TCC_EA0_RDREQ_DRAM_32B_sum", "k4::")
+wr = per_kernel_raw("dramwr", "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", "k4::")
+out = {k: int(32.0 * (rd.get(k, 0.0) + wr.get(k, 0.0))) for k in set(rd) | set(wr)}
 if out:
-    doc = {"source_sha": source_hash(), "calibration_factors": factors,
-           "raw_reported_bytes": {"fetch": {k: int(v) for k, v in fetch.items()}, "write": {k: int(v) for k, v in write.items()}},
+    doc = {"source_sha": source_hash(), "counters": "32 B x (TCC_EA0_RDREQ_DRAM_32B_sum + TCC_EA0_WRREQ_WRITE_DRAM_32B_sum), separate passes",
+           "calibration_vs_known_bytes": check,
+           "read_bytes_per_launch": {k: int(32.0 * v) for k, v in rd.items()}, "write_bytes_per_launch": {k: int(32.0 * v) for k, v in wr.items()},
            "traffic_bytes_per_launch": out}
     print("traffic bytes per launch:", out)
     if len(sys.argv) > 2:
