@@ -86,9 +86,16 @@ __device__ __forceinline__ uint32_t wave_count(const uint8_t *a, const uint8_t *
     }
 }
 
-constexpr int ENCODE_SCRATCH_BYTES = 1024;     /* same-hash detection: one bit per hash value (8192 of them) */
-constexpr int ENCODE_SCRATCH_BYTES_GTAB = 1024;
-constexpr int ENCODE_LDS_DWORDS = 4096 + ENCODE_SCRATCH_BYTES / 4;   /* hash table + detection slots */
+constexpr int ENCODE_SCRATCH_BYTES = 512;      /* same-hash detection: 4096 bits, one per hash value (per two of the byU16 table's) */
+/* Sequences found but not written out yet, 8 bytes each: position; offset (16 bits), what is known about the bytes
+ * before position and match (4 bits), match length code (12 bits; REC_CODE_MAX = "this or more", counted again when it
+ * is written out).  A round finds ~8 on text, at most 16; they are written out a wave-full at a time, one per lane,
+ * instead of by the ~8 lanes that found them. */
+constexpr int ENCODE_REC_SLOTS = 64;
+constexpr int ENCODE_REC_DWORDS = 2 * ENCODE_REC_SLOTS;
+constexpr uint32_t REC_CODE_MAX = 4095u;
+constexpr int ENCODE_STAGE_DWORDS = ENCODE_SCRATCH_BYTES / 4 + ENCODE_REC_DWORDS;   /* what every encoder wave needs besides its table */
+constexpr int ENCODE_LDS_DWORDS = 4096 + ENCODE_STAGE_DWORDS;                       /* hash table + the above */
 
 /* length field tail: `rem` encoded as 255-run + final byte (LL64.fast.cs:262-272,:365-381,:484-495) */
 __device__ __forceinline__ void emit_length_run(uint8_t *dst, uint32_t op, uint32_t rem, int lane)
@@ -231,6 +238,9 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
     uint32_t *const tabmem = gtab ? gtab : ldsw;
     tab.t = (decltype(tab.t))tabmem;
     uint32_t *const seen = gtab ? ldsw : ldsw + 4096;       /* bit h: a lane of the current window hashed to h */
+    uint2 *const rec = (uint2 *)(seen + ENCODE_SCRATCH_BYTES / 4);        /* the pending sequences */
+    constexpr uint32_t REC_SLOTS = (uint32_t)ENCODE_REC_SLOTS, REC_FLUSH_AT = REC_SLOTS - 16u;
+    constexpr uint32_t SEEN_SHIFT = BYU16 ? 1u : 0u;        /* hash value -> bit of `seen` */
     const unsigned long long me = 1ull << lane, below_me = me - 1ull;
 
     for (int k = lane; k < 1024; k += 64) ((uint4 *)tabmem)[k] = make_uint4(0u, 0u, 0u, 0u);
@@ -239,6 +249,89 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
 
     uint32_t anchor = 0;
     uint32_t op = 0;
+    uint32_t rec_head = 0, rec_count = 0;      /* the pending sequences: ring slots rec_head .. rec_head + rec_count - 1 */
+    uint32_t emitted_to = 0;                   /* end of the last sequence written out = start of the next one's literals */
+
+    /* ---- write out up to 64 pending sequences, one per lane (:237-382).  The literal run of a sequence starts where the
+     * one before it ended; backward extension (:237-242) from the 4 bytes the finding lane knew, the rare longer one
+     * counted here.  Returns false when the output does not fit (:251-255, :346-350). */
+    auto flush = [&]() -> bool {
+        const uint32_t n = rec_count < 64u ? rec_count : 64u;
+        lds_sync();
+        const bool mine = (uint32_t)lane < n;
+        const uint32_t slot = (rec_head + (uint32_t)lane) & (REC_SLOTS - 1u);
+        const uint2 r = rec[slot];
+        const uint32_t pos = r.x, cpos = r.x - (r.y & 0xffffu), binfo = (r.y >> 16) & 15u;
+        uint32_t code = r.y >> 20;
+        unsigned long long longer = __ballot(mine && code == REC_CODE_MAX);     /* :326-329 once more, from where the record stops */
+        while (longer) {
+            const int g = ctz64(longer);
+            longer &= longer - 1ull;
+            const uint32_t p = readlane_u32(pos, g) + MINMATCH, m = readlane_u32(cpos, g) + MINMATCH;
+            const uint32_t c = REC_CODE_MAX + wave_count(src + p + REC_CODE_MAX, src + m + REC_CODE_MAX, U - LASTLITERALS - p - REC_CODE_MAX, lane);
+            if (lane == g) code = c;
+        }
+        const uint32_t end = mine ? pos + MINMATCH + code : 0u;
+        const uint32_t prev = (uint32_t)__shfl_up((int)end, 1);
+        const uint32_t ls = lane == 0 ? emitted_to : prev;
+        const uint32_t lit0 = mine ? pos - ls : 0u;
+        const uint32_t maxback = lit0 < cpos ? lit0 : cpos;                /* 0 right after a match */
+        const uint32_t nb = binfo & 7u;
+        uint32_t back = nb < maxback ? nb : maxback;
+        unsigned long long slow = __ballot(mine && (!(binfo & 8u) || nb == 4u) && back < maxback);
+        while (slow) {
+            const int g = ctz64(slow);
+            slow &= slow - 1ull;
+            const uint32_t p = readlane_u32(pos, g), match = readlane_u32(cpos, g), mb = readlane_u32(maxback, g);
+            uint32_t b = readlane_u32(back, g);
+            while (b < mb) {
+                const uint32_t i = b + (uint32_t)lane;
+                const bool eq = i < mb && src[p - 1u - i] == src[match - 1u - i];
+                const unsigned long long ne2 = ~__ballot(eq);
+                const int run = ne2 ? ctz64(ne2) : 64;
+                b += (uint32_t)run;
+                if (run < 64) break;
+            }
+            if (lane == g) back = b;
+        }
+        const uint32_t ll = lit0 - back, mc = mine ? code + back : 0u;
+        const bool short_run = mine && ll != 0u && ll <= LANE_COPY_MAX;
+        const uint32_t lx = ll >= (uint32_t)RUN_MASK ? (ll - RUN_MASK) / 255u + 1u : 0u;
+        const uint32_t mx = mc >= (uint32_t)ML_MASK ? (mc - ML_MASK) / 255u + 1u : 0u;
+        const uint32_t sz = mine ? 1u + lx + ll + 2u + mx : 0u;
+        const uint32_t incl = wave_inclusive_scan(sz);
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        const uint32_t o_tok = op + incl - sz;
+        const uint32_t o_lit = o_tok + 1u + lx, o_off = o_lit + ll, o_mx = o_off + 2u;
+        if (limited) {                                      /* :251-255, :346-350 */
+            const bool fail = mine && ((uint64_t)o_tok + 1u + ll + (2 + 1 + LASTLITERALS) + ll / 255u > olimit ||
+                                       (uint64_t)o_mx + (1 + LASTLITERALS) + (mc + 240u) / 255u > olimit);
+            if (__ballot(fail)) return false;
+        }
+        if (mine) {
+            dst[o_tok] = (uint8_t)(((ll < (uint32_t)RUN_MASK ? ll : (uint32_t)RUN_MASK) << ML_BITS) |
+                                   (mc < (uint32_t)ML_MASK ? mc : (uint32_t)ML_MASK));
+            if (lx == 1u) dst[o_tok + 1u] = (uint8_t)(ll - RUN_MASK);
+            ((U16u *)(dst + o_off))->v = (uint16_t)(pos - cpos);   /* :299-304 */
+            if (mx == 1u) dst[o_mx] = (uint8_t)(mc - ML_MASK);
+        }
+        if (short_run) lane_copy32(dst + o_lit, src + ls, ll, U - ls);
+        unsigned long long big = __ballot(mine && (ll > LANE_COPY_MAX || lx > 1u || mx > 1u));
+        while (big) {
+            const int g = ctz64(big);
+            big &= big - 1ull;
+            const uint32_t g_ll = readlane_u32(ll, g), g_mc = readlane_u32(mc, g);
+            const uint32_t g_tok = readlane_u32(o_tok, g);
+            if (g_ll >= (uint32_t)RUN_MASK + 255u) emit_length_run(dst, g_tok + 1u, g_ll - RUN_MASK, lane);
+            if (g_ll > LANE_COPY_MAX) wave_copy(dst + readlane_u32(o_lit, g), src + readlane_u32(ls, g), g_ll, lane);
+            if (g_mc >= (uint32_t)ML_MASK + 255u) emit_length_run(dst, readlane_u32(o_mx, g), g_mc - ML_MASK, lane);
+        }
+        op += total;
+        emitted_to = readlane_u32(end, (int)n - 1);
+        rec_head += n;
+        rec_count -= n;
+        return true;
+    };
 
     if (src_len >= MFLIMIT + 1) {                                   /* :117 */
         const uint32_t mflimit_plus_one = U - MFLIMIT + 1;
@@ -301,7 +394,8 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             if (valid) {
                 h = Table::hash_of(pa.seq, pa.n0);
                 cand = tab.get(h);
-                flagged = ((atomicOr(&seen[h >> 5], 1u << (h & 31u)) >> (h & 31u)) & 1u) != 0u;
+                const uint32_t bit = h >> SEEN_SHIFT;       /* two hash values may share a bit: the groups below compare the hashes */
+                flagged = ((atomicOr(&seen[bit >> 5], 1u << (bit & 31u)) >> (bit & 31u)) & 1u) != 0u;
             }
             const Around ca = load_around(src, cand);       /* the round's one dependent trip to memory: everything below that
                                                              * does not need the candidate bytes runs while it is under way */
@@ -310,7 +404,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             unsigned long long G = me;
             {
                 unsigned long long fl = __ballot(flagged);
-                if (valid) seen[h >> 5] = 0u;      /* every lane has recorded its hash by now: wipe the words this window touched */
+                if (valid) seen[h >> (5u + SEEN_SHIFT)] = 0u;      /* every lane has recorded its hash by now: wipe the words this window touched */
                 while (fl) {
                     const int j = ctz64(fl);
                     const uint32_t hj = __builtin_amdgcn_readlane(h, j);
@@ -326,7 +420,6 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             const unsigned long long t1 = prof_now<PROF>();
             const unsigned long long inv_m = __ballot(!valid), preok_m = __ballot(pa.pre_ok);
             const uint32_t fwd_max = matchlimit - (pos + MINMATCH);
-            const uint32_t anchor_in = anchor;
             /* the common group is a pair: the later lane's candidate is the earlier lane while that one counts
              * as visited, else the table entry -- both known up front, so losing a candidate is a select */
             const unsigned long long gb = G & below_me;
@@ -385,15 +478,13 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 cand_m = cand0 & ~lost_cands;
                 hopv = hop_word(c8, counted ? 0u : (cinfo & 0x100u));
             };
-            /* from the hits so far: the lanes inside their matches (never visited) and the lanes right after them */
-            unsigned long long cursors = 1;
+            /* from the hits so far: the lanes inside their matches (never visited) */
             auto derive = [&](unsigned long long hits_now) {
                 const unsigned long long hb = hits_now & below_me;
                 const int ph = hb ? 63 - (int)__clzll((long long)hb) : 0;
                 const uint32_t qp = (uint32_t)__shfl((int)hopv, ph) & 127u;       /* lane after the match of the hit below */
                 const bool in = hb != 0ull && (uint32_t)lane < qp;
                 skipped = __ballot(in && (uint32_t)lane + 2u != qp);
-                cursors = 1ull | __ballot(hb != 0ull && (uint32_t)lane == qp);
             };
             bool general = false;
             if (dirty) {
@@ -490,36 +581,16 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             }
             prepare();                                      /* also when the block ends here: every lane is invalid then and reads offset 0 */
 
-            /* per hit lane: literal run, backward extension (:237-242), the sequence's numbers */
+            /* the k sequences of this round join the pending ones */
             const bool mine = ((hits >> lane) & 1ull) != 0ull;
-            uint32_t r_ls = 0, r_ll = 0, r_off = 0, r_mc = 0, r_cq = 0, r_back = 0;
-            if (k) {
-                const unsigned long long cb = cursors & (below_me | me);                   /* bit 0 is always set */
-                const uint32_t cq = 63u - (uint32_t)__clzll((long long)cb);
-                const uint32_t anchor_l = cq == 0u ? anchor_in : ip0 + cq;
-                const uint32_t lit0 = pos - anchor_l;
-                const uint32_t maxback = lit0 < cpos ? lit0 : cpos;               /* 0 right after a match */
-                const uint32_t nb = (cinfo >> 4) & 7u;
-                uint32_t back = nb < maxback ? nb : maxback;
-                unsigned long long slow = __ballot(mine && (!(cinfo & 0x200u) || nb == 4u) && back < maxback);
-                while (slow) {
-                    const int g = ctz64(slow);
-                    slow &= slow - 1ull;
-                    if (PROF) n_rt3++;
-                    const uint32_t p = readlane_u32(pos, g), match = readlane_u32(cpos, g), mb = readlane_u32(maxback, g);
-                    uint32_t b = readlane_u32(back, g);
-                    while (b < mb) {
-                        const uint32_t i = b + (uint32_t)lane;
-                        const bool eq = i < mb && src[p - 1u - i] == src[match - 1u - i];
-                        const unsigned long long ne2 = ~__ballot(eq);
-                        const int run = ne2 ? ctz64(ne2) : 64;
-                        b += (uint32_t)run;
-                        if (run < 64) break;
-                    }
-                    if (lane == g) back = b;
+            if (k && !dry) {
+                if (mine) {
+                    const uint32_t slot = (rec_head + rec_count + (uint32_t)__popcll(hits & below_me)) & (REC_SLOTS - 1u);
+                    const uint32_t code = xcode != 0xffffffffu ? xcode : (cinfo & 15u);
+                    const uint32_t binfo = ((cinfo >> 4) & 7u) | ((cinfo & 0x200u) ? 8u : 0u);
+                    rec[slot] = make_uint2(pos, (pos - cpos) | (binfo << 16) | ((code < REC_CODE_MAX ? code : REC_CODE_MAX) << 20));
                 }
-                const uint32_t code = xcode != 0xffffffffu ? xcode : (cinfo & 15u);
-                r_ls = anchor_l; r_ll = lit0 - back; r_off = pos - cpos; r_mc = code + back; r_cq = cq; r_back = back;
+                rec_count += k;
             }
             /* ---------------- commit the visited positions, one writer per hash ---------------- */
             const unsigned long long t2 = prof_now<PROF>();
@@ -527,70 +598,18 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             if (outcome != 2) {
                 if (((I >> lane) & 1ull) && (G & I & ~(below_me | me)) == 0ull) tab.put(h, pos);
             }
+            __builtin_amdgcn_wave_barrier();    /* the next round's put of ip - 2 may hit one of these slots and comes second (a wave's
+                                                 * LDS accesses execute in program order; this keeps the compiler to it) */
 
-            /* ---------------- emit the k sequences (:244-382) ---------------- */
-            if (k) {
-                const uint32_t ll = mine ? r_ll : 0u, mc = mine ? r_mc : 0u;
-                const uint32_t lx = ll >= (uint32_t)RUN_MASK ? (ll - RUN_MASK) / 255u + 1u : 0u;
-                const uint32_t mx = mc >= (uint32_t)ML_MASK ? (mc - ML_MASK) / 255u + 1u : 0u;
-                const uint32_t sz = mine ? 1u + lx + ll + 2u + mx : 0u;
-                const uint32_t incl = wave_inclusive_scan(sz);
-                const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-                const uint32_t o_tok = op + incl - sz;
-                const uint32_t o_lit = o_tok + 1u + lx, o_off = o_lit + ll, o_mx = o_off + 2u;
-                if (limited) {                                      /* :251-255, :346-350 */
-                    const bool fail = mine && ((uint64_t)o_tok + 1u + ll + (2 + 1 + LASTLITERALS) + ll / 255u > olimit ||
-                                               (uint64_t)o_mx + (1 + LASTLITERALS) + (mc + 240u) / 255u > olimit);
-                    if (__ballot(fail)) return 0;
-                }
-                if (!dry) {
-                    if (mine) {
-                        dst[o_tok] = (uint8_t)(((ll < (uint32_t)RUN_MASK ? ll : (uint32_t)RUN_MASK) << ML_BITS) |
-                                               (mc < (uint32_t)ML_MASK ? mc : (uint32_t)ML_MASK));
-                        if (lx == 1u) dst[o_tok + 1u] = (uint8_t)(ll - RUN_MASK);
-                        ((U16u *)(dst + o_off))->v = (uint16_t)r_off;   /* :299-304 */
-                        if (mx == 1u) dst[o_mx] = (uint8_t)(mc - ML_MASK);
-                    }
-                    unsigned long long big;
-                    if (contig) {
-                        /* literals: lane l holds source byte ip0 + l, so every literal position of the window
-                         * stores its own byte; it belongs to the first sequence that hits at or above l */
-                        const unsigned long long hg = hits & ~below_me;
-                        const int nh = hg ? ctz64(hg) : 0;
-                        const uint32_t pk = (uint32_t)__shfl((int)(r_cq | ((r_back < 64u ? r_back : 64u) << 8)), nh);
-                        const uint32_t ol = (uint32_t)__shfl((int)o_lit, nh);
-                        const int c = (int)(pk & 0xffu), b = (int)(pk >> 8);
-                        const uint32_t n_pre = ip0 - anchor_in;     /* literals pending from before the window */
-                        if (hg != 0ull && lane >= c && lane < nh - b)
-                            dst[ol + (uint32_t)(lane - c) + (c == 0 ? n_pre : 0u)] = (uint8_t)pa.seq;
-                        if (n_pre) {
-                            const int f0 = ctz64(hits);
-                            const uint32_t l0 = readlane_u32(ll, f0);
-                            wave_copy(dst + readlane_u32(o_lit, f0), src + anchor_in, l0 < n_pre ? l0 : n_pre, lane);
-                        }
-                        big = __ballot(mine && (lx > 1u || mx > 1u));
-                    } else {
-                        if (mine && ll != 0u && ll <= LANE_COPY_MAX) lane_copy32(dst + o_lit, src + r_ls, ll, U - r_ls);
-                        big = __ballot(mine && (ll > LANE_COPY_MAX || lx > 1u || mx > 1u));
-                    }
-                    while (big) {
-                        const int g = ctz64(big);
-                        big &= big - 1ull;
-                        const uint32_t g_ll = readlane_u32(ll, g), g_mc = readlane_u32(mc, g);
-                        const uint32_t g_tok = readlane_u32(o_tok, g);
-                        if (g_ll >= (uint32_t)RUN_MASK + 255u) emit_length_run(dst, g_tok + 1u, g_ll - RUN_MASK, lane);
-                        if (!contig && g_ll > LANE_COPY_MAX)
-                            wave_copy(dst + readlane_u32(o_lit, g), src + readlane_u32(r_ls, g), g_ll, lane);
-                        if (g_mc >= (uint32_t)ML_MASK + 255u) emit_length_run(dst, readlane_u32(o_mx, g), g_mc - ML_MASK, lane);
-                    }
-                }
-                op += total;
-            }
+            /* ---------------- write sequences out once a wave-full of them is pending (:244-382) ---------------- */
+            if (rec_count >= REC_FLUSH_AT && !flush()) return 0;
             if (PROF) { const unsigned long long t3 = prof_now<PROF>(); c_probe += t1 - t0; c_ext += t2 - t1; c_emit += t3 - t2; }
 
             if (outcome == 2) break;
         }
     }
+
+    while (rec_count) if (!flush()) return 0;
 
     /* ---- _last_literals (:469-503) ---- */
     {
@@ -717,7 +736,7 @@ __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) void k4_encode_fast_kerne
  * below that line; one register more costs 20 % of the batch rate (measured). */
 __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void k4_encode_fast_gtab_kernel(BatchArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t stages[ENCODE_WAVES_PER_WG][ENCODE_SCRATCH_BYTES_GTAB / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t stages[ENCODE_WAVES_PER_WG][ENCODE_STAGE_DWORDS];
     const int lane = lane_id();
     const uint32_t wave = uni(threadIdx.x >> 6);
     const long long slot = (long long)blockIdx.x * ENCODE_WAVES_PER_WG + (long long)wave;
