@@ -182,6 +182,80 @@ __device__ __forceinline__ void hop_chain(unsigned long long hmx, uint32_t hopv,
 #endif
 }
 
+/* The same chain with the one thing that used to interrupt it most done on the way: when a match covers lanes that later
+ * lanes count on as candidates (flag 0x400 and no other), those later lanes fall back to their table candidates -- the
+ * second word every lane at or above the cursor has ready (hopB, hit mask hmB) replaces the first in place.  `lostC` collects the lanes such
+ * matches covered; `j1c` = 63 - the lane's candidate lane (63 - the lane itself where it has none, a lane the cursor has
+ * not passed is never covered). */
+__device__ __forceinline__ void hop_chain_pairs(unsigned long long &hmx, unsigned long long hmB, uint32_t &hopv, uint32_t hopB, uint32_t j1c,
+                                                unsigned long long &lostC, uint32_t &q, unsigned long long &hits, int &f,
+                                                uint32_t &hv, unsigned long long &stop)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t t;
+    unsigned long long sk, t2, vt;
+    asm volatile(
+        "s_lshl_b64 %[stop], -1, %[q]\n\t"
+        "s_and_b64 %[stop], %[stop], %[hmx]\n\t"
+        "s_cbranch_scc0 .Lh2_end%=\n"
+        ".Lh2_next%=:\n\t"
+        "s_ff1_i32_b64 %[f], %[stop]\n\t"
+        "v_readlane_b32 %[hv], %[hopv], %[f]\n\t"
+        "s_bitset1_b64 %[hits], %[f]\n\t"
+        "s_and_b32 %[t], %[hv], 0xf40\n\t"
+        "s_cbranch_scc1 .Lh2_special%=\n"
+        ".Lh2_cont%=:\n\t"
+        "s_and_b32 %[q], %[hv], 63\n\t"
+        "s_lshl_b64 %[stop], -1, %[q]\n\t"
+        "s_and_b64 %[stop], %[stop], %[hmx]\n\t"
+        "s_cbranch_scc1 .Lh2_next%=\n\t"
+        "s_branch .Lh2_end%=\n"
+        ".Lh2_special%=:\n\t"
+        "s_cmpk_lg_u32 %[t], 0x400\n\t"
+        "s_cbranch_scc1 .Lh2_end%=\n\t"
+        "s_and_b32 %[q], %[hv], 63\n\t"
+        "s_lshl_b64 %[sk], -2, %[f]\n\t"
+        "s_lshl_b64 %[t2], -1, %[q]\n\t"
+        "s_andn2_b64 %[sk], %[sk], %[t2]\n\t"
+        "s_sub_u32 %[t], %[q], 2\n\t"
+        "s_bitset0_b64 %[sk], %[t]\n\t"
+        "s_or_b64 %[lostC], %[lostC], %[sk]\n\t"
+        "v_lshlrev_b64 %[vt], %[j1c], %[lostC]\n\t"
+        "v_cmp_gt_i64_e64 %[t2], 0, %[vt]\n\t"
+        "s_xor_b64 %[sk], %[hmx], %[hmB]\n\t"
+        "s_and_b64 %[sk], %[sk], %[t2]\n\t"
+        "s_xor_b64 %[hmx], %[hmx], %[sk]\n\t"
+        "s_lshl_b64 %[sk], -1, %[q]\n\t"
+        "s_and_b64 %[t2], %[t2], %[sk]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e64 %[hopv], %[hopv], %[hopB], %[t2]\n\t"
+        "s_branch .Lh2_cont%=\n"
+        ".Lh2_end%=:"
+        : [stop] "=&s"(stop), [q] "+s"(q), [hits] "+s"(hits), [f] "+s"(f), [hv] "+s"(hv), [t] "=&s"(t), [hmx] "+s"(hmx),
+          [lostC] "+s"(lostC), [hopv] "+v"(hopv), [sk] "=&s"(sk), [t2] "=&s"(t2), [vt] "=&v"(vt)
+        : [hmB] "s"(hmB), [hopB] "v"(hopB), [j1c] "v"(j1c)
+        : "scc");
+#else
+    for (;;) {
+        stop = hmx & (~0ull << q);
+        if (!stop) break;
+        f = ctz64(stop);
+        hv = readlane_u32(hopv, f);
+        hits |= 1ull << f;
+        const uint32_t t = hv & 0xf40u;
+        if (t) {
+            if (t != 0x400u) break;
+            const uint32_t qn = hv & 63u;
+            lostC |= (~1ull << f) & ~(~0ull << qn) & ~(1ull << ((qn - 2u) & 63u));
+            const unsigned long long now = __ballot((long long)(lostC << j1c) < 0);
+            hmx ^= (hmx ^ hmB) & now;
+            if (((now >> lane_id()) & 1ull) && (uint32_t)lane_id() >= qn) hopv = hopB;   /* below the cursor: final already */
+        }
+        q = hv & 63u;
+    }
+#endif
+}
+
 /*
  * LL64.LZ4_compress_generic for one block.  `ldsw`: ENCODE_LDS_DWORDS dwords of LDS owned by this
  * wave (16 KiB hash table, zeroed here = LZ4_initStream, LL.tools.cs:235-239; then the 1 KiB bit set
@@ -218,7 +292,7 @@ __device__ __forceinline__ void hop_chain(unsigned long long hmx, uint32_t hopv,
  * After 64 misses the schedule's step grows (LL64.fast.cs:156-172); those rounds probe the strided
  * positions and stop at their first sequence.
  */
-template <bool BYU16, bool PROF = false, bool X32 = false>
+template <bool BYU16, bool PROF = false, bool X32 = false, bool PAIRS = true>
 __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
                                                  uint32_t accel, uint32_t *ldsw, int lane, unsigned long long *pc = nullptr,
                                                  bool dry = false, uint32_t *seq_count = nullptr, uint32_t *gtab = nullptr)
@@ -424,7 +498,6 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
              * as visited, else the table entry -- both known up front, so losing a candidate is a select */
             const unsigned long long gb = G & below_me;
             const int j1 = gb ? 63 - (int)__clzll((long long)gb) : -1;
-            const unsigned long long multi_m = __ballot((gb & (gb - 1ull)) != 0ull);
             const unsigned long long cand0 = __ballot((G & ~(below_me | me)) != 0ull);
             /* now the candidate bytes */
             const bool hit_tab = valid && (BYU16 || cand + (uint32_t)DISTANCE_MAX >= pos) && ca.seq == pa.seq;
@@ -493,31 +566,75 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             publish();
             /* the word of a pair lane that has fallen back to its table candidate; candidate lanes lost so far.
              * (cand_m only shrinks while the round goes on: a stale one costs a needless check, never a missed one) */
-            const uint32_t hop_tab = dirty ? hop_word(info & 15u, info & 0x100u) : hopv;
+            /* A lane with ONE candidate in the window has both its words ready, so that losing the candidate is a select; a
+             * lane with several stops the chain the moment it would go by its second word (0x1000) and the candidates are
+             * then worked out in full (`general`) for the rest of the round. */
+            const bool many = (gb & (gb - 1ull)) != 0ull;
+            const uint32_t hop_tab = many ? 0x1040u : (dirty ? hop_word(info & 15u, info & 0x100u) : hopv);
+            const unsigned long long hmB = dirty ? (__ballot(hit_tab || many) | inv_m) : hmx;
+            const uint32_t j1c = 63u - (uint32_t)(j1 >= 0 ? j1 : lane);
             const unsigned long long ta = prof_now<PROF>();
             if (PROF) c_s1 += ta - t1;
             unsigned long long t_rec = 0;
             unsigned long long hits = 0;       /* lanes where a sequence's match starts (before backward extension) */
             uint32_t q = 0;                    /* lane of the cursor */
             int outcome;                       /* 0 window exhausted, 1 next round starts after a match, 2 block ends */
+            auto go_general = [&]() {
+                general = true;
+                candidates();
+                publish();
+            };
+            /* lanes f+1 .. q-1 except q-2 were never visited: a lane whose candidate is one of them falls back
+             * to the next visited lane of its group (or to the table); q-2 is the put of :394 */
+            auto lose = [&](unsigned long long sk) {
+                if (!(sk & cand_m)) return;
+                const unsigned long long tr0 = prof_now<PROF>();
+                if (PROF) n_dup++;
+                lost_cands |= sk;
+                const bool lost = (long long)(lost_cands << j1c) < 0;
+                if (general) {
+                    if (__ballot(lost) & (~0ull << q)) go_general();   /* lanes behind the cursor no longer matter */
+                } else {
+                    hmx ^= (hmx ^ hmB) & __ballot(lost);
+                    if (lost && (uint32_t)lane >= q) {              /* what the lanes below the cursor hold is final */
+                        hopv = hop_tab;
+                        chit = hit_tab;
+                        cpos = cand;
+                        cinfo = info;
+                        epos = pos + MINMATCH + (info & 15u);
+                    }
+                }
+                if (PROF) t_rec += prof_now<PROF>() - tr0;
+            };
             for (;;) {
                 /* plain hops: one readlane per sequence; everything else about the chain is derived afterwards.
                  * Lanes past the last probe position (:172) stop the chain like hits and carry flag 0x800. */
                 uint32_t hv = 0;
                 int f = 0;
                 unsigned long long stop;
-                hop_chain(hmx, hopv, q, hits, f, hv, stop);
+                if (general || !PAIRS) hop_chain(hmx, hopv, q, hits, f, hv, stop);
+                else hop_chain_pairs(hmx, hmB, hopv, hop_tab, j1c, lost_cands, q, hits, f, hv, stop);
                 if (!stop || (hv & 0x800u)) {
                     hits &= ~inv_m;
                     if (hits) anchor = ip0 + q;
                     outcome = stop ? 2 : 0;
                     break;
                 }
+                if (hv & 0x1000u) {                                 /* not a hit yet: a lane of a larger group that has lost its first candidate */
+                    hits &= ~(1ull << f);
+                    go_general();
+                    continue;
+                }
                 /* hit f needs attention before the chain can go on */
-                uint32_t e_end = readlane_u32(epos, f);
+                const uint32_t qn = hv & 127u;
+                /* a lane the chain itself has switched to its table candidate still holds the first one in cpos / epos */
+                const bool second = PAIRS && !general && ((hv & 0x100u) || qn == 127u) && (long long)(lost_cands << readlane_u32(j1c, f)) < 0;
+                uint32_t e_end = qn < 127u ? ip0 + qn
+                                           : (second ? readlane_u32(pos, f) + MINMATCH + (readlane_u32(info, f) & 15u) : readlane_u32(epos, f));
                 if (hv & 0x100u) {                                  /* :326-329 beyond the 12 known bytes */
                     if (PROF) n_rt3++;
-                    const uint32_t p = readlane_u32(pos, f), match = readlane_u32(cpos, f);
+                    const uint32_t p = readlane_u32(pos, f);
+                    const uint32_t match = second ? readlane_u32(cand, f) : readlane_u32(cpos, f);
                     const uint32_t code = 8u + wave_count(src + p + MINMATCH + 8u, src + match + MINMATCH + 8u, matchlimit - (p + MINMATCH) - 8u, lane);
                     e_end = p + MINMATCH + code;
                     const uint32_t qf = e_end - ip0;
@@ -527,31 +644,12 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 if (e_end >= mflimit_plus_one) { outcome = 2; break; }   /* :391 */
                 if (!contig || e_end - ip0 >= 64u) { outcome = 1; break; }
                 q = e_end - ip0;
-                /* lanes f+1 .. q-1 except q-2 were never visited: a lane whose candidate is one of them falls back
-                 * to the next visited lane of its group (or to the table); q-2 is the put of :394 */
-                const unsigned long long sk = (~1ull << f) & ((1ull << q) - 1ull) & ~(1ull << (q - 2u));
-                if (sk & cand_m) {
-                    const unsigned long long tr0 = prof_now<PROF>();
-                    if (PROF) n_dup++;
-                    lost_cands |= sk & cand_m;
-                    const bool lost = j1 >= 0 && ((lost_cands >> (j1 & 63)) & 1ull) != 0ull;
-                    const unsigned long long lost_m = __ballot(lost) & (~0ull << q);   /* lanes behind the cursor no longer matter */
-                    if (lost_m) {
-                        if (!general && (lost_m & multi_m)) general = true;
-                        if (general) {
-                            candidates();
-                            publish();
-                        } else if (lost && (uint32_t)lane >= q) {   /* pair: the other alternative, both known up front */
-                            chit = hit_tab;
-                            cpos = cand;
-                            cinfo = info;
-                            epos = pos + MINMATCH + (info & 15u);
-                            hopv = hop_tab;
-                        }
-                        if (!general) hmx = __ballot(chit) | inv_m;
-                    }
-                    if (PROF) t_rec += prof_now<PROF>() - tr0;
-                }
+                lose((~1ull << f) & ((1ull << q) - 1ull) & ~(1ull << (q - 2u)));
+            }
+            if (PAIRS && !general && (long long)(lost_cands << j1c) < 0) {   /* the lanes the chain switched to their table candidates, for what follows */
+                chit = hit_tab;
+                cpos = cand;
+                cinfo = info;
             }
             if (hits) derive(hits);
             const unsigned long long I = ~skipped; /* lanes whose position has been put into the table this round */
@@ -639,13 +737,14 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
 }
 
 /* LL64.LZ4_compress_fast (LL64.fast.cs:517-576): table type by input size */
+template <bool PAIRS = true>
 __device__ __forceinline__ int compress_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
                                                    int accel, uint32_t *ldsw, int lane, uint32_t *gtab = nullptr, bool x32 = false)
 {
     const uint32_t a = accel < 1 ? 1u : (accel > 65536 ? 65536u : (uint32_t)accel);
-    if (src_len < LIMIT_64K) return encode_fast_block<true>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
-    if (x32) return encode_fast_block<false, false, true>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
-    return encode_fast_block<false>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
+    if (src_len < LIMIT_64K) return encode_fast_block<true, false, false, PAIRS>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
+    if (x32) return encode_fast_block<false, false, true, PAIRS>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
+    return encode_fast_block<false, false, false, PAIRS>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
 }
 
 /* LZ4Codec.Encode mapping (LZ4Codec.cs:40-52) */
@@ -712,7 +811,7 @@ __global__ __launch_bounds__(256) void k4_order_kernel(BatchArgs a)
 }
 
 constexpr int ENCODE_WAVES_PER_WG = 2;      /* blocks per workgroup; measured 1: 53.1, 2: 54.2, 4: 54.3 GiB/s on the bench batch */
-__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) void k4_encode_fast_kernel(BatchArgs a)
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_num_vgpr(80))) void k4_encode_fast_kernel(BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tabs[ENCODE_WAVES_PER_WG][ENCODE_LDS_DWORDS];
     const int lane = lane_id();
@@ -747,8 +846,8 @@ __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_wav
     const int cap = a.dstCap[b];
     int ret = 0;
     if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
-        ret = compress_fast_block(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.accel, stage, lane,
-                                  a.gtab + 4096ull * (unsigned long long)slot, (a.flags & FLAG_X32) != 0);
+        ret = compress_fast_block<false>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.accel, stage, lane,
+                                         a.gtab + 4096ull * (unsigned long long)slot, (a.flags & FLAG_X32) != 0);
     if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
 }
 

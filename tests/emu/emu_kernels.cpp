@@ -60,6 +60,20 @@ int k4emu_encode_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t
     return 0;
 }
 
+/* the same blocks through the variant with its hash tables in (here: host) memory, 16 KiB per block */
+int k4emu_encode_gtab_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                            const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int level,
+                            int accel, int flags, int threads)
+{
+    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, accel, flags, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (n <= 0) return 0;
+    const unsigned grid = (unsigned)((n + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG);
+    std::vector<uint32_t> tables((size_t)grid * k4::ENCODE_WAVES_PER_WG * 4096u);
+    a.gtab = tables.data();
+    k4emu::launch_fn(dim3(grid), dim3(64 * k4::ENCODE_WAVES_PER_WG), [=] { k4::k4_encode_fast_gtab_kernel(a); }, threads);
+    return 0;
+}
+
 /* dispatch-order kernels: cost estimate (dry encoder run over a sample, or by length) + bucket order */
 int k4emu_order(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, long long n, int by_length,
                 uint32_t *cost, uint32_t *hist, uint32_t *order, int threads)

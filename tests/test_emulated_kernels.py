@@ -35,12 +35,14 @@ def _fixture_blocks():
     return b
 
 
-def test_encode_fast_matches_oracle(emu, oracle):
+@pytest.mark.parametrize("gtab", [False, True], ids=["lds_table", "global_table"])
+def test_encode_fast_matches_oracle(emu, oracle, gtab):
+    """both builds of the encoder: table in LDS (chain with the pair fall-back inside), table in memory (plain chain)"""
     blocks = _fixture_blocks()
     src, soff, slen = pack(blocks)
     caps = [oracle.compress_bound(b.size) for b in blocks]
     dst, doff, dcap = arena(caps)
-    out = emu.encode_batch(src, soff, slen, dst, doff, dcap)
+    out = emu.encode_batch(src, soff, slen, dst, doff, dcap, gtab=gtab)
     for i, b in enumerate(blocks):
         want = oracle.encode(b)
         if b.size == 0:
