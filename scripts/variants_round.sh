@@ -3,6 +3,7 @@
 # latency shows): encode / decode GiB/s per build, alternating, REPS times.  Usage: scripts/variants_round.sh [tag] [reps]
 TAG=${1:-var}
 REPS=${2:-2}
+SIZES=${3:-"4096 512"}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -11,7 +12,7 @@ cp $L /tmp/keep.so
 for r in $(seq $REPS); do
   for f in ab/v_*.so; do
     cp $f $L
-    for nb in 4096 512; do
+    for nb in $SIZES; do
       echo -n "$(basename $f .so) blocks=$nb " | tee -a $OUT/variants.txt
       timeout 300 python bench.py --steps 10 --warmup 2 --blocks $nb --no-cpu-baseline --no-verify --no-host-path 2>&1 | tail -1 | grep -o '"encode_GiBs_per_gpu[^,]*,[^,]*' | tee -a $OUT/variants.txt
     done
