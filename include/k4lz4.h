@@ -92,6 +92,11 @@ K4LZ4_API int k4lz4_synchronize(k4lz4_ctx *ctx, void *stream);
  * at most longestBlock bytes each only enqueue, like every other *_device call; a batch that exceeds the reservation is
  * not encoded (outLen = failure, K4LZ4_E_NOMEM at the next synchronising call).  (0, 0) removes the reservation. */
 K4LZ4_API int k4lz4_ctx_reserve_hc(k4lz4_ctx *ctx, int64_t totalSrcBytes, int32_t longestBlock);
+/* Diagnostic, no counterpart in the reference: the three serial chains of the kernels exist as hand-written scalar ISA and
+ * as C (the form the CPU wave emulator of the test suite runs).  Runs both forms on the device over `waves` x `rounds`
+ * pseudo-random well-formed inputs; mismatches[0..2] = rounds in which they disagreed (token chain of the decoder, hop
+ * chain of the fast encoder, its variant with pair fall-backs).  All zero on a healthy build. */
+K4LZ4_API int k4lz4_selftest_chains(k4lz4_ctx *ctx, int waves, int rounds, uint32_t seed, uint32_t mismatches[3]);
 
 /* LZ4Codec.MaximumOutputSize (LZ4Codec.cs:30-31) == LL.LZ4_compressBound (Engine/LL.tools.cs:38-40).
  * Pure host arithmetic. */

@@ -34,6 +34,7 @@ SYMBOLS = {
     "k4lz4_ctx_device": (C.c_int, [C.c_void_p]),
     "k4lz4_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "k4lz4_ctx_reserve_hc": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
+    "k4lz4_selftest_chains": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_uint32)]),
     "k4lz4_set_enforce32": (None, [C.c_int]),
     "k4lz4_get_enforce32": (C.c_int, []),
     "k4lz4_compress_bound": (C.c_int, [C.c_int]),

@@ -32,6 +32,7 @@
 #include "k4lz4_encode_hc.hpp"
 #include "k4lz4_frame.hpp"
 #include "k4lz4_xxh32.hpp"
+#include "k4lz4_selftest.hpp"
 
 struct k4lz4_ctx {
     int device = -1;
@@ -807,6 +808,24 @@ int k4lz4_ctx_reserve_hc(k4lz4_ctx *ctx, int64_t totalSrcBytes, int32_t longestB
     if (totalSrcBytes < 0 || longestBlock < 0) return fail(ctx, K4LZ4_E_ARG, "negative reservation");
     ctx->hc_res_total = (uint64_t)totalSrcBytes;
     ctx->hc_res_longest = (uint32_t)longestBlock;
+    return K4LZ4_OK;
+}
+
+int k4lz4_selftest_chains(k4lz4_ctx *ctx, int waves, int rounds, uint32_t seed, uint32_t mismatches[3])
+{
+    if (!ctx || !mismatches || waves <= 0 || rounds <= 0) return fail(ctx, K4LZ4_E_ARG, "selftest: bad arguments");
+    K4_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t *d_res = nullptr;
+    K4_HIP(ctx, hipMalloc((void **)&d_res, 3 * sizeof(uint32_t)));
+    hipError_t e = hipMemsetAsync(d_res, 0, 3 * sizeof(uint32_t), ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k4::k4_chain_selftest_kernel, dim3((unsigned)waves), dim3(64), 0, ctx->stream, seed, rounds, d_res);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(mismatches, d_res, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_res);
+    K4_HIP(ctx, e);
     return K4LZ4_OK;
 }
 

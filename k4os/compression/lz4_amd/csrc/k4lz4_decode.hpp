@@ -57,6 +57,17 @@ __device__ __forceinline__ uint32_t token_word(bool fast, uint32_t next, int lan
 {
     return (fast && next < 64u ? next : (0x80u | (uint32_t)lane)) | (fast ? 0x100u : 0u) | (next << 9);
 }
+__device__ __forceinline__ void follow_tokens_ref(uint32_t word, unsigned long long &T, uint32_t &idx)
+{   /* what the ISA below does, in C: the emulator build runs this, k4_chain_selftest_kernel compares the two on the GPU */
+    T = 0;
+    idx = 0;
+    while (idx < 64u) {
+        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane(word, (int)idx);
+        if (!(pk & 0x100u)) break;
+        T |= 1ull << idx;
+        idx = pk >> 9;
+    }
+}
 __device__ __forceinline__ void follow_tokens(uint32_t word, unsigned long long &T, uint32_t &idx)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -86,14 +97,7 @@ __device__ __forceinline__ void follow_tokens(uint32_t word, unsigned long long 
         idx = last;
     }
 #else
-    T = 0;
-    idx = 0;
-    while (idx < 64u) {
-        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane(word, (int)idx);
-        if (!(pk & 0x100u)) break;
-        T |= 1ull << idx;
-        idx = pk >> 9;
-    }
+    follow_tokens_ref(word, T, idx);
 #endif
 }
 

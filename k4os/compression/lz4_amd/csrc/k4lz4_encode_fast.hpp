@@ -146,6 +146,19 @@ __device__ __forceinline__ uint32_t extension_info(uint32_t a_pre, uint32_t a_n0
  * word carries one of the 0xf40 flags (hit needs attention / window left / invalid lane) or no stop is left
  * (stop == 0).  Written out in scalar ISA: the compiler's version of this two-exit uniform loop carries its exit
  * reasons in extra mask registers and takes 18 instructions and three branches per hop; this takes 9 and two. */
+__device__ __forceinline__ void hop_chain_ref(unsigned long long hmx, uint32_t hopv, uint32_t &q, unsigned long long &hits,
+                                              int &f, uint32_t &hv, unsigned long long &stop)
+{   /* what the ISA below does, in C: the emulator build runs this, k4_chain_selftest_kernel compares the two on the GPU */
+    for (;;) {
+        stop = hmx & (~0ull << q);
+        if (!stop) break;
+        f = ctz64(stop);
+        hv = readlane_u32(hopv, f);
+        hits |= 1ull << f;
+        if (hv & 0xf40u) break;
+        q = hv & 63u;
+    }
+}
 __device__ __forceinline__ void hop_chain(unsigned long long hmx, uint32_t hopv, uint32_t &q, unsigned long long &hits,
                                           int &f, uint32_t &hv, unsigned long long &stop)
 {
@@ -170,15 +183,7 @@ __device__ __forceinline__ void hop_chain(unsigned long long hmx, uint32_t hopv,
         : [hmx] "s"(hmx), [hopv] "v"(hopv)
         : "scc");
 #else
-    for (;;) {
-        stop = hmx & (~0ull << q);
-        if (!stop) break;
-        f = ctz64(stop);
-        hv = readlane_u32(hopv, f);
-        hits |= 1ull << f;
-        if (hv & 0xf40u) break;
-        q = hv & 63u;
-    }
+    hop_chain_ref(hmx, hopv, q, hits, f, hv, stop);
 #endif
 }
 
@@ -187,6 +192,28 @@ __device__ __forceinline__ void hop_chain(unsigned long long hmx, uint32_t hopv,
  * second word every lane at or above the cursor has ready (hopB, hit mask hmB) replaces the first in place.  `lostC` collects the lanes such
  * matches covered; `j1c` = 63 - the lane's candidate lane (63 - the lane itself where it has none, a lane the cursor has
  * not passed is never covered). */
+__device__ __forceinline__ void hop_chain_pairs_ref(unsigned long long &hmx, unsigned long long hmB, uint32_t &hopv, uint32_t hopB, uint32_t j1c,
+                                                    unsigned long long &lostC, uint32_t &q, unsigned long long &hits, int &f,
+                                                    uint32_t &hv, unsigned long long &stop)
+{
+    for (;;) {
+        stop = hmx & (~0ull << q);
+        if (!stop) break;
+        f = ctz64(stop);
+        hv = readlane_u32(hopv, f);
+        hits |= 1ull << f;
+        const uint32_t t = hv & 0xf40u;
+        if (t) {
+            if (t != 0x400u) break;
+            const uint32_t qn = hv & 63u;
+            lostC |= (~1ull << f) & ~(~0ull << qn) & ~(1ull << ((qn - 2u) & 63u));
+            const unsigned long long now = __ballot((long long)(lostC << j1c) < 0);
+            hmx ^= (hmx ^ hmB) & now;
+            if (((now >> lane_id()) & 1ull) && (uint32_t)lane_id() >= qn) hopv = hopB;   /* below the cursor: final already */
+        }
+        q = hv & 63u;
+    }
+}
 __device__ __forceinline__ void hop_chain_pairs(unsigned long long &hmx, unsigned long long hmB, uint32_t &hopv, uint32_t hopB, uint32_t j1c,
                                                 unsigned long long &lostC, uint32_t &q, unsigned long long &hits, int &f,
                                                 uint32_t &hv, unsigned long long &stop)
@@ -236,23 +263,7 @@ __device__ __forceinline__ void hop_chain_pairs(unsigned long long &hmx, unsigne
         : [hmB] "s"(hmB), [hopB] "v"(hopB), [j1c] "v"(j1c)
         : "scc");
 #else
-    for (;;) {
-        stop = hmx & (~0ull << q);
-        if (!stop) break;
-        f = ctz64(stop);
-        hv = readlane_u32(hopv, f);
-        hits |= 1ull << f;
-        const uint32_t t = hv & 0xf40u;
-        if (t) {
-            if (t != 0x400u) break;
-            const uint32_t qn = hv & 63u;
-            lostC |= (~1ull << f) & ~(~0ull << qn) & ~(1ull << ((qn - 2u) & 63u));
-            const unsigned long long now = __ballot((long long)(lostC << j1c) < 0);
-            hmx ^= (hmx ^ hmB) & now;
-            if (((now >> lane_id()) & 1ull) && (uint32_t)lane_id() >= qn) hopv = hopB;   /* below the cursor: final already */
-        }
-        q = hv & 63u;
-    }
+    hop_chain_pairs_ref(hmx, hmB, hopv, hopB, j1c, lostC, q, hits, f, hv, stop);
 #endif
 }
 

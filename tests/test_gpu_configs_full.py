@@ -176,3 +176,15 @@ def test_compress_hc_refuses_levels_below_3():
     assert lib.k4lz4_last_status() == _native.E_ARG
     assert lib.k4lz4_compress_hc(data.ctypes.data, dst.ctypes.data, data.size, dst.size, 3) > 0
     assert lib.k4lz4_last_status() == 0
+
+
+def test_hand_written_chains_agree_with_their_c_twins_on_the_device():
+    """follow_tokens / hop_chain / hop_chain_pairs are inline ISA; the emulator suite runs their C twins.  Both forms run
+    here on the GPU over random well-formed hop words and must agree in every output (k4_chain_selftest_kernel)."""
+    import ctypes as C
+    from k4os.compression.lz4_amd import _native
+    ctx = _native.default_context()
+    res = (C.c_uint32 * 3)()
+    for seed in (1, 2, 0xC0FFEE):
+        ctx.check(ctx.lib.k4lz4_selftest_chains(ctx.handle, 512, 200, seed, res))
+        assert list(res) == [0, 0, 0], f"ISA and C disagree (token chain, hop chain, pair chain): {list(res)}"
