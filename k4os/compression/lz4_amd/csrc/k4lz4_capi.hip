@@ -23,6 +23,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 #include "../../../../include/k4lz4.h"
@@ -73,6 +74,7 @@ struct k4lz4_ctx {
      * K4LZ4_NO_PAIR (decode with one wave per block) */
     int split_pct = -1;
     bool no_pair = false;
+    bool trace = false;         /* K4LZ4_TRACE: host-pointer calls print where their time went (stderr) */
 };
 
 /* a few helper threads for the staging copies of big host-pointer calls (memcpy between the caller's pageable memory and
@@ -446,7 +448,9 @@ Pool *pool_of(k4lz4_ctx *ctx)
 {
     if (!ctx->pool) {
         unsigned hw = std::thread::hardware_concurrency();
-        const int nthreads = (int)std::min<unsigned>(7u, hw > 2 ? hw / 2 - 1 : 0u);
+        unsigned want = 7u;
+        if (const char *e = getenv("K4LZ4_STAGE_THREADS")) want = (unsigned)std::max(0, std::min(63, atoi(e) - 1));
+        const int nthreads = (int)std::min<unsigned>(want, hw > 2 ? hw / 2 - 1 : 0u);
         ctx->pool = new (std::nothrow) Pool(nthreads);
     }
     return ctx->pool;
@@ -485,6 +489,47 @@ int staged_upload(k4lz4_ctx *ctx, uint8_t *d_dst, const uint8_t *h_src, size_t n
         K4_HIP(ctx, hipMemcpyAsync(d_dst + pos, ctx->h_in[b], len, hipMemcpyHostToDevice, st));
         K4_HIP(ctx, hipEventRecord(ctx->ev_in[b], st));
         used[b] = true;
+    }
+    return K4LZ4_OK;
+}
+
+/* The same for blocks that lie far apart in the caller's memory (compressed blocks in slots of worst-case size: the
+ * span is 1.7 times the bytes): only the blocks travel, packed next to each other at 16-byte steps -- the copy into the
+ * pinned buffer is being made anyway.  packed[i] = where block i ends up on the device (filled in here). */
+int staged_upload_packed(k4lz4_ctx *ctx, uint8_t *d_dst, const uint8_t *h_base, const uint64_t *srcOff, const int32_t *srcLen,
+                         int64_t n, uint64_t *packed, hipStream_t st)
+{
+    int rc;
+    for (int b = 0; b < 2; b++)
+        if ((rc = grow(ctx, &ctx->h_in[b], &ctx->h_in_cap[b], STAGE_CHUNK, true)) != K4LZ4_OK) return rc;
+    bool used[2] = {false, false};
+    int b = 0;
+    uint64_t base = 0;                                   /* device offset of the chunk being filled */
+    for (int64_t first = 0; first < n; b ^= 1) {
+        uint64_t fill = 0;
+        int64_t last = first;
+        for (; last < n; last++) {
+            const uint64_t len = srcLen[last] > 0 ? (((uint64_t)srcLen[last] + 15u) & ~(uint64_t)15u) : 0u;
+            if (fill + len > STAGE_CHUNK) break;
+            packed[last] = base + fill;
+            fill += len;
+        }
+        if (used[b]) K4_HIP(ctx, hipEventSynchronize(ctx->ev_in[b]));   /* the DMA out of this buffer two chunks ago */
+        uint8_t *buf = ctx->h_in[b];
+        const int64_t cnt = last - first;
+        Pool *p = pool_of(ctx);
+        const int parts = p && fill >= ((uint64_t)2 << 20) ? (int)std::min<int64_t>((int64_t)p->workers.size() + 1, cnt) : 1;
+        auto body = [&, parts](int part) {
+            const int64_t a = first + cnt * part / parts, e = first + cnt * (part + 1) / parts;
+            for (int64_t i = a; i < e; i++)
+                if (srcLen[i] > 0) memcpy(buf + (packed[i] - base), h_base + srcOff[i], (size_t)srcLen[i]);
+        };
+        if (parts <= 1) body(0); else p->parallel(parts, body);
+        if (fill) K4_HIP(ctx, hipMemcpyAsync(d_dst + base, buf, (size_t)fill, hipMemcpyHostToDevice, st));
+        K4_HIP(ctx, hipEventRecord(ctx->ev_in[b], st));
+        used[b] = true;
+        base += fill;
+        first = last;
     }
     return K4LZ4_OK;
 }
@@ -554,17 +599,27 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
     }
     if (n == 0) return K4LZ4_OK;
     K4_HIP(ctx, hipSetDevice(ctx->device));
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto lap = [&, last = tr0](const char *what) mutable {
+        if (!ctx->trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[k4lz4 trace] %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    };
 
     /* source span and compact destination layout */
     uint64_t lo = UINT64_MAX, hi = 0;
     std::vector<uint64_t> h_soff((size_t)n), h_doff((size_t)n);
     std::vector<int32_t> h_cap((size_t)n);
     uint64_t dtotal = 0;
+    uint64_t packed_bytes = 0, longest = 0;
     for (int64_t i = 0; i < n; i++) {
         const int32_t len = srcLen[i];
         if (len > 0) {
             lo = std::min(lo, srcOff[i]);
             hi = std::max(hi, srcOff[i] + (uint64_t)len);
+            packed_bytes += ((uint64_t)len + 15u) & ~(uint64_t)15u;
+            longest = std::max<uint64_t>(longest, (uint64_t)len);
         }
         h_cap[(size_t)i] = dstCap[i] < 0 ? 0 : dstCap[i];
         h_doff[(size_t)i] = dtotal;
@@ -585,7 +640,12 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
     int32_t *d_cap = d_slen + n;
     int32_t *d_out = d_cap + n;
     hipStream_t st = ctx->stream;
-    if (span && (rc = staged_upload(ctx, ctx->d_src, src + lo, span, st)) != K4LZ4_OK) return rc;
+    lap("prepare");
+    /* blocks that fill less than 7/8 of their span (and each fit a staging chunk) travel packed */
+    if (span >= 2 * STAGE_CHUNK && packed_bytes + (packed_bytes >> 3) < span && longest <= STAGE_CHUNK) {
+        if ((rc = staged_upload_packed(ctx, ctx->d_src, src, srcOff, srcLen, n, h_soff.data(), st)) != K4LZ4_OK) return rc;
+    } else if (span && (rc = staged_upload(ctx, ctx->d_src, src + lo, span, st)) != K4LZ4_OK) return rc;
+    lap("upload");
     K4_HIP(ctx, hipMemcpyAsync(d_soff, h_soff.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
     K4_HIP(ctx, hipMemcpyAsync(d_doff, h_doff.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
     K4_HIP(ctx, hipMemcpyAsync(d_slen, srcLen, (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -625,7 +685,9 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
     rc = launch(ctx, kind, ctx->d_src, d_soff, d_slen, ctx->d_dst, d_doff, d_cap, d_out, n, level, flags, st, &ddev, srcLen);
     if (rc != K4LZ4_OK) return rc;
     K4_HIP(ctx, hipMemcpyAsync(outLen, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    lap("enqueue");
     K4_HIP(ctx, hipStreamSynchronize(st));
+    lap("kernels");
     if ((rc = take_device_status(ctx)) != K4LZ4_OK) return rc;
     /* what each block produced; those bytes are packed next to each other on the device (when that saves a tenth or more of
      * the transfer) and come back through the pinned buffers in chunks cut at block boundaries; exactly outLen[i] bytes land
@@ -654,7 +716,10 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
         d_from = ctx->d_pack;
         from_off = h_poff.data();
     }
-    return staged_download(ctx, dst, dstOff, d_from, from_off, stored.data(), n, st);
+    lap("pack");
+    rc = staged_download(ctx, dst, dstOff, d_from, from_off, stored.data(), n, st);
+    lap("download");
+    return rc;
 }
 
 int run_device(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
@@ -755,6 +820,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     }
     if (const char *pct = getenv("K4LZ4_SPLIT_PCT")) { const int v = atoi(pct); ctx->split_pct = v < 1 ? 1 : (v > 100 ? 100 : v); }
     ctx->no_pair = getenv("K4LZ4_NO_PAIR") != nullptr;
+    ctx->trace = getenv("K4LZ4_TRACE") != nullptr;
     if (e != hipSuccess) { delete ctx; return hip_fail(nullptr, e, "hipStreamCreate"); }
     *out = ctx;
     return K4LZ4_OK;
