@@ -188,3 +188,26 @@ def test_hand_written_chains_agree_with_their_c_twins_on_the_device():
     for seed in (1, 2, 0xC0FFEE):
         ctx.check(ctx.lib.k4lz4_selftest_chains(ctx.handle, 512, 200, seed, res))
         assert list(res) == [0, 0, 0], f"ISA and C disagree (token chain, hop chain, pair chain): {list(res)}"
+
+
+def test_host_pointer_batches_big_enough_for_the_staged_path_round_trip(oracle):
+    """k4lz4_encode_batch / k4lz4_decode_batch on pageable host memory, 1024 x 64 KiB: the source goes up through the pinned
+    double buffers, the compressed blocks come back packed and are scattered into worst-case slots, and the decode call
+    finds them far apart there and sends only the blocks (staged_upload_packed).  Bytes against the oracle both ways."""
+    n, bs = 1024, 65536
+    blocks = corpus.silesia_like_blocks(n, bs, seed=9)
+    src = blocks.reshape(-1)
+    off = np.arange(n, dtype=np.uint64) * bs
+    lens = np.full(n, bs, np.int32)
+    caps = np.full(n, LZ4Codec.MaximumOutputSize(bs), np.int32)
+    dst, doff = make_arena(caps, fill=0xCD)
+    out = LZ4Codec.EncodeBatchPacked(src, off, lens, dst, doff, caps)
+    for i in range(0, n, 37):
+        want = oracle.encode(blocks[i])
+        assert out[i] == len(want) and dst[int(doff[i]):int(doff[i]) + out[i]].tobytes() == want, i
+        assert (dst[int(doff[i]) + out[i]:int(doff[i]) + caps[i]] == 0xCD).all(), i     # the rest of the slot is untouched
+    back, boff = make_arena(lens, fill=0xCD)
+    got = LZ4Codec.DecodeBatchPacked(dst, doff, out, back, boff, lens)
+    assert (got == bs).all()
+    for i in range(n):
+        assert np.array_equal(back[int(boff[i]):int(boff[i]) + bs], blocks[i]), i
