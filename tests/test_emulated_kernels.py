@@ -60,7 +60,9 @@ def test_encode_fast_matches_oracle(emu, oracle, gtab):
 def test_encode_fast_big_block_hash5(emu, oracle):
     """>= 65547 bytes switches to the u32 table + hash5 (LL64.fast.cs:526-544)"""
     blocks = [corpus.lorem(65547), corpus.class_bytes("samba", 200000, 5), corpus.class_bytes("mozilla", 140000, 5),
-              np.concatenate([corpus.class_bytes("dickens", 70000, 9)] * 2)]
+              np.concatenate([corpus.class_bytes("dickens", 70000, 9)] * 2),
+              # matches far longer than a pending-sequence record can say (12 bits): counted again when written out
+              np.concatenate([corpus.random_bytes(30000, 4)] * 3), corpus.repeated(7, 100000)]
     src, soff, slen = pack(blocks)
     dst, doff, dcap = arena([oracle.compress_bound(b.size) for b in blocks])
     out = emu.encode_batch(src, soff, slen, dst, doff, dcap)

@@ -176,6 +176,9 @@ def test_batch_ragged_and_empty(oracle):
     sizes = [0, 1, 5, 12, 13, 14, 100, 65535, 65536, 65546, 65547, 70000, 300000, 0, 1 << 20]
     blocks = [corpus.class_bytes(corpus.SILESIA_NAMES[i % 12], s, i) if s else np.zeros(0, np.uint8)
               for i, s in enumerate(sizes)]
+    # matches of tens of thousands of bytes, in a small-table and in two big-table blocks
+    blocks += [corpus.repeated(0x55, 65000), np.concatenate([corpus.random_bytes(30000, 4)] * 3), corpus.repeated(7, 100000)]
+    sizes = sizes + [65000, 90000, 100000]
     enc = LZ4Codec.EncodeBatch(blocks)
     for i, b in enumerate(blocks):
         assert enc[i] == (b"" if b.size == 0 else oracle.encode(b)), i
