@@ -69,6 +69,11 @@ struct k4lz4_ctx {
     uint8_t *h_out[2] = {nullptr, nullptr}; size_t h_out_cap[2] = {0, 0};
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     uint8_t *d_pack = nullptr; size_t d_pack_cap = 0;
+    /* big host-pointer calls run as two halves: the second half's bytes go up (copy queue) while the first half's kernels
+     * run, the first half's results come down while the second half's kernels run; results' sizes via a pinned array */
+    hipStream_t copyq = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_len[2] = {nullptr, nullptr};
+    uint8_t *h_len = nullptr; size_t h_len_cap = 0;
     struct Pool *pool = nullptr;
     /* diagnostic switches, read once at creation: K4LZ4_SPLIT_PCT (1..100, share of an encode batch on the LDS-table kernel),
      * K4LZ4_NO_PAIR (decode with one wave per block) */
@@ -480,7 +485,7 @@ int staged_upload(k4lz4_ctx *ctx, uint8_t *d_dst, const uint8_t *h_src, size_t n
     int rc;
     for (int b = 0; b < 2; b++)
         if ((rc = grow(ctx, &ctx->h_in[b], &ctx->h_in_cap[b], STAGE_CHUNK, true)) != K4LZ4_OK) return rc;
-    bool used[2] = {false, false};
+    bool used[2] = {true, true};            /* an earlier upload of this call may still be reading the buffers */
     int b = 0;
     for (size_t pos = 0; pos < nbytes; pos += STAGE_CHUNK, b ^= 1) {
         const size_t len = std::min(STAGE_CHUNK, nbytes - pos);
@@ -495,23 +500,23 @@ int staged_upload(k4lz4_ctx *ctx, uint8_t *d_dst, const uint8_t *h_src, size_t n
 
 /* The same for blocks that lie far apart in the caller's memory (compressed blocks in slots of worst-case size: the
  * span is 1.7 times the bytes): only the blocks travel, packed next to each other at 16-byte steps -- the copy into the
- * pinned buffer is being made anyway.  packed[i] = where block i ends up on the device (filled in here). */
+ * pinned buffer is being made anyway.  packed[i] = where block i goes on the device (ascending, 16-byte steps, given);
+ * blocks first .. last-1. */
 int staged_upload_packed(k4lz4_ctx *ctx, uint8_t *d_dst, const uint8_t *h_base, const uint64_t *srcOff, const int32_t *srcLen,
-                         int64_t n, uint64_t *packed, hipStream_t st)
+                         int64_t first_block, int64_t last_block, const uint64_t *packed, hipStream_t st)
 {
     int rc;
     for (int b = 0; b < 2; b++)
         if ((rc = grow(ctx, &ctx->h_in[b], &ctx->h_in_cap[b], STAGE_CHUNK, true)) != K4LZ4_OK) return rc;
-    bool used[2] = {false, false};
+    bool used[2] = {true, true};            /* an earlier upload of this call may still be reading the buffers */
     int b = 0;
-    uint64_t base = 0;                                   /* device offset of the chunk being filled */
-    for (int64_t first = 0; first < n; b ^= 1) {
+    for (int64_t first = first_block; first < last_block; b ^= 1) {
+        const uint64_t base = packed[first];             /* device offset of the chunk being filled */
         uint64_t fill = 0;
         int64_t last = first;
-        for (; last < n; last++) {
+        for (; last < last_block; last++) {
             const uint64_t len = srcLen[last] > 0 ? (((uint64_t)srcLen[last] + 15u) & ~(uint64_t)15u) : 0u;
             if (fill + len > STAGE_CHUNK) break;
-            packed[last] = base + fill;
             fill += len;
         }
         if (used[b]) K4_HIP(ctx, hipEventSynchronize(ctx->ev_in[b]));   /* the DMA out of this buffer two chunks ago */
@@ -528,7 +533,6 @@ int staged_upload_packed(k4lz4_ctx *ctx, uint8_t *d_dst, const uint8_t *h_base, 
         if (fill) K4_HIP(ctx, hipMemcpyAsync(d_dst + base, buf, (size_t)fill, hipMemcpyHostToDevice, st));
         K4_HIP(ctx, hipEventRecord(ctx->ev_in[b], st));
         used[b] = true;
-        base += fill;
         first = last;
     }
     return K4LZ4_OK;
@@ -613,9 +617,11 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
     std::vector<int32_t> h_cap((size_t)n);
     uint64_t dtotal = 0;
     uint64_t packed_bytes = 0, longest = 0;
+    bool ascending = true;                  /* the blocks lie one after the other in the caller's memory, in index order */
     for (int64_t i = 0; i < n; i++) {
         const int32_t len = srcLen[i];
         if (len > 0) {
+            if (hi != 0 && srcOff[i] < hi) ascending = false;
             lo = std::min(lo, srcOff[i]);
             hi = std::max(hi, srcOff[i] + (uint64_t)len);
             packed_bytes += ((uint64_t)len + 15u) & ~(uint64_t)15u;
@@ -626,26 +632,45 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
         dtotal += ((uint64_t)h_cap[(size_t)i] + 15u) & ~(uint64_t)15u;
     }
     if (lo == UINT64_MAX) { lo = 0; hi = 0; }
-    for (int64_t i = 0; i < n; i++) h_soff[(size_t)i] = srcLen[i] > 0 ? srcOff[i] - lo : 0;
     const size_t span = (size_t)(hi - lo);
+    /* blocks that fill less than 7/8 of their span (and each fit a staging chunk) travel packed */
+    const bool packed = span >= 2 * STAGE_CHUNK && packed_bytes + (packed_bytes >> 3) < span && longest <= STAGE_CHUNK;
+    {
+        uint64_t at = 0;
+        for (int64_t i = 0; i < n; i++) {
+            const uint64_t len = srcLen[i] > 0 ? (uint64_t)srcLen[i] : 0u;
+            h_soff[(size_t)i] = packed ? at : (len ? srcOff[i] - lo : 0);
+            at += (len + 15u) & ~(uint64_t)15u;
+        }
+    }
+    /* Two halves (of about equal source bytes) when the call is big: see k4lz4_ctx::copyq.  HC levels and dictionaries keep
+     * to one part (their launches size scratch and synchronise on their own). */
+    const uint64_t up_bytes = packed ? packed_bytes : (uint64_t)span;
+    const bool hc = (kind == KIND_ENCODE || kind == KIND_PICKLE) && level >= K4LZ4_L03_HC;
+    int64_t cut = n;
+    if (n >= 1024 && up_bytes >= 4 * STAGE_CHUNK && (packed || ascending) && !hc && !(hd && hd->dict)) {
+        uint64_t acc = 0;
+        for (cut = 0; cut < n && acc < up_bytes / 2; cut++) acc += srcLen[cut] > 0 ? (((uint64_t)srcLen[cut] + 15u) & ~(uint64_t)15u) : 0u;
+        if (cut < 256 || n - cut < 256) cut = n;
+    }
+    const int nparts = cut < n ? 2 : 1;
+    const int64_t part_lo[2] = {0, cut}, part_hi[2] = {cut, n};
 
-    const size_t meta_bytes = (size_t)n * (8 + 4 + 8 + 4 + 4);
+    const size_t meta_bytes = (size_t)n * (8 + 4 + 8 + 4 + 4 + 8);
     if ((rc = grow(ctx, &ctx->d_src, &ctx->d_src_cap, span + 64, false)) != K4LZ4_OK) return rc;
     if ((rc = grow(ctx, &ctx->d_dst, &ctx->d_dst_cap, (size_t)dtotal + 64, false)) != K4LZ4_OK) return rc;
     if ((rc = grow(ctx, &ctx->d_meta, &ctx->d_meta_cap, meta_bytes + 64, false)) != K4LZ4_OK) return rc;
+    if ((rc = grow(ctx, &ctx->h_len, &ctx->h_len_cap, (size_t)n * 4 + 64, true)) != K4LZ4_OK) return rc;
 
     uint64_t *d_soff = (uint64_t *)ctx->d_meta;
     uint64_t *d_doff = d_soff + n;
-    int32_t *d_slen = (int32_t *)(d_doff + n);
+    uint64_t *d_poff = d_doff + n;
+    int32_t *d_slen = (int32_t *)(d_poff + n);
     int32_t *d_cap = d_slen + n;
     int32_t *d_out = d_cap + n;
+    int32_t *h_len = (int32_t *)ctx->h_len;
     hipStream_t st = ctx->stream;
-    lap("prepare");
-    /* blocks that fill less than 7/8 of their span (and each fit a staging chunk) travel packed */
-    if (span >= 2 * STAGE_CHUNK && packed_bytes + (packed_bytes >> 3) < span && longest <= STAGE_CHUNK) {
-        if ((rc = staged_upload_packed(ctx, ctx->d_src, src, srcOff, srcLen, n, h_soff.data(), st)) != K4LZ4_OK) return rc;
-    } else if (span && (rc = staged_upload(ctx, ctx->d_src, src + lo, span, st)) != K4LZ4_OK) return rc;
-    lap("upload");
+    hipStream_t cq = nparts > 1 ? ctx->copyq : st;          /* one part: everything in order on the one queue, as ever */
     K4_HIP(ctx, hipMemcpyAsync(d_soff, h_soff.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
     K4_HIP(ctx, hipMemcpyAsync(d_doff, h_doff.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
     K4_HIP(ctx, hipMemcpyAsync(d_slen, srcLen, (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -682,44 +707,76 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
             ddev = DictArgs{base, d_dictoff, d_dictlen, d_mode};
         }
     }
-    rc = launch(ctx, kind, ctx->d_src, d_soff, d_slen, ctx->d_dst, d_doff, d_cap, d_out, n, level, flags, st, &ddev, srcLen);
-    if (rc != K4LZ4_OK) return rc;
-    K4_HIP(ctx, hipMemcpyAsync(outLen, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    lap("enqueue");
-    K4_HIP(ctx, hipStreamSynchronize(st));
-    lap("kernels");
-    if ((rc = take_device_status(ctx)) != K4LZ4_OK) return rc;
-    /* what each block produced; those bytes are packed next to each other on the device (when that saves a tenth or more of
-     * the transfer) and come back through the pinned buffers in chunks cut at block boundaries; exactly outLen[i] bytes land
-     * in each caller slot */
+    lap("prepare");
+
+    /* ---- up and launch, part by part: the host stages part 2 while part 1's kernels run ---- */
+    for (int p = 0; p < nparts; p++) {
+        const int64_t b0 = part_lo[p], b1 = part_hi[p], cnt = b1 - b0;
+        if (packed) {
+            if ((rc = staged_upload_packed(ctx, ctx->d_src, src, srcOff, srcLen, b0, b1, h_soff.data(), cq)) != K4LZ4_OK) return rc;
+        } else {
+            /* ascending blocks (or one part): this part's stretch of the span */
+            uint64_t a = UINT64_MAX, e = 0;
+            for (int64_t i = b0; i < b1; i++)
+                if (srcLen[i] > 0) { a = std::min(a, h_soff[(size_t)i]); e = std::max(e, h_soff[(size_t)i] + (uint64_t)srcLen[i]); }
+            if (nparts == 1) { a = 0; e = span; }
+            if (a != UINT64_MAX && e > a && (rc = staged_upload(ctx, ctx->d_src + a, src + lo + a, (size_t)(e - a), cq)) != K4LZ4_OK) return rc;
+        }
+        if (cq != st) {
+            K4_HIP(ctx, hipEventRecord(ctx->ev_up[p], cq));
+            K4_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_up[p], 0));
+        }
+        DictArgs dpart = ddev;
+        rc = launch(ctx, kind, ctx->d_src, d_soff + b0, d_slen + b0, ctx->d_dst, d_doff + b0, d_cap + b0, d_out + b0, cnt, level, flags, st,
+                    &dpart, srcLen + b0);
+        if (rc != K4LZ4_OK) return rc;
+        K4_HIP(ctx, hipMemcpyAsync(h_len + b0, d_out + b0, (size_t)cnt * 4, hipMemcpyDeviceToHost, st));
+        K4_HIP(ctx, hipEventRecord(ctx->ev_len[p], st));
+        lap(p == 0 ? "up+launch" : "up+launch2");
+    }
+
+    /* ---- down, part by part.  What each block produced is packed next to each other on the device (when that saves a tenth
+     * or more of the transfer) and comes back through the pinned buffers in chunks cut at block boundaries; exactly
+     * outLen[i] bytes land in each caller slot ---- */
     const bool raw_negative = (flags & K4LZ4_FLAG_ALLOW_COPY) && kind == KIND_ENCODE;
     std::vector<uint64_t> h_poff((size_t)n);
     std::vector<int32_t> stored((size_t)n);
-    uint64_t used = 0;
-    for (int64_t i = 0; i < n; i++) {
-        const int32_t got = outLen[i];
-        int32_t sv = (got < 0 && raw_negative) ? -got : got;   /* raw blocks come back as -length */
-        if (sv < 0 || sv > h_cap[(size_t)i]) sv = 0;
-        stored[(size_t)i] = sv;
-        h_poff[(size_t)i] = used;
-        used += ((uint64_t)sv + 15u) & ~(uint64_t)15u;
+    uint64_t pack_base = 0;
+    for (int p = 0; p < nparts; p++) {
+        const int64_t b0 = part_lo[p], b1 = part_hi[p], cnt = b1 - b0;
+        K4_HIP(ctx, hipEventSynchronize(ctx->ev_len[p]));
+        lap(p == 0 ? "kernels" : "kernels2");
+        memcpy(outLen + b0, h_len + b0, (size_t)cnt * 4);
+        uint64_t used = 0, cap_total = 0;
+        for (int64_t i = b0; i < b1; i++) {
+            const int32_t got = outLen[i];
+            int32_t sv = (got < 0 && raw_negative) ? -got : got;   /* raw blocks come back as -length */
+            if (sv < 0 || sv > h_cap[(size_t)i]) sv = 0;
+            stored[(size_t)i] = sv;
+            h_poff[(size_t)i] = pack_base + used;
+            used += ((uint64_t)sv + 15u) & ~(uint64_t)15u;
+            cap_total += ((uint64_t)h_cap[(size_t)i] + 15u) & ~(uint64_t)15u;
+        }
+        const uint8_t *d_from = ctx->d_dst;
+        const uint64_t *from_off = h_doff.data() + b0;
+        if (cq != st) K4_HIP(ctx, hipStreamWaitEvent(cq, ctx->ev_len[p], 0));    /* this part's kernels are through */
+        if (cnt > 1 && used + (used >> 3) < cap_total) {
+            if ((rc = grow(ctx, &ctx->d_pack, &ctx->d_pack_cap, (size_t)dtotal + 64, false)) != K4LZ4_OK) return rc;
+            K4_HIP(ctx, hipMemcpyAsync(d_poff + b0, h_poff.data() + b0, (size_t)cnt * 8, hipMemcpyHostToDevice, cq));
+            hipLaunchKernelGGL(k4::k4_compact_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, cq, ctx->d_dst, d_doff + b0, d_out + b0,
+                               ctx->d_pack, d_poff + b0, (long long)cnt, raw_negative ? 1 : 0);
+            K4_HIP(ctx, hipGetLastError());
+            d_from = ctx->d_pack;
+            from_off = h_poff.data() + b0;
+        }
+        pack_base += used;
+        rc = staged_download(ctx, dst, dstOff + b0, d_from, from_off, stored.data() + b0, cnt, cq);
+        if (rc != K4LZ4_OK) return rc;
+        lap(p == 0 ? "download" : "download2");
     }
-    const uint8_t *d_from = ctx->d_dst;
-    const uint64_t *from_off = h_doff.data();
-    if (n > 1 && used + (used >> 3) < dtotal) {
-        if ((rc = grow(ctx, &ctx->d_pack, &ctx->d_pack_cap, (size_t)used + 64, false)) != K4LZ4_OK) return rc;
-        uint64_t *d_poff = d_soff;                           /* the source offsets are no longer needed */
-        K4_HIP(ctx, hipMemcpyAsync(d_poff, h_poff.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k4::k4_compact_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ctx->d_dst, d_doff, d_out, ctx->d_pack,
-                           d_poff, (long long)n, raw_negative ? 1 : 0);
-        K4_HIP(ctx, hipGetLastError());
-        d_from = ctx->d_pack;
-        from_off = h_poff.data();
-    }
-    lap("pack");
-    rc = staged_download(ctx, dst, dstOff, d_from, from_off, stored.data(), n, st);
-    lap("download");
-    return rc;
+    K4_HIP(ctx, hipStreamSynchronize(st));
+    if (cq != st) K4_HIP(ctx, hipStreamSynchronize(cq));
+    return take_device_status(ctx);
 }
 
 int run_device(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
@@ -811,12 +868,15 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copyq, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_busy, hipEventDisableTiming);
     for (int b = 0; b < 2 && e == hipSuccess; b++) {
         e = hipEventCreateWithFlags(&ctx->ev_in[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_out[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_up[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_len[b], hipEventDisableTiming);
     }
     if (const char *pct = getenv("K4LZ4_SPLIT_PCT")) { const int v = atoi(pct); ctx->split_pct = v < 1 ? 1 : (v > 100 ? 100 : v); }
     ctx->no_pair = getenv("K4LZ4_NO_PAIR") != nullptr;
@@ -837,11 +897,15 @@ void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
     if (ctx->ev_busy) (void)hipEventDestroy(ctx->ev_busy);
     for (int b = 0; b < 2; b++) {
         if (ctx->ev_in[b]) (void)hipEventDestroy(ctx->ev_in[b]);
+        if (ctx->ev_up[b]) (void)hipEventDestroy(ctx->ev_up[b]);
+        if (ctx->ev_len[b]) (void)hipEventDestroy(ctx->ev_len[b]);
         if (ctx->ev_out[b]) (void)hipEventDestroy(ctx->ev_out[b]);
         if (ctx->h_in[b]) (void)hipHostFree(ctx->h_in[b]);
         if (ctx->h_out[b]) (void)hipHostFree(ctx->h_out[b]);
     }
     if (ctx->d_pack) (void)hipFree(ctx->d_pack);
+    if (ctx->h_len) (void)hipHostFree(ctx->h_len);
+    if (ctx->copyq) (void)hipStreamDestroy(ctx->copyq);
     delete ctx->pool;
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
     if (ctx->d_dict) (void)hipFree(ctx->d_dict);
