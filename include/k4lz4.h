@@ -29,7 +29,11 @@
  *   - Trouble that is not a property of a block's data (a decoder wave pair timing out on its partner,
  *     an HC scratch reservation that was too small) is never reported through outLen alone: the blocks
  *     concerned say "failed" AND the next synchronising call on the context (every host-pointer call,
- *     k4lz4_synchronize) returns K4LZ4_E_HIP / K4LZ4_E_NOMEM with the reason in k4lz4_last_error().
+ *     k4lz4_synchronize) returns K4LZ4_E_HIP / K4LZ4_E_NOMEM with the reason(s) in k4lz4_last_error().
+ *     The report is kept per CONTEXT (a word of device memory the context owns and hands to its kernels):
+ *     contexts that share a device -- one per managed thread in the .NET shim -- never see or clear each
+ *     other's.  This holds for pickles too: an HC pickle that was not encoded for want of reserved scratch
+ *     has outLen = -1, never a valid raw envelope.
  */
 #ifndef K4LZ4_H
 #define K4LZ4_H

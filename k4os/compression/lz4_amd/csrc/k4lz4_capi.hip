@@ -77,6 +77,7 @@ struct k4lz4_ctx {
     struct Pool *pool = nullptr;
     /* diagnostic switches, read once at creation: K4LZ4_SPLIT_PCT (1..100, share of an encode batch on the LDS-table kernel),
      * K4LZ4_NO_PAIR (decode with one wave per block) */
+    uint32_t *d_status = nullptr;   /* this context's status word: DEV_STATUS_* bits raised by its kernels (k4lz4_common.hpp) */
     int split_pct = -1;
     bool no_pair = false;
     bool trace = false;         /* K4LZ4_TRACE: host-pointer calls print where their time went (stderr) */
@@ -173,17 +174,21 @@ int check_level(k4lz4_ctx *ctx, int level)
 
 int grow(k4lz4_ctx *ctx, uint8_t **p, size_t *cap, size_t need, bool pinned);
 
-/* after a synchronisation: did a kernel of this device report call-level trouble (k4_dev_status)?  Reads and clears it. */
+/* After a synchronisation of the call's stream: did a kernel launched through THIS context report call-level trouble?
+ * Reads and clears the context's own word -- only this context's kernels write it and they have finished, so nothing can
+ * land between the read and the clear -- and reports every bit that is set. */
 int take_device_status(k4lz4_ctx *ctx)
 {
     uint32_t v = 0;
-    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(k4::k4_dev_status), sizeof v) != hipSuccess) { (void)hipGetLastError(); return K4LZ4_OK; }
+    if (!ctx->d_status) return K4LZ4_OK;
+    if (hipMemcpy(&v, ctx->d_status, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return K4LZ4_OK; }
     if (v == 0) return K4LZ4_OK;
-    const uint32_t zero = 0;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(k4::k4_dev_status), &zero, sizeof zero);
-    if (v & k4::DEV_STATUS_HC_SCRATCH)
-        return fail(ctx, K4LZ4_E_NOMEM, "HC scratch reserved with k4lz4_ctx_reserve_hc was too small for the batch: its blocks were not encoded");
-    return fail(ctx, K4LZ4_E_HIP, "a decoder wave gave up waiting for its partner wave (scheduling time-out, not corrupt data): the affected blocks report failure");
+    (void)hipMemset(ctx->d_status, 0, sizeof v);
+    const bool nomem = (v & k4::DEV_STATUS_HC_SCRATCH) != 0, timeout = (v & k4::DEV_STATUS_PIPE_TIMEOUT) != 0;
+    std::string msg;
+    if (nomem) msg += "HC scratch reserved with k4lz4_ctx_reserve_hc was too small for the batch: its blocks were not encoded";
+    if (timeout) msg += std::string(nomem ? "; " : "") + "a decoder wave gave up waiting for its partner wave (scheduling time-out, not corrupt data): the affected blocks report failure";
+    return fail(ctx, nomem ? K4LZ4_E_NOMEM : K4LZ4_E_HIP, msg.c_str());
 }
 
 /* HC levels: layout -> (sync for the scratch size) -> hash-table clear -> chain kernel -> parse kernel.
@@ -208,6 +213,7 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
         int32_t *d_enccap = (int32_t *)(d_encoff + cnt);
         int32_t *d_enclen = d_enccap + cnt;
         k4::HcArgs h{};
+        h.status = ctx->d_status;
         h.src = src; h.srcOff = srcOff + first; h.srcLen = srcLen + first;
         h.dst = dst; h.dstOff = dstOff + first; h.dstCap = dstCap + first; h.outLen = outLen + first;
         h.n = cnt; h.level = level; h.flags = flags;
@@ -341,6 +347,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
         a.outLen = outLen + first; a.n = cnt; a.level = level; a.accel = ctx->accel;
         a.flags = flags | (g_enforce32.load(std::memory_order_relaxed) ? K4LZ4_FLAG_X32 : 0);
         a.prof = ctx->prof ? ctx->prof + k4::PROF_STRIDE * first : nullptr;
+        a.status = ctx->d_status;
         if (dd && dd->dict) {
             a.dict = dd->dict; a.dictOff = dd->off + first; a.dictLen = dd->len + first;
             a.dictMode = dd->mode ? dd->mode + first : nullptr;
@@ -867,6 +874,8 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_status, 64);
+    if (e == hipSuccess) e = hipMemset(ctx->d_status, 0, 64);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copyq, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
@@ -907,6 +916,7 @@ void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
     if (ctx->h_len) (void)hipHostFree(ctx->h_len);
     if (ctx->copyq) (void)hipStreamDestroy(ctx->copyq);
     delete ctx->pool;
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
     if (ctx->d_dict) (void)hipFree(ctx->d_dict);
     if (ctx->d_src) (void)hipFree(ctx->d_src);
@@ -1155,7 +1165,7 @@ int k4lz4_decode_chain_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const ui
         return fail(ctx, K4LZ4_E_ARG, "bad argument");
     if (nStreams == 0) return K4LZ4_OK;
     K4_HIP(ctx, hipSetDevice(ctx->device));
-    k4::ChainArgs a{src, blkOff, blkLen, firstBlk, nBlk, blockSize, chained, dst, dstOff, dstCap, (long long *)outLen, nStreams};
+    k4::ChainArgs a{src, blkOff, blkLen, firstBlk, nBlk, blockSize, chained, dst, dstOff, dstCap, (long long *)outLen, nStreams, ctx->d_status};
     const unsigned grid = (unsigned)((nStreams + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
     if (nStreams <= 16 * (int64_t)ctx->cu_count && !ctx->no_pair)    /* room for two waves per stream */
         hipLaunchKernelGGL(k4::k4_decode_chain_pair_kernel, dim3((unsigned)((nStreams + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),

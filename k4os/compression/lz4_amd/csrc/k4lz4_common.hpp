@@ -58,6 +58,7 @@ struct BatchArgs {
     const uint64_t *dictOff;
     const int32_t *dictLen;
     const signed char *dictMode;   /* optional: 1 = prefix semantics, 2 = external (host staging); nullptr = by address */
+    uint32_t *status;              /* the context's status word (DEV_STATUS_* bits, raised with dev_status_raise), or nullptr */
 };
 
 struct __attribute__((packed, aligned(1))) U16u { uint16_t v; };
@@ -85,10 +86,16 @@ constexpr int PROF_STRIDE = 16;
 
 /* Call-level trouble that is not a property of any block's data: bit 0 = a wave of a decoder pair gave up waiting for
  * its partner (scheduling, never corrupt input), bit 1 = the HC scratch reserved for an asynchronous call was too small.
- * The host reads and clears it whenever it synchronises (k4lz4_synchronize, every host-pointer call) and reports
- * K4LZ4_E_HIP -- the affected blocks' outLen only say "failed". */
-__device__ uint32_t k4_dev_status;
+ * The word belongs to the CONTEXT whose call launched the kernel (every args struct carries its address), so that one
+ * context's trouble is never reported to -- or cleared by -- another context on the same device.  The host reads and
+ * clears it whenever it synchronises (k4lz4_synchronize, every host-pointer call) and reports all the bits it finds;
+ * the affected blocks' outLen only say "failed". */
 enum : uint32_t { DEV_STATUS_PIPE_TIMEOUT = 1u, DEV_STATUS_HC_SCRATCH = 2u };
+constexpr int HC_NO_SCRATCH = -0x7ffffff1;   /* LLxx-level result of an HC block that was not encoded for want of scratch (<= 0: failure) */
+__device__ __forceinline__ void dev_status_raise(uint32_t *status, uint32_t bits)
+{
+    if (status) atomicOr(status, bits);
+}
 
 /* placement record of the diagnostic kernels: [8] start, [9] end (100 MHz real-time counter), [10] HW_ID */
 template <bool PROF> __device__ __forceinline__ void prof_place(unsigned long long *pc, int slot, int lane)
@@ -108,7 +115,7 @@ template <bool PROF> __device__ __forceinline__ void prof_place(unsigned long lo
 template <bool PROF> __device__ __forceinline__ unsigned long long prof_now()
 {
     if (!PROF) return 0ull;
-#ifndef K4_HOST_EMU
+#if !defined(K4_HOST_EMU) && !defined(K4_PROF_NODRAIN)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
     return (unsigned long long)__builtin_readcyclecounter();

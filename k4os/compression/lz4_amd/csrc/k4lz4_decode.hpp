@@ -179,14 +179,22 @@ __device__ __forceinline__ void pipe_store(uint32_t *p, uint32_t v, int lane)
 #endif
     lds_sync();
 }
-/* poll until *p - base >= want (counters only grow); false after PIPE_SPIN_MAX polls */
-__device__ __forceinline__ bool pipe_wait(const uint32_t *p, uint32_t want)
+/* the pair's queue keeps the address of its context's status word in pipe[6..7] (written by pipe_init) */
+__device__ __forceinline__ void pipe_init(uint32_t *pipe, uint32_t *status, int lane)
+{
+    if (lane < 6) pipe[lane] = 0u;                          /* head, tail */
+    if (lane == 6) pipe[6] = (uint32_t)(uintptr_t)status;
+    if (lane == 7) pipe[7] = (uint32_t)((unsigned long long)(uintptr_t)status >> 32);
+}
+/* poll until pipe[which] >= want (counters only grow); false after PIPE_SPIN_MAX polls */
+__device__ __forceinline__ bool pipe_wait(const uint32_t *pipe, int which, uint32_t want)
 {
     for (uint32_t spin = 0; spin < PIPE_SPIN_MAX; spin++) {
-        if (pipe_load(p) >= want) return true;
+        if (pipe_load(pipe + which) >= want) return true;
         __builtin_amdgcn_s_sleep(1);
     }
-    atomicOr(&k4_dev_status, (uint32_t)DEV_STATUS_PIPE_TIMEOUT);   /* reported at call level: not this block's fault */
+    /* reported at call level, to the context that launched this kernel: not this block's fault */
+    dev_status_raise((uint32_t *)(uintptr_t)((unsigned long long)pipe[6] | ((unsigned long long)pipe[7] << 32)), (uint32_t)DEV_STATUS_PIPE_TIMEOUT);
     return false;
 }
 
@@ -252,9 +260,9 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             meta = pipe + 8 + 8 * slot;
             d_lpos = pipe + PIPE_DESC + 320 * slot; d_llen = d_lpos + 64; d_out = d_llen + 64; d_moff = d_out + 64; d_mlen = d_moff + 64;
             if (ROLE == 1) {                                /* the slot is free once the other wave has taken batch_no - PIPE_SLOTS */
-                if (batch_no >= (uint32_t)PIPE_SLOTS && !pipe_wait(pipe + 1, batch_no + 1u - (uint32_t)PIPE_SLOTS)) return PIPE_TIMEOUT;
+                if (batch_no >= (uint32_t)PIPE_SLOTS && !pipe_wait(pipe, 1, batch_no + 1u - (uint32_t)PIPE_SLOTS)) return PIPE_TIMEOUT;
             } else {
-                if (!pipe_wait(pipe + 0, batch_no + 1u)) return PIPE_TIMEOUT;
+                if (!pipe_wait(pipe, 0, batch_no + 1u)) return PIPE_TIMEOUT;
                 nseq = (int)uni(meta[0]);
                 op_batch = (int64_t)uni(meta[1]);
                 op = op_batch + (int64_t)uni(meta[2]);
@@ -710,7 +718,7 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
     const uint32_t pair = wave >> 1, role = (wave ^ blockIdx.x) & 1u;
     const long long slot = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
     uint32_t *ring = lds[pair], *pipe = lds[pair] + RING_DWORDS;
-    if (lane < 8 && role == 0) pipe[lane] = 0u;             /* head, tail */
+    if (role == 0) pipe_init(pipe, a.status, lane);
     __syncthreads();
     if (slot >= a.n) return;
     const long long b = a.order ? (long long)uni(a.order[slot]) : slot;

@@ -66,6 +66,7 @@ struct HcArgs {
     unsigned long long *workOff;   /* n + 2: byte offset of block i's work area, [n] = total, [n+1] = longest block (k4_hc_layout_kernel) */
     unsigned long long workCap;    /* bytes behind `work` when the launch was sized without asking the device (0 = sized from [n]) */
     unsigned int maxLen;           /* the longest block the launch was sized for (same case) */
+    uint32_t *status;              /* the context's status word (k4lz4_common.hpp), or nullptr */
 };
 
 /* a launch sized from a reservation (k4lz4_ctx_reserve_hc) whose batch turned out bigger: nothing is touched, every block
@@ -109,9 +110,9 @@ __global__ __launch_bounds__(256) void k4_hc_layout_kernel(HcArgs a)
     }
     if (t == 255) {
         a.workOff[a.n] = base;
-        if (a.workCap != 0ull && base > a.workCap) atomicOr(&k4_dev_status, (uint32_t)DEV_STATUS_HC_SCRATCH);
+        if (a.workCap != 0ull && base > a.workCap) dev_status_raise(a.status, (uint32_t)DEV_STATUS_HC_SCRATCH);
     }
-    if (t == 0 && a.workCap != 0ull && a.workOff[a.n + 1] > (unsigned long long)a.maxLen) atomicOr(&k4_dev_status, (uint32_t)DEV_STATUS_HC_SCRATCH);
+    if (t == 0 && a.workCap != 0ull && a.workOff[a.n + 1] > (unsigned long long)a.maxLen) dev_status_raise(a.status, (uint32_t)DEV_STATUS_HC_SCRATCH);
 }
 
 /* ---- kernel 1: chains ------------------------------------------------------------------- */
@@ -1006,6 +1007,7 @@ __global__ __launch_bounds__(64) void k4_hc_parse_kernel(HcArgs a)
     if (lane == 0) {
         int r = ret;
         if (!(a.flags & FLAG_RAW_RETURN)) r = src_len <= 0 ? 0 : (ret <= 0 ? -1 : ret);   /* LZ4Codec.cs:45-51 */
+        else if (!hc_scratch_ok(a)) r = HC_NO_SCRATCH;      /* "not encoded", which 0 would not say to the pickle envelope (raw fallback) */
         a.outLen[b] = r;
     }
 }
@@ -1026,6 +1028,7 @@ __global__ __launch_bounds__(64) void k4_hc_parse_opt_kernel(HcArgs a)
     if (lane == 0) {
         int r = ret;
         if (!(a.flags & FLAG_RAW_RETURN)) r = src_len <= 0 ? 0 : (ret <= 0 ? -1 : ret);   /* LZ4Codec.cs:45-51 */
+        else if (!hc_scratch_ok(a)) r = HC_NO_SCRATCH;      /* "not encoded", which 0 would not say to the pickle envelope (raw fallback) */
         a.outLen[b] = r;
     }
 }

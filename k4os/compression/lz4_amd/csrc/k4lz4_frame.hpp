@@ -65,6 +65,7 @@ struct ChainArgs {
     const uint64_t *dstCap;
     long long *outLen;           /* per stream: bytes produced, -6 a block does not decode, -9 target too small */
     long long n;
+    uint32_t *status;            /* the context's status word (k4lz4_common.hpp), or nullptr */
 };
 
 __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_decode_chain_kernel(ChainArgs a)
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
     const uint32_t pair = wave >> 1, role = (wave ^ blockIdx.x) & 1u;   /* as in k4_decode_pair_kernel */
     const long long s = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
     uint32_t *ring = lds[pair], *pipe = lds[pair] + RING_DWORDS;
-    if (lane < 8 && role == 0) pipe[lane] = 0u;
+    if (role == 0) pipe_init(pipe, a.status, lane);
     __syncthreads();
     if (s >= a.n) return;
     uint8_t *out = a.dst + a.dstOff[s];

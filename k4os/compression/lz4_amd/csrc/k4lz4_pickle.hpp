@@ -165,7 +165,7 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
     const uint32_t pair = wave >> 1, role = (wave ^ blockIdx.x) & 1u;   /* as in k4_decode_pair_kernel */
     const long long slot = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
     uint32_t *ring = lds[pair], *pipe = lds[pair] + RING_DWORDS;
-    if (lane < 8 && role == 0) pipe[lane] = 0u;
+    if (role == 0) pipe_init(pipe, a.status, lane);
     __syncthreads();
     if (slot >= a.n) return;
     const long long b = a.order ? (long long)uni(a.order[slot]) : slot;
@@ -200,6 +200,7 @@ __global__ __launch_bounds__(64) void k4_pickle_finish_kernel(BatchArgs a, const
     int r;
     if (U <= 0) r = 0;
     else if (a.dstCap[b] < 1 + 4 + U) r = -1;
+    else if (U > 1 && encLen[b] == HC_NO_SCRATCH) r = -1;   /* the HC reservation was too small: not pickled (the status word says why), never a raw envelope */
     else r = pickle_finish(a.src + a.srcOff[b], U, a.dst + a.dstOff[b], U > 1 ? encLen[b] : 0, a.flags, lane);
     if (lane == 0) a.outLen[b] = r;
 }

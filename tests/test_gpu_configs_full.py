@@ -139,6 +139,41 @@ def test_hc_device_call_with_reservation_only_enqueues_and_a_small_one_fails_lou
     assert (clen3.cpu().numpy() > 0).all()
 
 
+def test_status_word_is_per_context_and_a_short_hc_reservation_never_yields_raw_pickles(oracle):
+    """The status word belongs to the context whose call launched the kernels: another context on the same device neither
+    sees nor clears it.  And the pickle path: an HC reservation that is too small must not come back as valid raw
+    (uncompressed) envelopes -- outLen says failure, the context says why."""
+    import torch
+    from k4os.compression.lz4_amd import _native
+    from k4os.compression.lz4_amd.device import DeviceBatch, DeviceCodec
+    blocks = corpus.silesia_like_blocks(48, 65536, seed=6)
+    n = blocks.shape[0]
+    lens = np.full(n, 65536, np.int32)
+    off = np.arange(n, dtype=np.uint64) * 65536
+    a, b = DeviceCodec(0), DeviceCodec(0)
+    src = DeviceBatch.from_host(blocks.reshape(-1), off, lens, a.device)
+    env = DeviceBatch.empty_slots(np.full(n, 65536 + 5, np.int32), a.device, fill=0xCD)
+    a.ctx.check(a.lib.k4lz4_ctx_reserve_hc(a.ctx.handle, n * 65536 // 2, 65536))
+    plen = a.pickle(src, env, level=LZ4Level.L03_HC)
+    torch.cuda.synchronize()
+    # context b synchronises first: it finds nothing, and it does not take a's report away
+    comp = DeviceBatch.empty_slots(np.full(n, LZ4Codec.MaximumOutputSize(65536), np.int32), b.device)
+    clen = b.encode(src, comp)
+    b.ctx.check(b.lib.k4lz4_synchronize(b.ctx.handle, None))
+    assert (clen.cpu().numpy() > 0).all()
+    rc = a.lib.k4lz4_synchronize(a.ctx.handle, None)
+    assert rc == _native.E_NOMEM and b"reserve" in a.lib.k4lz4_last_error(a.ctx.handle)
+    assert (plen.cpu().numpy() == -1).all(), "a failed HC pickle must not look like a raw envelope"
+    assert a.lib.k4lz4_synchronize(a.ctx.handle, None) == 0        # read once, cleared
+    a.ctx.check(a.lib.k4lz4_ctx_reserve_hc(a.ctx.handle, 0, 0))
+    plen = a.pickle(src, env, level=LZ4Level.L03_HC)
+    a.ctx.check(a.lib.k4lz4_synchronize(a.ctx.handle, None))
+    eh, eoff, pl = env.data.cpu().numpy(), env.off.cpu().numpy(), plen.cpu().numpy()
+    for i in range(0, n, 5):
+        want = oracle.pickle(blocks[i], 3)
+        assert pl[i] == len(want) and eh[eoff[i]:eoff[i] + pl[i]].tobytes() == want, i
+
+
 def test_one_context_two_streams_do_not_race_on_its_scratch(oracle):
     """the context's dispatch-order / hash-table scratch is shared by all calls: two calls in a row on different streams
     must give the results of two calls in a row on one stream"""
