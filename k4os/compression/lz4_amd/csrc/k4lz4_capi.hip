@@ -41,6 +41,7 @@ struct k4lz4_ctx {
     hipStream_t stream = nullptr;   /* used by the host-pointer calls */
     int accel = 1;                  /* fast-encoder acceleration of the next launch (LLxx-level calls only) */
     unsigned long long *prof = nullptr;   /* diagnostic counters of the next launch (k4lz4_profile_batch_device) */
+    bool prof_pair = false;               /* ... of the two-waves-per-block decoder (32 counters per block) */
     /* grow-only device / pinned scratch for the host-pointer calls */
     uint8_t *d_src = nullptr; size_t d_src_cap = 0;
     uint8_t *d_dst = nullptr; size_t d_dst_cap = 0;
@@ -403,23 +404,29 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
                                     dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, a);
             break;
         case KIND_DECODE:
-            if (a.prof) hipLaunchKernelGGL(k4::k4_decode_prof_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
+            if (a.prof && ctx->prof_pair) {
+                hipLaunchKernelGGL(k4::k4_decode_pair_prof_kernel, dim3((unsigned)((cnt + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
+                                   dim3(128 * k4::DECODE_PAIRS_PER_WG), 0, stream, a);
+            }
+            else if (a.prof) hipLaunchKernelGGL(k4::k4_decode_prof_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
             else if (cnt > 24 * (int64_t)ctx->cu_count)   /* more blocks than can be resident (6 waves x 4 SIMDs per CU) */
                 hipLaunchKernelGGL(k4::k4_decode_dense_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
-            else if (cnt <= 16 * (int64_t)ctx->cu_count && !ctx->no_pair)
+            else if (cnt <= 16 * (int64_t)ctx->cu_count && !ctx->no_pair) {
                 /* at most half the chip's wave slots (8 per SIMD at 64 VGPRs) are needed: two waves per block, one
                  * parsing ahead of the one that copies */
                 hipLaunchKernelGGL(k4::k4_decode_pair_kernel, dim3((unsigned)((cnt + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
                                    dim3(128 * k4::DECODE_PAIRS_PER_WG), 0, stream, a);
+            }
             else hipLaunchKernelGGL(k4::k4_decode_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
             break;
         case KIND_PICKLE:
             hipLaunchKernelGGL(k4::k4_pickle_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a);
             break;
         case KIND_UNPICKLE:
-            if (cnt <= 64 * (int64_t)ctx->cu_count && !ctx->no_pair)
+            if (cnt <= 64 * (int64_t)ctx->cu_count && !ctx->no_pair) {
                 hipLaunchKernelGGL(k4::k4_unpickle_pair_kernel, dim3((unsigned)((cnt + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
                                    dim3(128 * k4::DECODE_PAIRS_PER_WG), 0, stream, a);
+            }
             else hipLaunchKernelGGL(k4::k4_unpickle_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
             break;
         }
@@ -1099,6 +1106,7 @@ int k4lz4_profile_batch_device(k4lz4_ctx *ctx, int decode, const uint8_t *src, c
 {
     if (!ctx || !counters) return fail(ctx, K4LZ4_E_ARG, "bad argument");
     ctx->prof = (unsigned long long *)counters;
+    ctx->prof_pair = decode == 2;        /* 2: the two-waves-per-block decoder, 32 counters per block (parsing wave, copying wave) */
     const int rc = run_device(ctx, decode ? KIND_DECODE : KIND_ENCODE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n,
                               K4LZ4_L00_FAST, 0, stream);
     ctx->prof = nullptr;
@@ -1167,10 +1175,10 @@ int k4lz4_decode_chain_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const ui
     K4_HIP(ctx, hipSetDevice(ctx->device));
     k4::ChainArgs a{src, blkOff, blkLen, firstBlk, nBlk, blockSize, chained, dst, dstOff, dstCap, (long long *)outLen, nStreams, ctx->d_status};
     const unsigned grid = (unsigned)((nStreams + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
-    if (nStreams <= 16 * (int64_t)ctx->cu_count && !ctx->no_pair)    /* room for two waves per stream */
+    if (nStreams <= 16 * (int64_t)ctx->cu_count && !ctx->no_pair) {  /* room for two waves per stream */
         hipLaunchKernelGGL(k4::k4_decode_chain_pair_kernel, dim3((unsigned)((nStreams + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
                            dim3(128 * k4::DECODE_PAIRS_PER_WG), 0, (hipStream_t)stream, a);
-    else
+    } else
         hipLaunchKernelGGL(k4::k4_decode_chain_kernel, dim3(grid), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, (hipStream_t)stream, a);
     K4_HIP(ctx, hipGetLastError());
     return K4LZ4_OK;

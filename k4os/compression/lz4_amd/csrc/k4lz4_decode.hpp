@@ -43,6 +43,7 @@ namespace k4 {
 constexpr int DECODE_STAGE_BYTES = 2048;          /* a batch's output, kept in LDS while its matches resolve */
 constexpr int DECODE_LDS_DWORDS = RING_DWORDS + 5 * 64 + (DECODE_STAGE_BYTES + 64) / 4;   /* ring + 5 descriptor arrays + stage */
 constexpr int MAX_SEQ_PER_ROUND = 22;            /* 64 hypotheses, >= 3 stream bytes per sequence */
+constexpr int DECODE_BATCH_SOFT_BYTES = DECODE_STAGE_BYTES - 512;   /* PARSE stops adding to a batch beyond this many output bytes */
 
 /* PARSE's serial part: from hypothesis 0 follow the `next` links while the hypotheses are usable and stay inside
  * the 64-lane window; T collects the real sequences, idx ends on the first position not taken.  A lane's word:
@@ -143,6 +144,92 @@ __device__ __forceinline__ void wave_dict_copy(uint8_t *out, const uint8_t *dict
     if (len > n1) wave_match_copy(out, op + n1, op + n1, len - n1, lane);
 }
 
+/* inclusive running maximum over the 64 lanes (values >= 0), DPP like wave_inclusive_scan */
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t x)
+{
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));   /* row_shr:1 */
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));   /* row_shr:2 */
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));   /* row_shr:4 */
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));   /* row_shr:8 */
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));  /* row_bcast:15 -> rows 1,3 */
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));  /* row_bcast:31 -> rows 2,3 */
+    return x;
+}
+
+/* Items longer than a lane moves at once (literal runs, match sources from before the batch), all of them together:
+ * lane l's item is `x` bytes (0 = none, else > 32) at src + soff, to go to stage + doff.  The items are cut into 16-byte
+ * pieces, the pieces are numbered through (prefix sum) and dealt out 64 at a time, so one load instruction of the wave
+ * moves a KiB of them whatever their number.  Which item a piece belongs to: every item marks the slot of its first piece
+ * (`own`, 64 dwords of LDS), a running maximum fills the slots in between.  An item's last piece is its last 16 bytes
+ * (it overlaps the piece before it), so nothing outside [src + soff, + x) is read and nothing outside the item written. */
+__device__ __forceinline__ void long_pieces(uint8_t *stg, uint32_t *own, const uint8_t *src, uint32_t soff, uint32_t x, uint32_t doff, int lane)
+{
+    const uint32_t np = (x + 15u) >> 4;
+    const uint32_t incl = wave_inclusive_scan(np);
+    const uint32_t total = readlane_u32(incl, 63), base = incl - np;
+    uint32_t carry = 0;                                     /* the item (lane + 1) that owns the last piece of the pass before */
+    for (uint32_t p0 = 0; p0 < total; p0 += 64u) {
+        lds_sync();
+        own[lane] = 0u;
+        lds_sync();
+        if (np != 0u && base - p0 < 64u) own[base - p0] = (uint32_t)lane + 1u;
+        lds_sync();
+        uint32_t it = wave_inclusive_max(own[lane]);
+        if (it == 0u) it = carry;
+        carry = readlane_u32(it, 63);
+        const bool act = p0 + (uint32_t)lane < total;
+        const int sl = (int)((it - 1u) & 63u);
+        const uint32_t i_soff = (uint32_t)__shfl((int)soff, sl), i_x = (uint32_t)__shfl((int)x, sl);
+        const uint32_t i_doff = (uint32_t)__shfl((int)doff, sl), i_base = (uint32_t)__shfl((int)base, sl);
+        if (act) {
+            uint32_t o = 16u * (p0 + (uint32_t)lane - i_base);
+            if (o + 16u > i_x) o = i_x - 16u;
+            const U128u v = ld128u(src + i_soff + o);
+            uint8_t *d = stg + i_doff + o;
+            ((U64u *)d)->v = ((uint64_t)v.v[1] << 32) | v.v[0];
+            ((U64u *)(d + 8))->v = ((uint64_t)v.v[3] << 32) | v.v[2];
+        }
+    }
+    lds_sync();
+}
+
+/* stage[dst ..) = stage[dst - offset ..) for n bytes with the byte-serial semantics of LL64.dec.cs:408-450, by the whole
+ * wave: eight bytes per lane and pass, a pass never reaching into what it writes (periods of 8 bytes and more); one
+ * byte per lane for shorter periods, every lane reading the first period, which is final. */
+__device__ __forceinline__ void stage_wave_copy(uint8_t *stg, uint32_t dst, uint32_t offset, uint32_t n, int lane)
+{
+    uint8_t *d = stg + dst;
+    const uint8_t *m = d - offset;
+    lds_sync();
+    if (offset >= 8u) {
+        const uint32_t per = offset < 512u ? offset : 512u;          /* bytes per pass */
+        for (uint32_t k0 = 0; k0 < n; k0 += per) {
+            const uint32_t len = n - k0 < per ? n - k0 : per;        /* this pass: [k0, k0 + len), len >= 1 */
+            uint32_t k = 8u * (uint32_t)lane;
+            const bool act = k < len;
+            if (len >= 8u) {
+                if (k + 8u > len) k = len - 8u;                      /* the last word of the pass: its last 8 bytes */
+                if (act) {
+                    const uint64_t v = ld64u(m + k0 + k);
+                    ((U64u *)(d + k0 + k))->v = v;
+                }
+            } else if ((uint32_t)lane < len) {
+                d[k0 + (uint32_t)lane] = m[k0 + (uint32_t)lane];
+            }
+            lds_sync();
+        }
+    } else {
+        const uint32_t chunk = (64u / offset) * offset;
+        const uint32_t r = (uint32_t)lane % offset;
+        for (uint32_t k0 = 0; k0 < n; k0 += chunk) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            if ((uint32_t)lane < chunk && k < n) d[k] = m[r];
+        }
+        lds_sync();
+    }
+}
+
 /*
  * Two wavefronts per block (k4_decode_pair_kernel): a decoder wave spends ~85 % of its cycles waiting on its own
  * dependent chains, so PARSE (wave A) and LITERALS/MATCHES (wave B) of one block run side by side, batch k+1 being
@@ -218,7 +305,8 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     const bool prefix64 = dict.mode == 1 && dict.size == 65536u;
     unsigned long long c_parse = 0, c_lit = 0, c_match = 0, n_batch = 0, n_round = 0, n_seq = 0, n_slow = 0;
     unsigned long long c_hyp = 0, c_chain = 0, c_rules = 0, c_slots = 0, n_spec = 0;   /* PARSE split: speculative rounds */
-    prof_place<PROF>(pc, 8, lane);
+    unsigned long long c_wait = 0, c_search = 0, c_rounds = 0, c_flush = 0;               /* pair kernel: queue waits; the copying wave's staged batches */
+    if (ROLE == 0) prof_place<PROF>(pc, 8, lane);
     const unsigned long long t_begin = prof_now<PROF>();
     if (out_size == 0) {                                   /* LL64.dec.cs:162-168 */
         if (partial) return 0;
@@ -254,6 +342,8 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
         int nseq = 0;
         int err = 0;
         bool done = false;
+        bool gap = false;      /* a sequence of the batch leaves output bytes as they are (offset 0 in a hostile stream: the reference
+                                * copies them onto themselves, LL64.dec.cs:408-418) -- such a batch is not assembled in the stage */
         uint32_t *meta = nullptr;
         if (ROLE != 0) {
             const uint32_t slot = batch_no & (uint32_t)(PIPE_SLOTS - 1);
@@ -261,16 +351,20 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             d_lpos = pipe + PIPE_DESC + 320 * slot; d_llen = d_lpos + 64; d_out = d_llen + 64; d_moff = d_out + 64; d_mlen = d_moff + 64;
             if (ROLE == 1) {                                /* the slot is free once the other wave has taken batch_no - PIPE_SLOTS */
                 if (batch_no >= (uint32_t)PIPE_SLOTS && !pipe_wait(pipe, 1, batch_no + 1u - (uint32_t)PIPE_SLOTS)) return PIPE_TIMEOUT;
+                if (PROF) c_wait += prof_now<PROF>() - t0;
             } else {
                 if (!pipe_wait(pipe, 0, batch_no + 1u)) return PIPE_TIMEOUT;
+                if (PROF) c_wait += prof_now<PROF>() - t0;
                 nseq = (int)uni(meta[0]);
                 op_batch = (int64_t)uni(meta[1]);
                 op = op_batch + (int64_t)uni(meta[2]);
                 done = uni(meta[3]) != 0u;
                 err = (int)uni(meta[4]);                    /* the block's result, valid with `done` */
+                gap = uni(meta[5]) != 0u;
             }
         }
-        while (ROLE != 2 && nseq <= 64 - MAX_SEQ_PER_ROUND && !done) {
+        /* a batch is closed when it may not take another round's sequences, or when its output nears what the stage holds */
+        while (ROLE != 2 && nseq <= 64 - MAX_SEQ_PER_ROUND && op - op_batch <= (int64_t)DECODE_BATCH_SOFT_BYTES && !done) {
             /* ---- speculative round: 64 hypotheses "a token starts at ip + lane" ---- */
             const int64_t lim = shortiend - 1 - ip;        /* hypotheses i < lim satisfy ip + i + 1 < shortiend */
             if (lim > 0 || iend - RUN_MASK - 1 - ip > 0) {
@@ -465,12 +559,14 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                     s_moff = offset;
                     s_mlen = offset != 0u ? mlen : 0u;
                     adv = mlen;
+                    gap = gap || (offset == 0u && mlen != 0u);
                     if (op + (int64_t)mlen == oend) last = true;
                 } else {
                     if (cpy > oend - MATCH_SAFEGUARD && cpy > oend - LASTLITERALS) { err = (int)(-ip) - 1; break; }  /* :427-433 */
                     s_moff = offset;
                     s_mlen = offset != 0u ? length : 0u;       /* offset 0 (hostile): output left as is */
                     adv = length;
+                    gap = gap || offset == 0u;
                 }
             }
             if (lane == 0) {
@@ -487,11 +583,17 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 meta[2] = err ? 0u : (uint32_t)(op - op_batch);
                 meta[3] = (err || done) ? 1u : 0u;
                 meta[4] = (uint32_t)(err ? err : (int)op);
+                meta[5] = gap ? 1u : 0u;
             }
             pipe_store(pipe + 0, batch_no + 1u, lane);
             batch_no++;
+            if (PROF) { c_parse += prof_now<PROF>() - t0; n_batch++; n_seq += (unsigned long long)nseq; }
             if (err || done) {
                 if (seq) *seq = batch_no;
+                if (PROF && pc && lane == 0) {
+                    pc[0] = prof_now<PROF>() - t_begin; pc[1] = c_wait; pc[2] = c_parse; pc[4] = n_batch; pc[6] = n_seq; pc[7] = n_slow;
+                    pc[11] = c_hyp; pc[12] = c_chain; pc[13] = c_rules; pc[14] = c_slots; pc[15] = n_spec;
+                }
                 return err ? err : (int)op;
             }
             continue;
@@ -512,21 +614,28 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
 
         const uint32_t o0 = (uint32_t)op_batch, T = (uint32_t)(op - op_batch);
         const bool has_m = mine && v_mlen != 0u;
-        const unsigned long long complex_m = __ballot((mine && v_llen > LANE_COPY_MAX) ||
-                                                      (has_m && (v_mlen > LANE_COPY_MAX || v_moff < v_mlen || v_moff > v_out + v_llen)));
+        /* matches that start before the block (dictionary) keep the general path below */
+        const unsigned long long neg_m = __ballot(has_m && v_moff > v_out + v_llen);
         unsigned long long t2 = t1;
-        if (T <= (uint32_t)DECODE_STAGE_BYTES && complex_m == 0ull) {
+        if (T <= (uint32_t)DECODE_STAGE_BYTES && neg_m == 0ull && !gap) {
             /* ======================= STAGED: the batch's output lives in LDS while it is assembled ==========
              * All global loads of the batch go out first -- literals from the compressed stream, and the
              * match sources that lie before the batch's output (they are final).  Matches that read this
              * batch's own output take it from the LDS stage, so the dependency rounds never wait for global
-             * memory; the finished batch is then written out in one coalesced pass. */
+             * memory; the finished batch is then written out in one coalesced pass.
+             * A lane moves up to 32 bytes at a time.  Longer literal runs and longer sources from before the batch are cut
+             * into 16-byte pieces that are dealt out to the lanes -- one load instruction then serves all the long
+             * items of a batch (`long_pieces`); a longer copy inside the stage, or one that overlaps its own output
+             * (offset < length: the reference's byte-serial semantics, LL64.dec.cs:408-450), takes several rounds of its lane,
+             * each round a piece that lies entirely behind its source, or -- periods under 8 bytes, copies over 128 bytes --
+             * is made by the whole wave (`stage_wave_copy`). */
             uint8_t *stg = stage_base;
             const uint32_t mdst = v_out + v_llen, mend = mdst + v_mlen, msrc = mdst - v_moff;
             const uint32_t before = has_m && msrc < o0 ? (o0 - msrc < v_mlen ? o0 - msrc : v_mlen) : 0u;   /* source bytes before the batch */
+            const bool lit_long = mine && v_llen > LANE_COPY_MAX, bef_long = before > LANE_COPY_MAX;
             LaneRun L, M;
-            lane_run_load(L, in + v_lpos, mine ? v_llen : 0u, (uint32_t)src_size - v_lpos);
-            lane_run_load(M, out + msrc, before, (uint32_t)out_size - msrc);
+            lane_run_load(L, in + v_lpos, (mine && !lit_long) ? v_llen : 0u, (uint32_t)src_size - v_lpos);
+            lane_run_load(M, out + msrc, bef_long ? 0u : before, (uint32_t)out_size - msrc);
             /* dependencies among the matches of the batch, as below */
             const uint32_t send = msrc + v_mlen < mdst ? msrc + v_mlen : mdst;
             lds_sync();
@@ -543,22 +652,40 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             unsigned long long deps = 0;
             const bool later = has_m && before < v_mlen;            /* some source bytes are this batch's output */
             if (later && lo < hi_c) deps = ((hi_c >= 64u ? 0ull : (1ull << hi_c)) - 1ull) & ~((1ull << lo) - 1ull);
-            if (mine && v_llen != 0u) lane_run_store(stg + (v_out - o0), L, v_llen);
-            if (before) lane_run_store(stg + (mdst - o0), M, before);
+            if (PROF) c_search += prof_now<PROF>() - t1;
+            if (mine && v_llen != 0u && !lit_long) lane_run_store(stg + (v_out - o0), L, v_llen);
+            if (before != 0u && !bef_long) lane_run_store(stg + (mdst - o0), M, before);
+            if (__ballot(lit_long)) long_pieces(stg, w_out, in, v_lpos, lit_long ? v_llen : 0u, v_out - o0, lane);
+            if (__ballot(bef_long)) long_pieces(stg, w_out, out, msrc, bef_long ? before : 0u, mdst - o0, lane);
             if (PROF) t2 = prof_now<PROF>();
             /* the part of every match that comes out of the stage: stage[src_s ..) -> stage[dst_s ..), `n` bytes */
             const uint32_t n = later ? v_mlen - before : 0u;
             const uint32_t dst_s = mdst + before - o0, src_s = msrc + before - o0;
+            const bool overlap = later && v_moff < v_mlen;
+            const bool by_wave = later && (n > 128u || (overlap && v_moff < 8u));
+            const uint32_t piece = overlap && v_moff < LANE_COPY_MAX ? v_moff : LANE_COPY_MAX;    /* what one round of the lane may move */
+            uint32_t moved = 0;
             unsigned long long pend = __ballot(later);
             while (pend) {
                 if (PROF) n_round++;
                 const bool ready = ((pend >> lane) & 1ull) != 0 && (deps & pend) == 0;
-                const unsigned long long rmask = __ballot(ready);
+                unsigned long long fin = __ballot(ready && by_wave);
                 lds_sync();
-                if (ready) lane_move32_slack(stg + dst_s, stg + src_s, n);   /* the stage has slack behind it */
-                pend &= ~rmask;
+                if (ready && !by_wave) {
+                    const uint32_t c = n - moved < piece ? n - moved : piece;
+                    lane_move32_slack(stg + dst_s + moved, stg + src_s + moved, c);   /* the stage has slack behind it */
+                    moved += c;
+                }
+                for (unsigned long long big = fin; big; big &= big - 1ull) {
+                    const int g = ctz64(big);
+                    stage_wave_copy(stg, readlane_u32(dst_s, g), readlane_u32(v_moff, g), readlane_u32(n, g), lane);
+                }
+                fin |= __ballot(ready && !by_wave && moved == n);
+                pend &= ~fin;
             }
             lds_sync();
+            const unsigned long long tc = prof_now<PROF>();
+            if (PROF) c_rounds += tc - t2;
             /* the finished batch leaves the stage in one pass, 16 bytes per lane */
             for (uint32_t k = 16u * (uint32_t)lane; k + 16u <= T; k += 1024u) {
                 const uint4 v = *(const uint4 *)(stg + k);
@@ -573,6 +700,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                     out[o0 + (uint32_t)lane] = stg[lane];
                 }
             }
+            if (PROF) c_flush += prof_now<PROF>() - tc;
         } else {
         /* ======================= LITERALS ======================= */
         {
@@ -644,6 +772,10 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
         }
         if (ROLE == 2 && done) {                            /* the result the parsing wave arrived at */
             if (seq) *seq = batch_no;
+            if (PROF && pc && lane == 0) {
+                pc[0] = prof_now<PROF>() - t_begin; pc[1] = c_wait; pc[2] = c_parse; pc[3] = c_search; pc[4] = c_lit; pc[5] = c_rounds;
+                pc[6] = c_flush; pc[7] = c_match; pc[8] = n_batch; pc[9] = n_round; pc[10] = n_seq;
+            }
             return err;
         }
         if (done) break;
@@ -734,6 +866,32 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
     } else {
         int ret = 0;
         if (run) ret = decode_block<false, 2>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, nullptr, partial, dict, pipe);
+        if (lane == 0) a.outLen[b] = codec_decode_result(src_len, ret, a.flags);
+    }
+}
+
+/* diagnostic twin of the pair kernel: 32 counters per block, the parsing wave's in [0, 16), the copying wave's in [16, 32) */
+__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) void k4_decode_pair_prof_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
+    const int lane = lane_id();
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t pair = wave >> 1, role = (wave ^ blockIdx.x) & 1u;
+    const long long b = (long long)blockIdx.x * DECODE_PAIRS_PER_WG + (long long)pair;
+    uint32_t *ring = lds[pair], *pipe = lds[pair] + RING_DWORDS;
+    if (role == 0) pipe_init(pipe, a.status, lane);
+    __syncthreads();
+    if (b >= a.n) return;
+    const int src_len = a.srcLen[b];
+    const int cap = a.dstCap[b];
+    const uint8_t *in = a.src + a.srcOff[b];
+    uint8_t *out = a.dst + a.dstOff[b];
+    const DecodeDict dict{nullptr, 0u, 0};
+    if (src_len <= 0) return;
+    if (role == 0) {
+        decode_block<true, 1>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, a.prof + 2 * PROF_STRIDE * b, false, dict, pipe);
+    } else {
+        const int ret = decode_block<true, 2>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, a.prof + 2 * PROF_STRIDE * b + PROF_STRIDE, false, dict, pipe);
         if (lane == 0) a.outLen[b] = codec_decode_result(src_len, ret, a.flags);
     }
 }

@@ -124,10 +124,11 @@ class DeviceCodec:
         return out
 
     def profile(self, decode: bool, src: DeviceBatch, dst: DeviceBatch, out_len: Optional[torch.Tensor] = None):
-        """instrumented twin kernels: returns (out_len, counters[n, 16] int64 tensor)"""
+        """instrumented twin kernels: returns (out_len, counters[n, 16] int64 tensor); decode == 2: the two-waves-per-block
+        decoder, counters[n, 32] (parsing wave, copying wave)"""
         out_len = self.new_out_len(src.n) if out_len is None else out_len
-        counters = torch.zeros((src.n, 16), dtype=torch.int64, device=self.device)
-        rc = self.lib.k4lz4_profile_batch_device(self.ctx.handle, 1 if decode else 0, _dp(src.data), _dp(src.off),
+        counters = torch.zeros((src.n, 32 if int(decode) == 2 else 16), dtype=torch.int64, device=self.device)
+        rc = self.lib.k4lz4_profile_batch_device(self.ctx.handle, int(decode), _dp(src.data), _dp(src.off),
                                                  _dp(src.length), _dp(dst.data), _dp(dst.off), _dp(dst.length),
                                                  _dp(out_len), src.n, _dp(counters), C.c_void_p(self._stream()))
         self.ctx.check(rc)

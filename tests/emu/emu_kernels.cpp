@@ -36,6 +36,20 @@ int k4emu_decode_pair_batch(const uint8_t *src, const uint64_t *srcOff, const in
     return 0;
 }
 
+/* the pair kernel's instrumented twin: counters[32 * i ..] (parsing wave, copying wave; see k4_decode_pair_prof_kernel) */
+int k4emu_decode_pair_prof_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                                 const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n,
+                                 unsigned long long *counters, int threads)
+{
+    k4::BatchArgs a{};
+    a.src = src; a.srcOff = srcOff; a.srcLen = srcLen; a.dst = dst; a.dstOff = dstOff; a.dstCap = dstCap;
+    a.outLen = outLen; a.n = n; a.accel = 1; a.prof = counters;
+    if (n <= 0) return 0;
+    unsigned grid = (unsigned)((n + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG);
+    k4emu::launch_fn(dim3(grid), dim3(128 * k4::DECODE_PAIRS_PER_WG), [=] { k4::k4_decode_pair_prof_kernel(a); }, threads);
+    return 0;
+}
+
 int k4emu_decode_dict_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
                             const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int flags,
                             const uint8_t *dict, const uint64_t *dictOff, const int32_t *dictLen, int threads)

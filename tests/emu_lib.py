@@ -140,6 +140,17 @@ class Emu:
         assert rc == 0
         return out
 
+    def decode_pair_prof(self, src, src_off, src_len, dst, dst_off, dst_cap, threads=0):
+        """the pair kernel's instrumented twin: (outLen, counters[n, 32]) -- parsing wave [0, 16), copying wave [16, 32)"""
+        out = np.full(len(src_len), -12345, dtype=np.int32)
+        counters = np.zeros((len(src_len), 32), dtype=np.uint64)
+        self.lib.k4emu_decode_pair_prof_batch.argtypes = [_u8p, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
+                                                          C.c_void_p, C.c_int]
+        rc = self.lib.k4emu_decode_pair_prof_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst), dst_off.ctypes.data,
+                                                   dst_cap.ctypes.data, out.ctypes.data, len(src_len), counters.ctypes.data, threads)
+        assert rc == 0
+        return out, counters
+
     def lane_copy(self, src, soff, dst, doff, length, mode):
         self.lib.k4emu_lane_copy.argtypes = [_u8p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
         rc = self.lib.k4emu_lane_copy(self._p(src), soff.ctypes.data, self._p(dst), doff.ctypes.data, length.ctypes.data,

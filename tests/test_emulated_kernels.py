@@ -555,3 +555,44 @@ def test_lane_run_copies_every_length_and_alignment(emu, mode):
             n = int(length[l])
             want[int(doff[l]):int(doff[l]) + n] = src[int(soff[l]):int(soff[l]) + n]
         assert np.array_equal(dst, want), (trial, int(np.argmax(dst != want)))
+
+
+def test_staged_batches_hold_long_and_overlapping_copies(emu, oracle):
+    """batches that fit the LDS stage are assembled there whatever they contain: literal runs and far match sources of more
+    than 32 bytes (16-byte pieces dealt out to the lanes), long copies inside the stage (several rounds of a lane, or the
+    whole wave), periods of 1..40 bytes (byte-serial semantics, LL64.dec.cs:408-450), and the offset-0 sequence of a hostile
+    stream, whose bytes stay as they are (such a batch is not staged)"""
+    rng = np.random.default_rng(5)
+    blocks = []
+    for period in list(range(1, 41)) + [63, 64, 65, 100, 300]:
+        parts = []
+        for rep in range(6):
+            pat = rng.integers(0, 256, period, dtype=np.uint8)
+            parts.append(rng.integers(0, 256, int(rng.integers(1, 70)), dtype=np.uint8))            # literals, some over 32 bytes
+            parts.append(np.tile(pat, int(rng.integers(40, 700)) // period + 2))                     # an overlapping match
+        blocks.append(np.concatenate(parts))
+    text = corpus.class_bytes("xml", 30000, 3)
+    far = np.concatenate([text[:5000], rng.integers(0, 256, 3000, dtype=np.uint8), text[100:1400], rng.integers(0, 256, 50, dtype=np.uint8),
+                          text[2000:2090], text[3000:3033], text[:600]])
+    blocks.append(far)
+    comp = [np.frombuffer(oracle.encode(b), np.uint8) for b in blocks]
+    # a hand-made stream with an offset of 0: 8 literals, "match" of 6 bytes at offset 0, then ordinary sequences
+    hostile = bytes([0x82]) + b"ABCDEFGH" + bytes([0, 0]) + bytes([0x21]) + b"ij" + bytes([8, 0]) + bytes([0xC0]) + b"123456789012"
+    comp.append(np.frombuffer(hostile, np.uint8))
+    for pair in (False, True):
+        emu.pair = pair
+        src, soff, slen = pack(comp)
+        caps = [b.size for b in blocks] + [64]
+        dst, doff, dcap = arena(caps)
+        out = emu.decode_batch(src, soff, slen, dst, doff, dcap, flags=FLAG_RAW)
+        for i, b in enumerate(blocks):
+            assert out[i] == b.size and dst[int(doff[i]):int(doff[i]) + b.size].tobytes() == b.tobytes(), (pair, i)
+        n, ref = oracle.decompress_safe(comp[-1], 64)
+        assert out[-1] == n == 33
+        got = dst[int(doff[-1]):int(doff[-1]) + n]
+        assert got[:8].tobytes() == b"ABCDEFGH" and (got[8:14] == 0xCD).all() and got[14:].tobytes() == ref[14:n].tobytes()
+    emu.pair = False
+    mask = np.ones(dst.size, bool)
+    for i in range(len(caps)):
+        mask[int(doff[i]):int(doff[i]) + caps[i]] = False
+    assert (dst[mask] == 0xCD).all()
