@@ -177,3 +177,72 @@ def test_hc_encode_equals_liblz4_and_roundtrips(oracle, syslz4, name, data, leve
     assert r3 == ret and d3[:ret].tobytes() == dst[:ret].tobytes()
     if ret > 1:
         assert oracle.compress_hc(data, level, cap=ret - 1)[0] == 0
+
+
+# ---- the data the GPU path is graded on -------------------------------------------------
+# The fixtures above are a few dozen inputs; the bench batch, the configs[3] messages and the configs[4] blocks are what
+# the kernels are compared with the oracle on, so the oracle itself is compared with liblz4 on exactly those bytes.
+
+def _pool_map(fn, items):
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:      # ctypes releases the GIL
+        return list(ex.map(fn, items))
+
+
+def test_fast_oracle_equals_liblz4_on_every_block_of_the_bench_batch(oracle, syslz4):
+    """all 4096 blocks of bench.py's batch (BASELINE.json configs[1], seed 2 = rank 0's), L00_FAST"""
+    blocks = corpus.silesia_like_blocks(4096, 65536, seed=2)
+    bound = oracle.compress_bound(65536)
+
+    def one(i):
+        r, d = oracle.compress_fast(blocks[i])
+        r2, d2 = syslz4.compress_fast(blocks[i], bound)
+        return r == r2 and d[:r].tobytes() == d2[:r2].tobytes()
+    bad = [i for i, ok in enumerate(_pool_map(one, range(blocks.shape[0]))) if not ok]
+    assert not bad, bad[:10]
+
+
+def test_hc3_oracle_equals_liblz4_on_the_unique_blocks_of_the_bench_batch(oracle, syslz4):
+    """configs[4]: L03_HC of the same data -- the first 384 blocks hold every class's unique material"""
+    blocks = corpus.silesia_like_blocks(4096, 65536, seed=2)[:384]
+    bound = oracle.compress_bound(65536)
+
+    def one(i):
+        r, d = oracle.compress_hc(blocks[i], 3)
+        r2, d2 = syslz4.compress_hc(blocks[i], bound, 3)
+        return r == r2 and d[:r].tobytes() == d2[:r2].tobytes()
+    bad = [i for i, ok in enumerate(_pool_map(one, range(blocks.shape[0]))) if not ok]
+    assert not bad, bad[:10]
+
+
+def test_fast_oracle_equals_liblz4_on_configs3_messages(oracle, syslz4):
+    """200 messages of the configs[3] batch (1 KiB .. 4 MiB, random / text alternating), the 20 longest of the first
+    20 000 among them: everything from 64 KiB + 11 bytes on takes the byU32 table and hash5 (LL64.fast.cs:526-544)"""
+    lens = corpus.config4_lengths()
+    first = lens[:20000]
+    pick = sorted(set(range(0, 20000, 111)) | set(int(i) for i in np.argsort(first)[-20:]))
+    assert len(pick) >= 200 and int(first[pick].max()) > (3 << 20)
+
+    def one(i):
+        data, off, ln = corpus.config4_share(lens, i, i + 1)
+        msg = data[:int(ln[0])]
+        r, d = oracle.compress_fast(msg)
+        r2, d2 = syslz4.compress_fast(msg, oracle.compress_bound(msg.size))
+        return r == r2 and d[:r].tobytes() == d2[:r2].tobytes()
+    bad = [i for i, ok in zip(pick, _pool_map(one, pick)) if not ok]
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("level", [9, 10, 12])
+def test_hc_high_levels_oracle_equals_liblz4_on_bench_blocks(oracle, syslz4, level):
+    """216 blocks of the bench batch (18 of every class) at the levels the reference holds goldens for besides 3
+    (ChecksumBlockTests.cs:137-172): pattern analysis (9) and the optimal parser (10, 12)"""
+    blocks = corpus.silesia_like_blocks(4096, 65536, seed=2)[:216]
+    bound = oracle.compress_bound(65536)
+
+    def one(i):
+        r, d = oracle.compress_hc(blocks[i], level)
+        r2, d2 = syslz4.compress_hc(blocks[i], bound, level)
+        return r == r2 and d[:r].tobytes() == d2[:r2].tobytes()
+    bad = [i for i, ok in enumerate(_pool_map(one, range(blocks.shape[0]))) if not ok]
+    assert not bad, bad[:10]
