@@ -198,7 +198,7 @@ def test_one_context_two_streams_do_not_race_on_its_scratch(oracle):
     torch.cuda.synchronize()
     for blocks, src, comp, clen in sets:
         cl, ch, coff = clen.cpu().numpy(), comp.data.cpu().numpy(), comp.off.cpu().numpy()
-        for i in range(0, blocks.shape[0], 5):
+        for i in range(blocks.shape[0]):
             assert ch[coff[i]:coff[i] + cl[i]].tobytes() == oracle.encode(blocks[i]), i
 
 
@@ -237,12 +237,62 @@ def test_host_pointer_batches_big_enough_for_the_staged_path_round_trip(oracle):
     caps = np.full(n, LZ4Codec.MaximumOutputSize(bs), np.int32)
     dst, doff = make_arena(caps, fill=0xCD)
     out = LZ4Codec.EncodeBatchPacked(src, off, lens, dst, doff, caps)
-    for i in range(0, n, 37):
-        want = oracle.encode(blocks[i])
-        assert out[i] == len(want) and dst[int(doff[i]):int(doff[i]) + out[i]].tobytes() == want, i
-        assert (dst[int(doff[i]) + out[i]:int(doff[i]) + caps[i]] == 0xCD).all(), i     # the rest of the slot is untouched
+    ref, roff = make_arena(caps, fill=0xCD)
+    want = oracle.encode_batch(src, off, lens, ref, roff, caps, threads=os.cpu_count() or 8)
+    assert np.array_equal(out, want)
+    for i in range(n):                                          # every block, and the rest of every slot untouched
+        assert np.array_equal(dst[int(doff[i]):int(doff[i]) + caps[i]], ref[int(roff[i]):int(roff[i]) + caps[i]]), i
     back, boff = make_arena(lens, fill=0xCD)
     got = LZ4Codec.DecodeBatchPacked(dst, doff, out, back, boff, lens)
     assert (got == bs).all()
     for i in range(n):
         assert np.array_equal(back[int(boff[i]):int(boff[i]) + bs], blocks[i]), i
+
+
+def test_host_pointer_staging_branches_big_ragged_shuffled(oracle):
+    """The staged host path's other branches: a decode call with more than 128 MiB of compressed input in worst-case slots
+    (packed upload, two parts), with empty blocks, a corrupt block, a destination that is too small and one block of more
+    than a staging chunk (17 MiB) among them; and the same blocks handed over in shuffled order (srcOff not ascending:
+    the unpacked fall-back).  Results and bytes against the oracle."""
+    rng = np.random.default_rng(77)
+    bs = 65536
+    rand = corpus.random_bytes(1200 * bs, 5).reshape(1200, bs)          # incompressible: 65 809-byte streams
+    text = corpus.silesia_like_blocks(900, bs, seed=13)
+    big = corpus.class_bytes("webster", 17 << 20, 3)
+    blocks = [rand[i] for i in range(1200)] + [text[i] for i in range(900)] + [big, np.zeros(0, np.uint8), np.zeros(0, np.uint8)]
+    order = rng.permutation(len(blocks))
+    blocks = [blocks[i] for i in order]
+    n = len(blocks)
+    lens = np.array([b.size for b in blocks], np.int32)
+    off = np.concatenate(([0], np.cumsum(lens[:-1].astype(np.int64)))).astype(np.uint64)
+    src = np.concatenate([b for b in blocks if b.size])
+    caps = np.array([LZ4Codec.MaximumOutputSize(int(l)) for l in lens], np.int32)
+    comp, coff = make_arena(caps, fill=0xCD)
+    clen = LZ4Codec.EncodeBatchPacked(src, off, lens, comp, coff, caps)
+    ref, roff = make_arena(caps, fill=0xCD)
+    want = oracle.encode_batch(src, off, lens, ref, roff, caps, threads=os.cpu_count() or 8)
+    assert np.array_equal(clen, want)
+    assert np.array_equal(comp, ref)                                  # every byte of every slot, slack included
+    assert int(clen[clen > 0].sum()) > (128 << 20) * 3 // 4 and int(caps.sum()) > (128 << 20)
+    # decode: exact destinations, except one corrupt stream and one destination that is too small
+    i_bad, i_small = int(np.flatnonzero(lens == bs)[3]), int(np.flatnonzero(lens == bs)[11])
+    comp[int(coff[i_bad]) + 7] ^= 0x55
+    comp[int(coff[i_bad]) + 200:int(coff[i_bad]) + 208] = 0
+    dcap = lens.copy()
+    dcap[i_small] = bs - 9
+    back, boff = make_arena(dcap, fill=0xCD)
+    got = LZ4Codec.DecodeBatchPacked(comp, coff, clen, back, boff, dcap)
+    for i in range(n):
+        c = comp[int(coff[i]):int(coff[i]) + max(int(clen[i]), 0)]
+        if lens[i] == 0:
+            assert got[i] == 0, i
+            continue
+        r, out = oracle.decompress_safe(c, int(dcap[i]))
+        assert got[i] == (r if r > 0 else -1), (i, int(got[i]), r)
+        if r > 0:
+            assert np.array_equal(back[int(boff[i]):int(boff[i]) + r], out[:r]), i
+    assert got[i_small] == -1 and (got[np.arange(n) != i_bad] != 0)[lens[np.arange(n) != i_bad] > 0].all()
+    # the same compressed blocks in shuffled order: offsets no longer ascend
+    perm = rng.permutation(n)
+    got2 = LZ4Codec.DecodeBatchPacked(comp, coff[perm], clen[perm], back, boff[perm], dcap[perm])
+    assert np.array_equal(got2, got[perm])
