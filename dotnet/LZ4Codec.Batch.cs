@@ -17,7 +17,8 @@ namespace K4os.Compression.LZ4
 		{
 			var n = ValidateBatch(source.Length, sourceOffsets, sourceLengths, target.Length, targetOffsets, targetLengths, encodedLengths.Length);
 			if (n == 0) return;
-			var ctx = NativeContext.Current;
+			using var lease = NativeContext.Rent();
+			var ctx = lease.Handle;
 			fixed (byte* s = source, t = target)
 			fixed (ulong* so = sourceOffsets, to = targetOffsets)
 			fixed (int* sl = sourceLengths, tl = targetLengths, ol = encodedLengths)
@@ -32,40 +33,64 @@ namespace K4os.Compression.LZ4
 		{
 			var n = ValidateBatch(source.Length, sourceOffsets, sourceLengths, target.Length, targetOffsets, targetLengths, decodedLengths.Length);
 			if (n == 0) return;
-			var ctx = NativeContext.Current;
+			using var lease = NativeContext.Rent();
+			var ctx = lease.Handle;
 			fixed (byte* s = source, t = target)
 			fixed (ulong* so = sourceOffsets, to = targetOffsets)
 			fixed (int* sl = sourceLengths, tl = targetLengths, ol = decodedLengths)
 				LLNative.ThrowIfFailed(LLNative.k4lz4_decode_batch(ctx, s, so, sl, t, to, tl, ol, n, 0), ctx);
 		}
 
-		/// <summary>Convenience form: every block compressed into a fresh array (null where Encode would return -1 cannot happen:
-		/// each target has MaximumOutputSize bytes).</summary>
-		public static unsafe byte[][] EncodeBatch(byte[][] blocks, LZ4Level level = LZ4Level.L00_FAST)
+		/// <summary>Convenience form: every block compressed into a fresh array.  The blocks travel packed into one managed
+		/// buffer per native call; a byte[] holds less than 2 GiB, so the batch is cut into runs of blocks whose sources AND
+		/// MaximumOutputSize targets both stay below <see cref="MaxPackedBytes"/> -- one native call (one launch) per run.</summary>
+		public static byte[][] EncodeBatch(byte[][] blocks, LZ4Level level = LZ4Level.L00_FAST)
 		{
 			if (blocks is null) throw new ArgumentNullException(nameof(blocks));
 			var n = blocks.Length;
 			var result = new byte[n][];
-			if (n == 0) return result;
+			for (var first = 0; first < n;)
+			{
+				long st = 0, dt = 0;
+				var last = first;
+				while (last < n)
+				{
+					if (blocks[last] is null) throw new ArgumentNullException($"{nameof(blocks)}[{last}]");
+					var bound = MaximumOutputSize(blocks[last].Length);
+					if (last > first && (st + blocks[last].Length > MaxPackedBytes || dt + bound > MaxPackedBytes)) break;
+					st += blocks[last].Length; dt += bound; last++;
+				}
+				EncodeRun(blocks, first, last, (int) Math.Max(1, st), (int) Math.Max(1, dt), level, result);
+				first = last;
+			}
+			return result;
+		}
+
+		/// <summary>What one packed native call may carry (sources, and targets): below the 2 GiB a byte[] can index.</summary>
+		internal const long MaxPackedBytes = 0x7FF00000;
+
+		private static void EncodeRun(byte[][] blocks, int first, int last, int srcBytes, int dstBytes, LZ4Level level, byte[][] result)
+		{
+			var n = last - first;
 			var srcOff = new ulong[n]; var srcLen = new int[n]; var dstOff = new ulong[n]; var dstCap = new int[n]; var outLen = new int[n];
-			ulong st = 0, dt = 0;
+			var src = new byte[srcBytes];
+			var dst = new byte[dstBytes];
+			int st = 0, dt = 0;
 			for (var i = 0; i < n; i++)
 			{
-				if (blocks[i] is null) throw new ArgumentNullException($"{nameof(blocks)}[{i}]");
-				srcOff[i] = st; srcLen[i] = blocks[i].Length; st += (ulong) blocks[i].Length;
-				dstOff[i] = dt; dstCap[i] = MaximumOutputSize(blocks[i].Length); dt += (ulong) dstCap[i];
+				var b = blocks[first + i];
+				srcOff[i] = (ulong) st; srcLen[i] = b.Length;
+				Buffer.BlockCopy(b, 0, src, st, b.Length);
+				st += b.Length;
+				dstOff[i] = (ulong) dt; dstCap[i] = MaximumOutputSize(b.Length); dt += dstCap[i];
 			}
-			var src = new byte[Math.Max(1UL, st)];
-			var dst = new byte[Math.Max(1UL, dt)];
-			for (var i = 0; i < n; i++) Buffer.BlockCopy(blocks[i], 0, src, (int) srcOff[i], srcLen[i]);
 			EncodeBatch(src, srcOff, srcLen, dst, dstOff, dstCap, outLen, level);
 			for (var i = 0; i < n; i++)
 			{
-				if (outLen[i] < 0) throw new InvalidOperationException($"block {i} did not fit into MaximumOutputSize bytes"); // cannot happen
-				result[i] = new byte[outLen[i]];
-				Buffer.BlockCopy(dst, (int) dstOff[i], result[i], 0, outLen[i]);
+				if (outLen[i] < 0) throw new InvalidOperationException($"block {first + i} did not fit into MaximumOutputSize bytes"); // cannot happen
+				result[first + i] = new byte[outLen[i]];
+				Buffer.BlockCopy(dst, (int) dstOff[i], result[first + i], 0, outLen[i]);
 			}
-			return result;
 		}
 
 		// the checks Encode/Decode make per call (Internal/Extensions.cs:37-52), once per batch

@@ -76,6 +76,8 @@ struct k4lz4_ctx {
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_len[2] = {nullptr, nullptr};
     uint8_t *h_len = nullptr; size_t h_len_cap = 0;
     struct Pool *pool = nullptr;
+    bool pool_failed = false;
+    int stage_threads = 7;      /* helper threads of the staging copies (K4LZ4_STAGE_THREADS - 1, read once at creation) */
     /* diagnostic switches, read once at creation: K4LZ4_SPLIT_PCT (1..100, share of an encode batch on the LDS-table kernel),
      * K4LZ4_NO_PAIR (decode with one wave per block) */
     uint32_t *d_status = nullptr;   /* this context's status word: DEV_STATUS_* bits raised by its kernels (k4lz4_common.hpp) */
@@ -465,12 +467,12 @@ constexpr size_t STAGE_CHUNK = (size_t)16 << 20;
 
 Pool *pool_of(k4lz4_ctx *ctx)
 {
-    if (!ctx->pool) {
-        unsigned hw = std::thread::hardware_concurrency();
-        unsigned want = 7u;
-        if (const char *e = getenv("K4LZ4_STAGE_THREADS")) want = (unsigned)std::max(0, std::min(63, atoi(e) - 1));
-        const int nthreads = (int)std::min<unsigned>(want, hw > 2 ? hw / 2 - 1 : 0u);
-        ctx->pool = new (std::nothrow) Pool(nthreads);
+    if (!ctx->pool && !ctx->pool_failed) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int nthreads = (int)std::min<unsigned>((unsigned)ctx->stage_threads, hw > 2 ? hw / 2 - 1 : 0u);
+        /* std::thread's constructor throws when the system has no thread to give: nothing may leave a C entry point that way,
+         * and the copies work without helpers (pool == nullptr: the calling thread does them alone) */
+        try { ctx->pool = new Pool(nthreads); } catch (...) { ctx->pool = nullptr; ctx->pool_failed = true; }
     }
     return ctx->pool;
 }
@@ -604,10 +606,34 @@ int staged_download(k4lz4_ctx *ctx, uint8_t *dst, const uint64_t *dstOff, const 
     return K4LZ4_OK;
 }
 
-/* host-pointer batch: stage, run, scatter */
+int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+                   uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level,
+                   int flags, const DictArgs *hd);
+
+/* host-pointer batch: stage, run, scatter.  A call that fails part-way has copies and kernels in flight on the context's
+ * two queues that use its staging buffers and scratch: they are drained -- and a status bit they may have raised is taken
+ * with them -- before the error is returned, so that the next call on the context starts from nothing. */
 int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
              uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level,
              int flags, const DictArgs *hd = nullptr)
+{
+    const int rc = run_host_inner(ctx, kind, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, hd);
+    if (rc != K4LZ4_OK && ctx) {
+        const std::string why = ctx->error;
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->copyq) (void)hipStreamSynchronize(ctx->copyq);
+        if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
+        (void)hipGetLastError();
+        (void)take_device_status(ctx);
+        ctx->error = why;
+        tl_error = why;
+    }
+    return rc;
+}
+
+int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
+                   uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level,
+                   int flags, const DictArgs *hd)
 {
     int rc = check_batch_args(ctx, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n);
     if (rc != K4LZ4_OK) return rc;
@@ -896,6 +922,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     }
     if (const char *pct = getenv("K4LZ4_SPLIT_PCT")) { const int v = atoi(pct); ctx->split_pct = v < 1 ? 1 : (v > 100 ? 100 : v); }
     ctx->no_pair = getenv("K4LZ4_NO_PAIR") != nullptr;
+    if (const char *e = getenv("K4LZ4_STAGE_THREADS")) ctx->stage_threads = std::max(0, std::min(63, atoi(e) - 1));
     ctx->trace = getenv("K4LZ4_TRACE") != nullptr;
     if (e != hipSuccess) { delete ctx; return hip_fail(nullptr, e, "hipStreamCreate"); }
     *out = ctx;
