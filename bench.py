@@ -36,7 +36,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s HBM3E
 def strong(args):
     """ONE batch sharded over the ranks (SURVEY.md 8e / BASELINE.json configs[3]): rank r pickles + unpickles the byte-balanced
     range r of the --messages batch in its own HBM; the int32 envelope-size vector is all-gathered over RCCL (the only
-    collective); rank 0 checks the gathered vector against the oracle on a sample drawn from EVERY rank's range."""
+    collective); rank 0 checks the gathered vector against the oracle on a sample drawn from EVERY rank's range and -- batches
+    of up to 8 GiB -- the WHOLE vector against a single-rank run of the same batch.  Also printed: the critical path (the
+    longest message of a range alone), every rank's busy time, and the time more ranks can at best make of the batch."""
     import torch
     import torch.distributed as dist
     from k4os.compression.lz4_amd import corpus
@@ -48,28 +50,45 @@ def strong(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    # K4LZ4_RANK_DEVICE=0 puts every rank on GPU 0: the real multi-rank backend (a context per rank, the gathered size vector)
+    # on a one-GPU box.  RCCL refuses two ranks on one device, so the size vector then travels over gloo.
+    shared = os.environ.get("K4LZ4_RANK_DEVICE")
+    device = int(shared) if shared is not None else local_rank
+    torch.cuda.set_device(device)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1 and shared is None:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        size_backend = "nccl (RCCL all_gather)"
     else:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("gloo", rank=0, world_size=1)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        size_backend = "gloo" + (f" ({world} ranks share GPU {device})" if world > 1 else "")
     lens_all = corpus.config4_lengths(args.messages)
-    backend = DevicePickleBackend(local_rank)
+    backend = DevicePickleBackend(device)
     ranges, sizes, mine = sharded_pickle_roundtrip(backend, lens_all, rank, world)
-    t = torch.tensor([mine["pickle_s"], mine["unpickle_s"], 0.0 if mine["roundtrip_ok"] else 1.0], dtype=torch.float64,
-                     device=backend.dc.device if world > 1 else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    t_p, t_u, bad = (float(v) for v in t.tolist())
+    on = backend.dc.device if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([mine["pickle_s"], mine["unpickle_s"], 0.0 if mine["roundtrip_ok"] else 1.0, mine["longest_s"]], dtype=torch.float64, device=on)
+    per_rank = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(per_rank, t)
+    per_rank = [[float(v) for v in p.tolist()] for p in per_rank]
+    t_p, t_u = max(p[0] for p in per_rank), max(p[1] for p in per_rank)
+    bad = max(p[2] for p in per_rank)
     if rank == 0:
         from oracle_lib import Oracle
         oracle = Oracle()
         sizes_h = sizes.cpu().numpy()
+        total = int(np.asarray(lens_all, dtype=np.int64).sum())
         rng = np.random.default_rng(1)
         sample = sorted({int(i) for lo, hi in ranges if hi > lo for i in rng.integers(lo, hi, size=8)})
         equal = all(len(oracle.pickle(corpus.config4_share(lens_all, i, i + 1)[0])) == int(sizes_h[i]) for i in sample)
-        total = int(np.asarray(lens_all, dtype=np.int64).sum())
+        busy = [round((p[0] + p[1]) * 1e3, 3) for p in per_rank]
+        crit = max(p[3] for p in per_rank)
+        check = {"size_vector_sample_equals_oracle": equal, "sampled_messages": len(sample)}
+        if total <= (8 << 30):
+            # ... and the WHOLE vector against one rank doing the whole batch alone (same GPU, a fresh context)
+            data, off, lens = corpus.config4_share(np.asarray(lens_all), 0, len(lens_all))
+            whole, _, _, _ = DevicePickleBackend(device).pickle_unpickle(data, off, lens)
+            check["size_vector_equals_single_rank_run"] = bool(np.array_equal(whole.cpu().numpy(), sizes_h))
         print(json.dumps({
             "metric": "GiB/s LZ4Pickler.Pickle + Unpickle over ONE batch of variable-length messages, byte-balanced over the GPUs",
             "value": round(total / 2 ** 30 / (t_p + t_u), 3), "unit": "GiB/s", "n_gpus": world, "steps": 1, "warmup": 1,
@@ -79,8 +98,12 @@ def strong(args):
                                    f"{total} bytes, split into {world} contiguous byte-balanced ranges", "messages": args.messages,
                        "bytes_per_rank": [int(np.asarray(lens_all[lo:hi], dtype=np.int64).sum()) for lo, hi in ranges],
                        "pickle_GiBs": round(total / 2 ** 30 / t_p, 3), "unpickle_GiBs": round(total / 2 ** 30 / t_u, 3),
-                       "envelope_bytes_total": int(sizes_h.astype(np.int64).sum())},
-            "roundtrip_ok_all_ranks": bad == 0.0, "size_vector_sample_equals_oracle": equal, "sampled_messages": len(sample)}), flush=True)
+                       "envelope_bytes_total": int(sizes_h.astype(np.int64).sum()), "size_vector_over": size_backend},
+            # a ragged batch is as slow as its longest message on its single wavefront: that message alone, each rank's own
+            # pickle + unpickle time, and what more ranks can at best make of it
+            "critical_path_ms": round(crit * 1e3, 3), "rank_busy_ms": busy,
+            "predicted_ms_at_ranks": {str(k): round(max(crit, sum(busy) / 1e3 / k) * 1e3, 3) for k in (1, 2, 4, 8)},
+            "roundtrip_ok_all_ranks": bad == 0.0, **check}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

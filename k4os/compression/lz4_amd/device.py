@@ -141,6 +141,25 @@ class DevicePickleBackend:
     def __init__(self, device: int):
         self.dc = DeviceCodec(device)
 
+    def time_alone(self, message: np.ndarray) -> float:
+        """Pickle + Unpickle seconds of ONE message with the GPU to itself (the critical path of a ragged batch)"""
+        import time
+        dc = self.dc
+        lens = np.array([message.size], np.int32)
+        src = DeviceBatch.from_host(message, np.zeros(1, np.uint64), lens, dc.device)
+        env = DeviceBatch.empty_slots(lens.astype(np.int64) + 5, dc.device)
+        back = DeviceBatch.empty_slots(lens, dc.device)
+        plen, ulen = dc.new_out_len(1), dc.new_out_len(1)
+        best = float("inf")
+        for _ in range(2):
+            torch.cuda.synchronize(dc.device)
+            t = time.perf_counter()
+            dc.pickle(src, env, plen)
+            dc.unpickle(DeviceBatch(env.data, env.off, plen), back, ulen)
+            torch.cuda.synchronize(dc.device)
+            best = min(best, time.perf_counter() - t)
+        return best
+
     def pickle_unpickle(self, data: np.ndarray, off: np.ndarray, lens: np.ndarray):
         import time
         dc = self.dc

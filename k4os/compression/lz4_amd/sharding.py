@@ -42,6 +42,8 @@ def gather_sizes(local_sizes, ranges: Sequence[Tuple[int, int]], group=None):
     world = dist.get_world_size(group)
     counts = [hi - lo for lo, hi in ranges]
     maxc = max(counts) if counts else 0
+    if dist.get_backend(group) == "gloo":
+        local_sizes = local_sizes.cpu()            # (two ranks sharing one GPU run their size exchange over gloo)
     pad = torch.zeros(maxc, dtype=torch.int32, device=local_sizes.device)
     pad[:local_sizes.numel()] = local_sizes
     parts = [torch.empty_like(pad) for _ in range(world)]
@@ -62,5 +64,16 @@ def sharded_pickle_roundtrip(backend, lens_all, rank: int, world: int, group=Non
     data, off, lens = corpus.config4_share(np.asarray(lens_all), lo, hi)
     sizes, t_p, t_u, ok = backend.pickle_unpickle(data, off, lens)
     full = gather_sizes(sizes, ranges, group)
-    return ranges, full, {"messages": int(hi - lo), "bytes": int(lens.astype(np.int64).sum()), "pickle_s": t_p, "unpickle_s": t_u,
-                          "roundtrip_ok": bool(ok)}
+    mine = {"messages": int(hi - lo), "bytes": int(lens.astype(np.int64).sum()), "pickle_s": t_p, "unpickle_s": t_u,
+            "roundtrip_ok": bool(ok), "longest_bytes": int(lens.max()) if lens.size else 0, "longest_s": 0.0}
+    if lens.size and hasattr(backend, "time_alone"):
+        # The range's longest messages on their own: with one wavefront per message the slowest of them is the floor of the
+        # range's time.  Content alternates with the global index (random bytes go fast, text does not), so the longest of
+        # either parity is timed.
+        idx = np.arange(lo, hi)
+        for parity in (0, 1):
+            sel = np.flatnonzero((idx & 1) == parity)
+            if sel.size:
+                i = int(sel[np.argmax(lens[sel])])
+                mine["longest_s"] = max(mine["longest_s"], float(backend.time_alone(data[int(off[i]):int(off[i]) + int(lens[i])])))
+    return ranges, full, mine

@@ -296,3 +296,21 @@ def test_host_pointer_staging_branches_big_ragged_shuffled(oracle):
     perm = rng.permutation(n)
     got2 = LZ4Codec.DecodeBatchPacked(comp, coff[perm], clen[perm], back, boff[perm], dcap[perm])
     assert np.array_equal(got2, got[perm])
+
+
+def test_two_ranks_on_one_gpu_run_the_real_multi_rank_backend():
+    """`bench.py --strong --gpus 2` as two processes (torch.distributed.run) that share GPU 0 (K4LZ4_RANK_DEVICE=0): a context
+    and a DevicePickleBackend per rank, byte-balanced ranges, the size vector gathered (over gloo: RCCL refuses two ranks
+    on one device) -- and rank 0 compares the WHOLE gathered vector with a single-rank run of the same batch."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, K4LZ4_RANK_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(root, "bench.py"), "--strong", "--gpus", "2", "--messages", "3000"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and lines, p.stderr[-2000:]
+    r = json.loads(lines[-1])
+    assert r["n_gpus"] == 2 and r["roundtrip_ok_all_ranks"] and r["size_vector_sample_equals_oracle"]
+    assert r["size_vector_equals_single_rank_run"] is True
+    assert len(r["rank_busy_ms"]) == 2 and r["critical_path_ms"] > 0
