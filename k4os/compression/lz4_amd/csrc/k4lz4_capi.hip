@@ -260,8 +260,13 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
             if (rc != K4LZ4_OK) return rc;
         }
         h.work = ctx->d_hc_work;
-        K4_HIP(ctx, hipMemsetAsync(ctx->d_hc_hash, 0, (size_t)cnt << (k4::HC_HASH_LOG + 2), stream));
-        hipLaunchKernelGGL(k4::k4_hc_chain_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
+        if (tail[1] <= 65536) {
+            /* no block over 64 KiB (known from the host lengths, the reservation or the device): hash tables in LDS */
+            hipLaunchKernelGGL(k4::k4_hc_chain_lds_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
+        } else {
+            K4_HIP(ctx, hipMemsetAsync(ctx->d_hc_hash, 0, (size_t)cnt << (k4::HC_HASH_LOG + 2), stream));
+            hipLaunchKernelGGL(k4::k4_hc_chain_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
+        }
         const bool optimal = level >= K4LZ4_L10_OPT;              /* clTable (LL64.high.cs:1124-1138): lz4opt strategy */
         if (tail[1] >= 13 && !optimal) {
             const unsigned gy = (unsigned)((tail[1] + k4::HC_CAND_POS_PER_WG - 1) / k4::HC_CAND_POS_PER_WG);

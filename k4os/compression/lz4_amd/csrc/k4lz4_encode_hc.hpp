@@ -116,42 +116,88 @@ __global__ __launch_bounds__(256) void k4_hc_layout_kernel(HcArgs a)
 }
 
 /* ---- kernel 1: chains ------------------------------------------------------------------- */
+/* prev[p] = nearest earlier position with the same hash (HC_NONE if there is none).  64 positions per step; positions
+ * of one step with equal hashes are rare (15-bit hash) and found through one LDS bit per hash value -- the atomic OR's
+ * old value tells a lane that another one was there first -- so that only the groups that exist are walked.
+ * TAB: the hash table, slot = position + 1 (0 = empty): uint32 in context scratch (any block length), or uint16 in LDS for
+ * blocks of up to 64 KiB -- 4096 tables of 128 KiB in memory are 512 MiB of two-byte-at-a-time traffic past every cache,
+ * 64 KiB of LDS per block is two blocks per CU and a look-up at LDS latency. */
+template <typename TAB>
+__device__ __forceinline__ void hc_chain_block(const uint8_t *src, uint32_t U, TAB *tab, uint32_t *prev, uint32_t *seen, int lane)
+{
+    const uint32_t npos = U - 3u;                          /* positions whose 4 bytes exist */
+    const unsigned long long below_me = (1ull << lane) - 1ull, above_me = ~(below_me | (1ull << lane));
+    /* The source bytes of a step are asked for four steps ahead (unconditionally, at a clamped position), into a register
+     * of their own: the loop is unrolled four times so that no word has to be moved from one register to another while it
+     * is still on its way -- such a move waits for the load, and a step would wait for memory after all. */
+    uint32_t wq[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; u++) wq[u] = ld32u(src + (64u * u + (uint32_t)lane < npos ? 64u * u + (uint32_t)lane : 0u));
+    for (uint32_t q0 = 0; q0 < npos; q0 += 256u) {
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            const uint32_t p0 = q0 + 64u * u;
+            const uint32_t p = p0 + (uint32_t)lane;
+            const bool act = p < npos;
+            const uint32_t w = wq[u];
+            wq[u] = ld32u(src + (p + 256u < npos ? p + 256u : 0u));
+            uint32_t h = 0, pr = HC_NONE;
+            bool flagged = false;
+            if (act) {
+                h = hc_hash(w);
+                const uint32_t t = tab[h];
+                pr = t ? t - 1u : HC_NONE;
+                flagged = ((atomicOr(&seen[h >> 5], 1u << (h & 31u)) >> (h & 31u)) & 1u) != 0u;
+            }
+            bool last = act;                               /* last lane of its hash inside this step */
+            unsigned long long fl = __ballot(flagged);
+            if (act) seen[h >> 5] = 0u;                     /* every lane has recorded its hash: wipe the words this step touched */
+            while (fl) {
+                const int j = ctz64(fl);
+                const uint32_t hj = __builtin_amdgcn_readlane(h, j);
+                const bool same = act && h == hj;
+                const unsigned long long m = __ballot(same);
+                if (same) {
+                    const unsigned long long lower = m & below_me;
+                    if (lower) pr = p0 + 63u - (uint32_t)__clzll((long long)lower);
+                    last = (m & above_me) == 0ull;
+                }
+                fl &= ~m;
+            }
+            if (act) prev[p] = pr;
+            if (last) tab[h] = (TAB)(p + 1u);
+            /* the next step's look-ups come after these puts: program order for a table in LDS (nothing waits for the
+             * stores of prev[], which nobody reads here), wave_sync for one in memory */
+            if (sizeof(TAB) == 2) lds_sync(); else wave_sync();
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void k4_hc_chain_kernel(HcArgs a)
 {
+    __shared__ uint32_t seen[(1u << HC_HASH_LOG) / 32u];
     const int lane = lane_id();
     const long long b = (long long)blockIdx.x;
     const int len = a.srcLen[b];
     if (len < MFLIMIT + 1 || !hc_scratch_ok(a)) return;    /* no search happens (LL64.high.cs:549) */
-    const uint32_t U = (uint32_t)len;
-    const uint8_t *src = a.src + a.srcOff[b];
-    uint32_t *tab = a.hash + (size_t)b * (1u << HC_HASH_LOG);
-    uint32_t *prev = (uint32_t *)(a.work + a.workOff[b]);
-    const uint32_t npos = U - 3u;                          /* positions whose 4 bytes exist */
+    for (uint32_t k = (uint32_t)lane; k < (1u << HC_HASH_LOG) / 32u; k += 64u) seen[k] = 0u;
+    lds_sync();
+    hc_chain_block<uint32_t>(a.src + a.srcOff[b], (uint32_t)len, a.hash + (size_t)b * (1u << HC_HASH_LOG), (uint32_t *)(a.work + a.workOff[b]), seen, lane);
+}
 
-    /* prev[p] = nearest earlier position with the same hash (HC_NONE if there is none) */
-    for (uint32_t p0 = 0; p0 < npos; p0 += 64u) {
-        const uint32_t p = p0 + (uint32_t)lane;
-        const bool act = p < npos;
-        uint32_t h = 0, pr = HC_NONE;
-        if (act) {
-            h = hc_hash(ld32u(src + p));
-            const uint32_t t = tab[h];
-            pr = t ? t - 1u : HC_NONE;
-        }
-        const unsigned long long am = __ballot(act);
-        const int cnt = __popcll(am);
-        bool last = act;                                   /* last lane of its hash inside this step */
-        for (int k = 0; k < cnt; k++) {
-            const uint32_t hk = __builtin_amdgcn_readlane(h, k);
-            if (act && hk == h) {
-                if (k < lane) pr = p0 + (uint32_t)k;
-                if (k > lane) last = false;
-            }
-        }
-        if (act) prev[p] = pr;
-        if (last) tab[h] = p + 1u;
-        wave_sync();
-    }
+/* every block of the launch is at most 64 KiB long (the host knows the longest): tables in LDS, no table memory touched */
+__global__ __launch_bounds__(64) void k4_hc_chain_lds_kernel(HcArgs a)
+{
+    __shared__ uint32_t seen[(1u << HC_HASH_LOG) / 32u];
+    __shared__ uint16_t tab[1u << HC_HASH_LOG];
+    const int lane = lane_id();
+    const long long b = (long long)blockIdx.x;
+    const int len = a.srcLen[b];
+    if (len < MFLIMIT + 1 || len > 65536 || !hc_scratch_ok(a)) return;
+    for (uint32_t k = (uint32_t)lane; k < (1u << HC_HASH_LOG) / 32u; k += 64u) seen[k] = 0u;
+    for (uint32_t k = (uint32_t)lane; k < (1u << HC_HASH_LOG) / 2u; k += 64u) ((uint32_t *)tab)[k] = 0u;
+    lds_sync();
+    hc_chain_block<uint16_t>(a.src + a.srcOff[b], (uint32_t)len, tab, (uint32_t *)(a.work + a.workOff[b]), seen, lane);
 }
 
 /* ---- kernel 1b: candidates + forward lengths, every position independently ------------------ */
@@ -464,8 +510,10 @@ __device__ __forceinline__ HcRec hc_load_rec(const uint32_t *cand, const uint2 *
     return r;
 }
 
-/* the records of 64 consecutive positions, one per lane (loaded by the literal-run scan) */
-struct HcWindow { uint32_t base; bool valid; uint4 rc; uint2 f, b; };
+/* The records of 128 consecutive positions, two per lane: [base, base + 64) in rc / f / b, the 64 after them in rc2 / f2 /
+ * b2.  The second set is asked for when the parse enters the first one and has a window's worth of work to arrive in;
+ * the searches of the three-match arbitration look ahead by a match length at most, so they find their records here. */
+struct HcWindow { uint32_t base; bool valid; uint4 rc; uint2 f, b; uint4 rc2; uint2 f2, b2; };
 
 __device__ __forceinline__ HcRec hc_get_rec(const HcWindow &w, const uint32_t *cand, const uint2 *flen, const uint2 *blen, uint32_t p)
 {
@@ -476,6 +524,15 @@ __device__ __forceinline__ HcRec hc_get_rec(const HcWindow &w, const uint32_t *c
         r.c2 = __builtin_amdgcn_readlane(w.rc.z, l); r.c3 = __builtin_amdgcn_readlane(w.rc.w, l);
         r.fl01 = __builtin_amdgcn_readlane(w.f.x, l); r.fl23 = __builtin_amdgcn_readlane(w.f.y, l);
         r.bl01 = __builtin_amdgcn_readlane(w.b.x, l); r.bl23 = __builtin_amdgcn_readlane(w.b.y, l);
+        return r;
+    }
+    if (w.valid && p - w.base < 128u) {
+        const int l = (int)(p - w.base - 64u);
+        HcRec r;
+        r.c0 = __builtin_amdgcn_readlane(w.rc2.x, l); r.c1 = __builtin_amdgcn_readlane(w.rc2.y, l);
+        r.c2 = __builtin_amdgcn_readlane(w.rc2.z, l); r.c3 = __builtin_amdgcn_readlane(w.rc2.w, l);
+        r.fl01 = __builtin_amdgcn_readlane(w.f2.x, l); r.fl23 = __builtin_amdgcn_readlane(w.f2.y, l);
+        r.bl01 = __builtin_amdgcn_readlane(w.b2.x, l); r.bl23 = __builtin_amdgcn_readlane(w.b2.y, l);
         return r;
     }
     return hc_load_rec(cand, flen, blen, p);
@@ -489,9 +546,42 @@ __device__ __forceinline__ HcRec hc_get_rec(const HcWindow &w, const uint32_t *c
 __device__ __forceinline__ HcMatch hc_search_l3(const uint8_t *src, const uint32_t *cand, const HcRec &rec, uint32_t ip, uint32_t ilow,
                                                 uint32_t matchlimit, int longest, uint32_t mpos, uint32_t spos, int lane)
 {
-    const uint32_t l0 = rec.fl01 & 0xffffu, l1 = rec.fl01 >> 16, l2 = rec.fl23 & 0xffffu, l3 = rec.fl23 >> 16;
+    uint32_t l0 = rec.fl01 & 0xffffu, l1 = rec.fl01 >> 16, l2 = rec.fl23 & 0xffffu, l3 = rec.fl23 >> 16;
     const uint32_t look_back = ip - ilow;
-    bool slow = l0 == HC_FLEN_CAP || l1 == HC_FLEN_CAP || l2 == HC_FLEN_CAP || l3 == HC_FLEN_CAP;
+    if (l0 == HC_FLEN_CAP || l1 == HC_FLEN_CAP || l2 == HC_FLEN_CAP || l3 == HC_FLEN_CAP) {
+        /* a forward length at its cap: the count goes on from there, 16 lanes per candidate and 64 bytes per step -- one
+         * trip to memory for the usual match, where the general search would start from the candidate records again */
+        const int grp = lane >> 4, sub = lane & 15;
+        const uint32_t c = grp == 0 ? rec.c0 : grp == 1 ? rec.c1 : grp == 2 ? rec.c2 : rec.c3;
+        const uint32_t l = grp == 0 ? l0 : grp == 1 ? l1 : grp == 2 ? l2 : l3;
+        const uint32_t maxn = matchlimit - (ip + MINMATCH);
+        bool open = l == HC_FLEN_CAP;
+        uint32_t done = HC_FLEN_CAP - MINMATCH, fwd = l;
+        for (;;) {
+            const uint32_t i = done + 4u * (uint32_t)sub;
+            uint32_t neq = 4u;
+            if (open) {
+                neq = 0;
+                if (i < maxn) {
+                    const uint32_t x = ld32u(src + ip + MINMATCH + i) ^ ld32u(src + c + MINMATCH + i);
+                    const uint32_t avail = maxn - i < 4u ? maxn - i : 4u;
+                    const uint32_t e = x ? (uint32_t)(__ffs(x) - 1) >> 3 : 4u;
+                    neq = e < avail ? e : avail;
+                }
+            }
+            const unsigned long long nf = __ballot(open && neq != 4u);
+            const uint32_t gm = (uint32_t)(nf >> (16 * grp)) & 0xffffu;     /* this group's not-full lanes */
+            const int fl = gm ? __ffs(gm) - 1 : 0;
+            const uint32_t nq = (uint32_t)__shfl((int)neq, (lane & 48) + fl);
+            if (open) {
+                if (gm) { fwd = MINMATCH + done + 4u * (uint32_t)fl + nq; open = false; }
+                else done += 64u;
+            }
+            if (!__ballot(open)) break;
+        }
+        l0 = readlane_u32(fwd, 0); l1 = readlane_u32(fwd, 16); l2 = readlane_u32(fwd, 32); l3 = readlane_u32(fwd, 48);
+    }
+    bool slow = false;
     uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
     if (look_back) {                                        /* LZ4HC_countBack = min(equal bytes, ip - ilow, match - 0) */
         const uint32_t s0 = rec.bl01 & 0xffffu, s1 = rec.bl01 >> 16, s2 = rec.bl23 & 0xffffu, s3 = rec.bl23 >> 16;
@@ -849,31 +939,44 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
     HcWindow win;
     win.base = 0; win.valid = false;
     win.rc = make_uint4(0u, 0u, 0u, 0u); win.f = make_uint2(0u, 0u); win.b = make_uint2(0u, 0u);
+    win.rc2 = make_uint4(0u, 0u, 0u, 0u); win.f2 = make_uint2(0u, 0u); win.b2 = make_uint2(0u, 0u);
 
     if (src_len >= MFLIMIT + 1) {
         const uint32_t mflimit = U - MFLIMIT;
         const uint32_t matchlimit = U - LASTLITERALS;
         while (ip <= mflimit) {
+          if (L3) {
+            /* One pass of this loop = one window of 64 positions.  The parse normally walks from a window into the next: its
+             * records are in the second set already and move up, and the set after it is asked for -- unconditionally, at a
+             * clamped address (records of positions past the last searchable one are never looked at), so that the load is
+             * not waited for where it is issued.  After a long match the window starts afresh at the cursor. */
+            if (win.valid && ip - win.base - 64u < 64u) {
+                win.rc = win.rc2; win.f = win.f2; win.b = win.b2;
+                win.base += 64u;
+            } else {
+                const uint32_t pos = ip + (uint32_t)lane < U - 4u ? ip + (uint32_t)lane : U - 4u;
+                win.rc = ((const uint4 *)cand)[pos]; win.f = flen[pos]; win.b = blen[pos];
+                win.base = ip;
+            }
+            win.valid = true;
+            const uint32_t pos2 = win.base + 64u + (uint32_t)lane < U - 4u ? win.base + 64u + (uint32_t)lane : U - 4u;
+            win.rc2 = ((const uint4 *)cand)[pos2]; win.f2 = flen[pos2]; win.b2 = blen[pos2];
+          }
+          do {      /* L3: the sequences that start in this window; other levels: one pass */
             uint32_t pf_anchor = HC_NONE;
             uint8_t pf_byte = 0;
             HcMatch m;
             if (L3) {
                 /* positions without a 4-byte candidate match cannot start a sequence: literal runs
-                 * are skipped 64 positions per load of the precomputed records, and the record of
-                 * the first position that can is already in registers */
-                const uint32_t pos = ip + (uint32_t)lane;
-                win.rc = make_uint4(0u, 0u, 0u, 0u);
-                win.f = make_uint2(0u, 0u);
-                win.b = make_uint2(0u, 0u);
-                if (pos < U - 3u) { win.rc = ((const uint4 *)cand)[pos]; win.f = flen[pos]; win.b = blen[pos]; }
-                win.base = ip;
-                win.valid = true;
+                 * are skipped a window at a time, and the record of the first position that can is
+                 * already in registers */
+                const uint32_t pos = win.base + (uint32_t)lane;
                 if (anchor + (uint32_t)lane < U) pf_byte = src[anchor + (uint32_t)lane];
                 pf_anchor = anchor;
-                const unsigned long long hm = __ballot(pos <= mflimit && (win.f.x | win.f.y) != 0u);
-                if (!hm) { ip += 64u; continue; }
+                const unsigned long long hm = __ballot(pos >= ip && pos <= mflimit && (win.f.x | win.f.y) != 0u);
+                if (!hm) { ip = win.base + 64u; continue; }
                 const int fz = ctz64(hm);
-                ip += (uint32_t)fz;
+                ip = win.base + (uint32_t)fz;
                 const HcRec rec = hc_get_rec(win, cand, flen, blen, ip);
                 m = hc_search_l3(src, cand, rec, ip, ip, matchlimit, MINMATCH - 1, 0u, ip, lane);
             } else {
@@ -961,6 +1064,7 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
                 start2 = start3; ref2 = ref3; ml2 = ml3;
                 /* goto _Search3 */
             }
+          } while (L3 && ip <= mflimit && ip - win.base < 64u);
         }
     }
     /* _last_literals (:751-787) */
