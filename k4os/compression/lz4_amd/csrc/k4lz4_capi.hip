@@ -73,10 +73,11 @@ struct k4lz4_ctx {
     /* big host-pointer calls run as two halves: the second half's bytes go up (copy queue) while the first half's kernels
      * run, the first half's results come down while the second half's kernels run; results' sizes via a pinned array */
     hipStream_t copyq = nullptr;
-    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_len[2] = {nullptr, nullptr};
+    hipStream_t dlq = nullptr;          /* ... and the way back has a queue (and a thread, and helper threads) of its own: up and down at once */
+    hipEvent_t ev_up[4] = {nullptr, nullptr, nullptr, nullptr}, ev_len[4] = {nullptr, nullptr, nullptr, nullptr};
     uint8_t *h_len = nullptr; size_t h_len_cap = 0;
-    struct Pool *pool = nullptr;
-    bool pool_failed = false;
+    struct Pool *pool = nullptr, *pool_dl = nullptr;   /* helper threads of the upload side, of the download side */
+    bool pool_failed = false, pool_dl_failed = false;
     int stage_threads = 7;      /* helper threads of the staging copies (K4LZ4_STAGE_THREADS - 1, read once at creation) */
     /* diagnostic switches, read once at creation: K4LZ4_SPLIT_PCT (1..100, share of an encode batch on the LDS-table kernel),
      * K4LZ4_NO_PAIR (decode with one wave per block) */
@@ -482,6 +483,16 @@ Pool *pool_of(k4lz4_ctx *ctx)
     return ctx->pool;
 }
 
+Pool *pool_dl_of(k4lz4_ctx *ctx)
+{
+    if (!ctx->pool_dl && !ctx->pool_dl_failed) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int nthreads = (int)std::min<unsigned>((unsigned)ctx->stage_threads, hw > 2 ? hw / 2 - 1 : 0u);
+        try { ctx->pool_dl = new Pool(nthreads); } catch (...) { ctx->pool_dl = nullptr; ctx->pool_dl_failed = true; }
+    }
+    return ctx->pool_dl;
+}
+
 /* memcpy split over the helper threads */
 void parallel_copy(k4lz4_ctx *ctx, uint8_t *d, const uint8_t *s, size_t nbytes)
 {
@@ -562,7 +573,7 @@ int staged_upload_packed(k4lz4_ctx *ctx, uint8_t *d_dst, const uint8_t *h_base, 
 /* device -> the caller's slots: block i's stored[i] bytes sit at d_from + from_off[i]; chunks of whole blocks come over
  * into a pinned buffer while the previous chunk is scattered into the slots by the helper threads */
 int staged_download(k4lz4_ctx *ctx, uint8_t *dst, const uint64_t *dstOff, const uint8_t *d_from, const uint64_t *from_off,
-                    const int32_t *stored, int64_t n, hipStream_t st)
+                    const int32_t *stored, int64_t n, hipStream_t st, Pool *p)
 {
     struct Chunk { int64_t first, last; uint64_t lo, hi; };
     std::vector<Chunk> chunks;
@@ -587,7 +598,6 @@ int staged_download(k4lz4_ctx *ctx, uint8_t *dst, const uint64_t *dstOff, const 
         if ((rc = grow(ctx, &ctx->h_out[b], &ctx->h_out_cap[b], biggest + 64, true)) != K4LZ4_OK) return rc;
     auto scatter = [&](const Chunk &c, const uint8_t *buf) {
         const int64_t cnt = c.last - c.first + 1;
-        Pool *p = pool_of(ctx);
         const int parts = p && (c.hi - c.lo) >= ((uint64_t)2 << 20) ? (int)std::min<int64_t>((int64_t)p->workers.size() + 1, cnt) : 1;
         auto body = [&, parts](int part) {
             const int64_t a = c.first + cnt * part / parts, e = c.first + cnt * (part + 1) / parts;
@@ -627,6 +637,7 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
         const std::string why = ctx->error;
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         if (ctx->copyq) (void)hipStreamSynchronize(ctx->copyq);
+        if (ctx->dlq) (void)hipStreamSynchronize(ctx->dlq);
         if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
         (void)hipGetLastError();
         (void)take_device_status(ctx);
@@ -692,15 +703,29 @@ int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t
      * to one part (their launches size scratch and synchronise on their own). */
     const uint64_t up_bytes = packed ? packed_bytes : (uint64_t)span;
     const bool hc = (kind == KIND_ENCODE || kind == KIND_PICKLE) && level >= K4LZ4_L03_HC;
-    int64_t cut = n;
+    /* Encoders: two parts (a part's kernels last as long as their slowest block whatever their number, and the parts' kernels
+     * run one after the other).  Decoders, whose kernels are short: four, so that more of the way up and of the way down
+     * overlap. */
+    int nparts = 1;
+    int64_t part_lo[4] = {0, n, n, n}, part_hi[4] = {n, n, n, n};
     if (n >= 1024 && up_bytes >= 4 * STAGE_CHUNK && (packed || ascending) && !hc && !(hd && hd->dict)) {
+        const bool decode_like = kind == KIND_DECODE || kind == KIND_UNPICKLE;
+        const int want = decode_like && n >= 2048 && up_bytes >= 8 * STAGE_CHUNK ? 4 : 2;
+        int64_t cuts[5] = {0, n, n, n, n};
         uint64_t acc = 0;
-        for (cut = 0; cut < n && acc < up_bytes / 2; cut++) acc += srcLen[cut] > 0 ? (((uint64_t)srcLen[cut] + 15u) & ~(uint64_t)15u) : 0u;
-        if (cut < 256 || n - cut < 256) cut = n;
+        int k = 1;
+        for (int64_t i = 0; i < n && k < want; i++) {
+            acc += srcLen[i] > 0 ? (((uint64_t)srcLen[i] + 15u) & ~(uint64_t)15u) : 0u;
+            if (acc >= up_bytes * (uint64_t)k / (uint64_t)want) cuts[k++] = i + 1;
+        }
+        bool ok = k == want;
+        cuts[want] = n;
+        for (int q = 0; q < want && ok; q++) ok = cuts[q + 1] - cuts[q] >= 256;
+        if (ok) {
+            nparts = want;
+            for (int q = 0; q < want; q++) { part_lo[q] = cuts[q]; part_hi[q] = cuts[q + 1]; }
+        }
     }
-    const int nparts = cut < n ? 2 : 1;
-    const int64_t part_lo[2] = {0, cut}, part_hi[2] = {cut, n};
-
     const size_t meta_bytes = (size_t)n * (8 + 4 + 8 + 4 + 4 + 8);
     if ((rc = grow(ctx, &ctx->d_src, &ctx->d_src_cap, span + 64, false)) != K4LZ4_OK) return rc;
     if ((rc = grow(ctx, &ctx->d_dst, &ctx->d_dst_cap, (size_t)dtotal + 64, false)) != K4LZ4_OK) return rc;
@@ -754,43 +779,24 @@ int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t
     }
     lap("prepare");
 
-    /* ---- up and launch, part by part: the host stages part 2 while part 1's kernels run ---- */
-    for (int p = 0; p < nparts; p++) {
-        const int64_t b0 = part_lo[p], b1 = part_hi[p], cnt = b1 - b0;
-        if (packed) {
-            if ((rc = staged_upload_packed(ctx, ctx->d_src, src, srcOff, srcLen, b0, b1, h_soff.data(), cq)) != K4LZ4_OK) return rc;
-        } else {
-            /* ascending blocks (or one part): this part's stretch of the span */
-            uint64_t a = UINT64_MAX, e = 0;
-            for (int64_t i = b0; i < b1; i++)
-                if (srcLen[i] > 0) { a = std::min(a, h_soff[(size_t)i]); e = std::max(e, h_soff[(size_t)i] + (uint64_t)srcLen[i]); }
-            if (nparts == 1) { a = 0; e = span; }
-            if (a != UINT64_MAX && e > a && (rc = staged_upload(ctx, ctx->d_src + a, src + lo + a, (size_t)(e - a), cq)) != K4LZ4_OK) return rc;
-        }
-        if (cq != st) {
-            K4_HIP(ctx, hipEventRecord(ctx->ev_up[p], cq));
-            K4_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_up[p], 0));
-        }
-        DictArgs dpart = ddev;
-        rc = launch(ctx, kind, ctx->d_src, d_soff + b0, d_slen + b0, ctx->d_dst, d_doff + b0, d_cap + b0, d_out + b0, cnt, level, flags, st,
-                    &dpart, srcLen + b0);
-        if (rc != K4LZ4_OK) return rc;
-        K4_HIP(ctx, hipMemcpyAsync(h_len + b0, d_out + b0, (size_t)cnt * 4, hipMemcpyDeviceToHost, st));
-        K4_HIP(ctx, hipEventRecord(ctx->ev_len[p], st));
-        lap(p == 0 ? "up+launch" : "up+launch2");
-    }
-
-    /* ---- down, part by part.  What each block produced is packed next to each other on the device (when that saves a tenth
-     * or more of the transfer) and comes back through the pinned buffers in chunks cut at block boundaries; exactly
-     * outLen[i] bytes land in each caller slot ---- */
+    /* ---- The way back, part by part.  What each block produced is packed next to each other on the device (when that saves a
+     * tenth or more of the transfer) and comes back through the pinned buffers in chunks cut at block boundaries; exactly
+     * outLen[i] bytes land in each caller slot.  With more than one part this runs on a thread of its own (own queue, own
+     * pinned buffers, own helper threads) while this thread stages and launches the later parts: PCIe carries both ways at
+     * once, and so do the host's copies.  `launched` says how many parts have had their kernels and their ev_len enqueued. ---- */
     const bool raw_negative = (flags & K4LZ4_FLAG_ALLOW_COPY) && kind == KIND_ENCODE;
     std::vector<uint64_t> h_poff((size_t)n);
     std::vector<int32_t> stored((size_t)n);
-    uint64_t pack_base = 0;
-    for (int p = 0; p < nparts; p++) {
+    if (nparts > 1 && (rc = grow(ctx, &ctx->d_pack, &ctx->d_pack_cap, (size_t)dtotal + 64, false)) != K4LZ4_OK) return rc;
+    hipStream_t dq = nparts > 1 ? ctx->dlq : st;
+    std::mutex dm;
+    std::condition_variable dcv;
+    int launched = 0;                       /* guarded by dm */
+    bool abandon = false;                   /* the staging side failed: the way back stops waiting */
+    std::string dl_error;
+    auto download_part = [&](int p, uint64_t &pack_base) -> int {
         const int64_t b0 = part_lo[p], b1 = part_hi[p], cnt = b1 - b0;
         K4_HIP(ctx, hipEventSynchronize(ctx->ev_len[p]));
-        lap(p == 0 ? "kernels" : "kernels2");
         memcpy(outLen + b0, h_len + b0, (size_t)cnt * 4);
         uint64_t used = 0, cap_total = 0;
         for (int64_t i = b0; i < b1; i++) {
@@ -804,21 +810,87 @@ int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t
         }
         const uint8_t *d_from = ctx->d_dst;
         const uint64_t *from_off = h_doff.data() + b0;
-        if (cq != st) K4_HIP(ctx, hipStreamWaitEvent(cq, ctx->ev_len[p], 0));    /* this part's kernels are through */
+        if (dq != st) K4_HIP(ctx, hipStreamWaitEvent(dq, ctx->ev_len[p], 0));    /* this part's kernels are through */
         if (cnt > 1 && used + (used >> 3) < cap_total) {
-            if ((rc = grow(ctx, &ctx->d_pack, &ctx->d_pack_cap, (size_t)dtotal + 64, false)) != K4LZ4_OK) return rc;
-            K4_HIP(ctx, hipMemcpyAsync(d_poff + b0, h_poff.data() + b0, (size_t)cnt * 8, hipMemcpyHostToDevice, cq));
-            hipLaunchKernelGGL(k4::k4_compact_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, cq, ctx->d_dst, d_doff + b0, d_out + b0,
+            int rc2;
+            if (nparts == 1 && (rc2 = grow(ctx, &ctx->d_pack, &ctx->d_pack_cap, (size_t)dtotal + 64, false)) != K4LZ4_OK) return rc2;
+            K4_HIP(ctx, hipMemcpyAsync(d_poff + b0, h_poff.data() + b0, (size_t)cnt * 8, hipMemcpyHostToDevice, dq));
+            hipLaunchKernelGGL(k4::k4_compact_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, dq, ctx->d_dst, d_doff + b0, d_out + b0,
                                ctx->d_pack, d_poff + b0, (long long)cnt, raw_negative ? 1 : 0);
             K4_HIP(ctx, hipGetLastError());
             d_from = ctx->d_pack;
             from_off = h_poff.data() + b0;
         }
         pack_base += used;
-        rc = staged_download(ctx, dst, dstOff + b0, d_from, from_off, stored.data() + b0, cnt, cq);
-        if (rc != K4LZ4_OK) return rc;
-        lap(p == 0 ? "download" : "download2");
+        return staged_download(ctx, dst, dstOff + b0, d_from, from_off, stored.data() + b0, cnt, dq, nparts > 1 ? pool_dl_of(ctx) : pool_of(ctx));
+    };
+    int dl_rc = K4LZ4_OK;
+    auto download_all = [&]() {
+        (void)hipSetDevice(ctx->device);
+        uint64_t pack_base = 0;
+        for (int p = 0; p < nparts; p++) {
+            {
+                std::unique_lock<std::mutex> lk(dm);
+                dcv.wait(lk, [&] { return launched > p || abandon; });
+                if (launched <= p) return;
+            }
+            const int r = download_part(p, pack_base);
+            if (r != K4LZ4_OK) { dl_rc = r; dl_error = ctx->error; return; }
+        }
+        if (hipStreamSynchronize(dq) != hipSuccess) { (void)hipGetLastError(); dl_rc = K4LZ4_E_HIP; dl_error = "download queue failed"; }
+    };
+    std::thread dl_thread;
+    bool threaded = false;
+    if (nparts > 1) {
+        try { dl_thread = std::thread(download_all); threaded = true; } catch (...) { threaded = false; }   /* no thread to be had: in line, below */
     }
+    auto finish = [&](int up_rc) -> int {   /* every way out of the staging loop comes through here */
+        if (threaded) {
+            { std::lock_guard<std::mutex> g(dm); if (up_rc != K4LZ4_OK) abandon = true; }
+            dcv.notify_all();
+            dl_thread.join();
+        } else if (up_rc == K4LZ4_OK) {
+            { std::lock_guard<std::mutex> g(dm); launched = nparts; }
+            download_all();
+        }
+        if (up_rc != K4LZ4_OK) return up_rc;
+        if (dl_rc != K4LZ4_OK) return fail(ctx, dl_rc, dl_error);
+        return K4LZ4_OK;
+    };
+
+    /* ---- up and launch, part by part: the host stages part k + 1 while part k's kernels run ---- */
+    for (int p = 0; p < nparts; p++) {
+        const int64_t b0 = part_lo[p], b1 = part_hi[p], cnt = b1 - b0;
+        if (packed) {
+            if ((rc = staged_upload_packed(ctx, ctx->d_src, src, srcOff, srcLen, b0, b1, h_soff.data(), cq)) != K4LZ4_OK) return finish(rc);
+        } else {
+            /* ascending blocks (or one part): this part's stretch of the span */
+            uint64_t a = UINT64_MAX, e = 0;
+            for (int64_t i = b0; i < b1; i++)
+                if (srcLen[i] > 0) { a = std::min(a, h_soff[(size_t)i]); e = std::max(e, h_soff[(size_t)i] + (uint64_t)srcLen[i]); }
+            if (nparts == 1) { a = 0; e = span; }
+            if (a != UINT64_MAX && e > a && (rc = staged_upload(ctx, ctx->d_src + a, src + lo + a, (size_t)(e - a), cq)) != K4LZ4_OK) return finish(rc);
+        }
+        hipError_t he = hipSuccess;
+        if (cq != st) {
+            he = hipEventRecord(ctx->ev_up[p], cq);
+            if (he == hipSuccess) he = hipStreamWaitEvent(st, ctx->ev_up[p], 0);
+            if (he != hipSuccess) return finish(hip_fail(ctx, he, "hipEventRecord"));
+        }
+        DictArgs dpart = ddev;
+        rc = launch(ctx, kind, ctx->d_src, d_soff + b0, d_slen + b0, ctx->d_dst, d_doff + b0, d_cap + b0, d_out + b0, cnt, level, flags, st,
+                    &dpart, srcLen + b0);
+        if (rc != K4LZ4_OK) return finish(rc);
+        he = hipMemcpyAsync(h_len + b0, d_out + b0, (size_t)cnt * 4, hipMemcpyDeviceToHost, st);
+        if (he == hipSuccess) he = hipEventRecord(ctx->ev_len[p], st);
+        if (he != hipSuccess) return finish(hip_fail(ctx, he, "hipMemcpyAsync"));
+        { std::lock_guard<std::mutex> g(dm); launched = p + 1; }
+        dcv.notify_all();
+        lap(p == 0 ? "up+launch" : "up+launch+");
+    }
+    rc = finish(K4LZ4_OK);
+    lap("down");
+    if (rc != K4LZ4_OK) return rc;
     K4_HIP(ctx, hipStreamSynchronize(st));
     if (cq != st) K4_HIP(ctx, hipStreamSynchronize(cq));
     return take_device_status(ctx);
@@ -922,9 +994,12 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     for (int b = 0; b < 2 && e == hipSuccess; b++) {
         e = hipEventCreateWithFlags(&ctx->ev_in[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_out[b], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_up[b], hipEventDisableTiming);
+    }
+    for (int b = 0; b < 4 && e == hipSuccess; b++) {
+        e = hipEventCreateWithFlags(&ctx->ev_up[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_len[b], hipEventDisableTiming);
     }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->dlq, hipStreamNonBlocking);
     if (const char *pct = getenv("K4LZ4_SPLIT_PCT")) { const int v = atoi(pct); ctx->split_pct = v < 1 ? 1 : (v > 100 ? 100 : v); }
     ctx->no_pair = getenv("K4LZ4_NO_PAIR") != nullptr;
     if (const char *e = getenv("K4LZ4_STAGE_THREADS")) ctx->stage_threads = std::max(0, std::min(63, atoi(e) - 1));
@@ -945,16 +1020,20 @@ void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
     if (ctx->ev_busy) (void)hipEventDestroy(ctx->ev_busy);
     for (int b = 0; b < 2; b++) {
         if (ctx->ev_in[b]) (void)hipEventDestroy(ctx->ev_in[b]);
-        if (ctx->ev_up[b]) (void)hipEventDestroy(ctx->ev_up[b]);
-        if (ctx->ev_len[b]) (void)hipEventDestroy(ctx->ev_len[b]);
         if (ctx->ev_out[b]) (void)hipEventDestroy(ctx->ev_out[b]);
         if (ctx->h_in[b]) (void)hipHostFree(ctx->h_in[b]);
         if (ctx->h_out[b]) (void)hipHostFree(ctx->h_out[b]);
     }
     if (ctx->d_pack) (void)hipFree(ctx->d_pack);
     if (ctx->h_len) (void)hipHostFree(ctx->h_len);
+    for (int b = 0; b < 4; b++) {
+        if (ctx->ev_up[b]) (void)hipEventDestroy(ctx->ev_up[b]);
+        if (ctx->ev_len[b]) (void)hipEventDestroy(ctx->ev_len[b]);
+    }
     if (ctx->copyq) (void)hipStreamDestroy(ctx->copyq);
+    if (ctx->dlq) (void)hipStreamDestroy(ctx->dlq);
     delete ctx->pool;
+    delete ctx->pool_dl;
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
     if (ctx->d_dict) (void)hipFree(ctx->d_dict);
