@@ -403,11 +403,18 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
                 {
                     k4::BatchArgs al = a;
                     al.n = n_lds;
-                    hipLaunchKernelGGL(k4::k4_encode_fast_kernel, dim3((unsigned)((n_lds + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)),
-                                       dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, al);
+                    if (n_g == 0 && cnt <= lds_slots)
+                        hipLaunchKernelGGL(k4::k4_encode_fast_more_kernel, dim3((unsigned)((n_lds + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)),
+                                           dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, al);
+                    else
+                        hipLaunchKernelGGL(k4::k4_encode_fast_kernel, dim3((unsigned)((n_lds + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)),
+                                           dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, al);
                 }
                 K4_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_join, 0));
             }
+            else if (cnt <= 8 * (int64_t)ctx->cu_count)       /* a half-empty chip: the variant that buys latency with instructions */
+                hipLaunchKernelGGL(k4::k4_encode_fast_more_kernel, dim3((unsigned)((cnt + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)),
+                                   dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, a);
             else hipLaunchKernelGGL(k4::k4_encode_fast_kernel, dim3((unsigned)((cnt + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)),
                                     dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, a);
             break;

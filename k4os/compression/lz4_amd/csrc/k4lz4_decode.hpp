@@ -40,10 +40,19 @@
 
 namespace k4 {
 
-constexpr int DECODE_STAGE_BYTES = 2048;          /* a batch's output, kept in LDS while its matches resolve */
+#ifndef K4_DEC_STAGE
+#define K4_DEC_STAGE 2048
+#endif
+#ifndef K4_DEC_SOFT
+#define K4_DEC_SOFT (K4_DEC_STAGE - 512)
+#endif
+#ifndef K4_DEC_WAVE_AT
+#define K4_DEC_WAVE_AT 128
+#endif
+constexpr int DECODE_STAGE_BYTES = K4_DEC_STAGE;          /* a batch's output, kept in LDS while its matches resolve */
 constexpr int DECODE_LDS_DWORDS = RING_DWORDS + 5 * 64 + (DECODE_STAGE_BYTES + 64) / 4;   /* ring + 5 descriptor arrays + stage */
 constexpr int MAX_SEQ_PER_ROUND = 22;            /* 64 hypotheses, >= 3 stream bytes per sequence */
-constexpr int DECODE_BATCH_SOFT_BYTES = DECODE_STAGE_BYTES - 512;   /* PARSE stops adding to a batch beyond this many output bytes */
+constexpr int DECODE_BATCH_SOFT_BYTES = K4_DEC_SOFT;   /* PARSE stops adding to a batch beyond this many output bytes */
 
 /* PARSE's serial part: from hypothesis 0 follow the `next` links while the hypotheses are usable and stay inside
  * the 64-lane window; T collects the real sequences, idx ends on the first position not taken.  A lane's word:
@@ -662,7 +671,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             const uint32_t n = later ? v_mlen - before : 0u;
             const uint32_t dst_s = mdst + before - o0, src_s = msrc + before - o0;
             const bool overlap = later && v_moff < v_mlen;
-            const bool by_wave = later && (n > 128u || (overlap && v_moff < 8u));
+            const bool by_wave = later && (n > (uint32_t)K4_DEC_WAVE_AT || (overlap && v_moff < 8u));
             const uint32_t piece = overlap && v_moff < LANE_COPY_MAX ? v_moff : LANE_COPY_MAX;    /* what one round of the lane may move */
             uint32_t moved = 0;
             unsigned long long pend = __ballot(later);

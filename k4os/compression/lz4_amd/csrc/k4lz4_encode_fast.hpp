@@ -128,18 +128,30 @@ __device__ __forceinline__ Around load_around(const uint8_t *src, uint32_t p)
 __device__ __forceinline__ unsigned long long geq_of(uint32_t q) { return ~0ull << q; }
 
 /* What the 16+16 bytes around a position and its candidate say about the match extension:
- * bits 0-3 forward bytes beyond MINMATCH (0..8, capped at fwd_max), bits 4-6 equal bytes backwards
- * (0..4), 0x100 forward run continues past the 8 known bytes, 0x200 the 4 bytes before both are known */
+ * bits 0-4 forward bytes beyond MINMATCH (0..8, or 0..24 with the 16 further bytes `ax` / `bx` of both, `more`; capped at
+ * fwd_max), bits 5-7 equal bytes backwards (0..4), 0x100 forward run continues past the known bytes, 0x200 the 4 bytes
+ * before both are known */
+constexpr uint32_t EXT_FWD_MASK = 31u, EXT_BACK_SHIFT = 5u;
 __device__ __forceinline__ uint32_t extension_info(uint32_t a_pre, uint32_t a_n0, uint32_t a_n1, bool a_ok, uint32_t b_pre, uint32_t b_n0,
-                                                   uint32_t b_n1, bool b_ok, uint32_t fwd_max)
+                                                   uint32_t b_n1, bool b_ok, uint32_t fwd_max, bool more = false,
+                                                   uint4 ax = make_uint4(0u, 0u, 0u, 0u), uint4 bx = make_uint4(0u, 0u, 0u, 0u))
 {
     const uint32_t x0 = a_n0 ^ b_n0, x1 = a_n1 ^ b_n1;
-    const uint32_t e = x0 ? (uint32_t)(__ffs((int)x0) - 1) >> 3 : (x1 ? 4u + ((uint32_t)(__ffs((int)x1) - 1) >> 3) : 8u);
-    const uint32_t c8 = e < fwd_max ? e : fwd_max;
+    uint32_t e = x0 ? (uint32_t)(__ffs((int)x0) - 1) >> 3 : (x1 ? 4u + ((uint32_t)(__ffs((int)x1) - 1) >> 3) : 8u);
+    uint32_t known = 8u;
+    if (more) {
+        const uint32_t y0 = ax.x ^ bx.x, y1 = ax.y ^ bx.y, y2 = ax.z ^ bx.z, y3 = ax.w ^ bx.w;
+        const uint32_t e2 = y0 ? (uint32_t)(__ffs((int)y0) - 1) >> 3
+                               : y1 ? 4u + ((uint32_t)(__ffs((int)y1) - 1) >> 3)
+                                    : y2 ? 8u + ((uint32_t)(__ffs((int)y2) - 1) >> 3) : y3 ? 12u + ((uint32_t)(__ffs((int)y3) - 1) >> 3) : 16u;
+        if (e == 8u) e += e2;
+        known = 24u;
+    }
+    const uint32_t c = e < fwd_max ? e : fwd_max;
     const bool ok = a_ok && b_ok;
     const uint32_t y = a_pre ^ b_pre;
     const uint32_t nb = ok ? (y ? (uint32_t)__clz(y) >> 3 : 4u) : 0u;
-    return c8 | (nb << 4) | ((e == 8u && fwd_max > 8u) ? 0x100u : 0u) | (ok ? 0x200u : 0u);
+    return c | (nb << EXT_BACK_SHIFT) | ((e == known && fwd_max > known) ? 0x100u : 0u) | (ok ? 0x200u : 0u);
 }
 
 /* The serial part of a round: from cursor lane q follow stop -> end of its match -> next stop, until a stop whose
@@ -303,7 +315,7 @@ __device__ __forceinline__ void hop_chain_pairs(unsigned long long &hmx, unsigne
  * After 64 misses the schedule's step grows (LL64.fast.cs:156-172); those rounds probe the strided
  * positions and stop at their first sequence.
  */
-template <bool BYU16, bool PROF = false, bool X32 = false, bool PAIRS = true>
+template <bool BYU16, bool PROF = false, bool X32 = false, bool PAIRS = true, bool MORE = false>
 __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
                                                  uint32_t accel, uint32_t *ldsw, int lane, unsigned long long *pc = nullptr,
                                                  bool dry = false, uint32_t *seq_count = nullptr, uint32_t *gtab = nullptr)
@@ -433,6 +445,11 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
         uint32_t pos_n;
         bool valid_n;
         Around pa_n;
+        /* MORE: the 16 source bytes after those (positions 12 .. 27 behind the probe), where the block has them: matches of
+         * up to 28 bytes are then measured from registers, and only longer ones cost a trip to memory in the middle of the
+         * chain (LL64.fast.cs:326-329).  Loaded unconditionally at a clamped address, like the others. */
+        uint4 px_n = make_uint4(0u, 0u, 0u, 0u);
+        bool more_n = false;
         auto prepare = [&]() {
             const bool fresh_n = jbase == 0u;
             const uint32_t sbase_n = fresh_n ? (test ? ip + 1u : ip) : sbase;
@@ -452,6 +469,11 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
              * predicated region gets its result copied into the merged registers right there, and the copy waits for it --
              * the loads would not fly during commit and emission at all */
             pa_n = load_around(src, valid_n ? pos_n : 0u);
+            if (MORE) {
+                more_n = valid_n && U >= 28u && pos_n <= U - 28u;
+                const U128u v = ld128u(src + (more_n ? pos_n + 12u : 0u));
+                px_n = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+            }
         };
         prepare();
 
@@ -466,6 +488,8 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             const uint32_t pos = pos_n;
             const bool valid = valid_n;
             const Around pa = pa_n;
+            const uint4 px = px_n;
+            const bool more = MORE && more_n && U >= 16u;
             if (shift && lane == 0) {
                 /* :394 -- the put of ip - 2.  Lane 0 probes ip itself and holds the 4 bytes before it: the bytes at
                  * ip - 2 come out of its registers, not out of another trip to memory at the top of every such round */
@@ -484,6 +508,11 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             }
             const Around ca = load_around(src, cand);       /* the round's one dependent trip to memory: everything below that
                                                              * does not need the candidate bytes runs while it is under way */
+            uint4 cx = make_uint4(0u, 0u, 0u, 0u);
+            if (MORE) {                                     /* (cand < pos, so cand + 28 <= U where pos + 28 <= U) */
+                const U128u v = ld128u(src + (more ? cand + 12u : 0u));
+                cx = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+            }
 
             /* ---------------- groups: lanes of the window with equal hashes ---------------- */
             unsigned long long G = me;
@@ -512,7 +541,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             const unsigned long long cand0 = __ballot((G & ~(below_me | me)) != 0ull);
             /* now the candidate bytes */
             const bool hit_tab = valid && (BYU16 || cand + (uint32_t)DISTANCE_MAX >= pos) && ca.seq == pa.seq;
-            const uint32_t info = extension_info(pa.pre, pa.n0, pa.n1, pa.pre_ok, ca.pre, ca.n0, ca.n1, ca.pre_ok, fwd_max);
+            const uint32_t info = extension_info(pa.pre, pa.n0, pa.n1, pa.pre_ok, ca.pre, ca.n0, ca.n1, ca.pre_ok, fwd_max, more, px, cx);
             /* per lane: the candidate as the table and the visited positions of this round define it */
             uint32_t cpos = cand, cinfo = info;
             bool chit = hit_tab;
@@ -556,7 +585,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             auto publish = [&]() {
                 hmx = __ballot(chit) | inv_m;
                 const bool counted = xcode != 0xffffffffu;          /* this lane's long match has been measured already */
-                const uint32_t c8 = counted ? xcode : (cinfo & 15u);
+                const uint32_t c8 = counted ? xcode : (cinfo & EXT_FWD_MASK);
                 epos = pos + MINMATCH + c8;
                 /* a visited-or-future lane with a later lane in its group may be that lane's candidate */
                 cand_m = cand0 & ~lost_cands;
@@ -581,7 +610,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
              * lane with several stops the chain the moment it would go by its second word (0x1000) and the candidates are
              * then worked out in full (`general`) for the rest of the round. */
             const bool many = (gb & (gb - 1ull)) != 0ull;
-            const uint32_t hop_tab = many ? 0x1040u : (dirty ? hop_word(info & 15u, info & 0x100u) : hopv);
+            const uint32_t hop_tab = many ? 0x1040u : (dirty ? hop_word(info & EXT_FWD_MASK, info & 0x100u) : hopv);
             const unsigned long long hmB = dirty ? (__ballot(hit_tab || many) | inv_m) : hmx;
             const uint32_t j1c = 63u - (uint32_t)(j1 >= 0 ? j1 : lane);
             const unsigned long long ta = prof_now<PROF>();
@@ -612,7 +641,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                         chit = hit_tab;
                         cpos = cand;
                         cinfo = info;
-                        epos = pos + MINMATCH + (info & 15u);
+                        epos = pos + MINMATCH + (info & EXT_FWD_MASK);
                     }
                 }
                 if (PROF) t_rec += prof_now<PROF>() - tr0;
@@ -641,12 +670,14 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 /* a lane the chain itself has switched to its table candidate still holds the first one in cpos / epos */
                 const bool second = PAIRS && !general && ((hv & 0x100u) || qn == 127u) && (long long)(lost_cands << readlane_u32(j1c, f)) < 0;
                 uint32_t e_end = qn < 127u ? ip0 + qn
-                                           : (second ? readlane_u32(pos, f) + MINMATCH + (readlane_u32(info, f) & 15u) : readlane_u32(epos, f));
+                                           : (second ? readlane_u32(pos, f) + MINMATCH + (readlane_u32(info, f) & EXT_FWD_MASK) : readlane_u32(epos, f));
                 if (hv & 0x100u) {                                  /* :326-329 beyond the 12 known bytes */
                     if (PROF) n_rt3++;
                     const uint32_t p = readlane_u32(pos, f);
                     const uint32_t match = second ? readlane_u32(cand, f) : readlane_u32(cpos, f);
-                    const uint32_t code = 8u + wave_count(src + p + MINMATCH + 8u, src + match + MINMATCH + 8u, matchlimit - (p + MINMATCH) - 8u, lane);
+                    /* the bytes already compared: 8, or 24 where the lane had them (a flagged lane's count sits at what it knew) */
+                    const uint32_t kn = (second ? readlane_u32(info, f) : readlane_u32(cinfo, f)) & EXT_FWD_MASK;
+                    const uint32_t code = kn + wave_count(src + p + MINMATCH + kn, src + match + MINMATCH + kn, matchlimit - (p + MINMATCH) - kn, lane);
                     e_end = p + MINMATCH + code;
                     const uint32_t qf = e_end - ip0;
                     if (lane == f) { xcode = code; hopv = (hopv & ~127u) | (contig && qf < 127u ? qf : 127u); }
@@ -695,8 +726,8 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             if (k && !dry) {
                 if (mine) {
                     const uint32_t slot = (rec_head + rec_count + (uint32_t)__popcll(hits & below_me)) & (REC_SLOTS - 1u);
-                    const uint32_t code = xcode != 0xffffffffu ? xcode : (cinfo & 15u);
-                    const uint32_t binfo = ((cinfo >> 4) & 7u) | ((cinfo & 0x200u) ? 8u : 0u);
+                    const uint32_t code = xcode != 0xffffffffu ? xcode : (cinfo & EXT_FWD_MASK);
+                    const uint32_t binfo = ((cinfo >> EXT_BACK_SHIFT) & 7u) | ((cinfo & 0x200u) ? 8u : 0u);
                     rec[slot] = make_uint2(pos, (pos - cpos) | (binfo << 16) | ((code < REC_CODE_MAX ? code : REC_CODE_MAX) << 20));
                 }
                 rec_count += k;
@@ -748,14 +779,14 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
 }
 
 /* LL64.LZ4_compress_fast (LL64.fast.cs:517-576): table type by input size */
-template <bool PAIRS = true>
+template <bool PAIRS = true, bool MORE = false>
 __device__ __forceinline__ int compress_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
                                                    int accel, uint32_t *ldsw, int lane, uint32_t *gtab = nullptr, bool x32 = false)
 {
     const uint32_t a = accel < 1 ? 1u : (accel > 65536 ? 65536u : (uint32_t)accel);
-    if (src_len < LIMIT_64K) return encode_fast_block<true, false, false, PAIRS>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
-    if (x32) return encode_fast_block<false, false, true, PAIRS>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
-    return encode_fast_block<false, false, false, PAIRS>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
+    if (src_len < LIMIT_64K) return encode_fast_block<true, false, false, PAIRS, MORE>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
+    if (x32) return encode_fast_block<false, false, true, PAIRS, MORE>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
+    return encode_fast_block<false, false, false, PAIRS, MORE>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
 }
 
 /* LZ4Codec.Encode mapping (LZ4Codec.cs:40-52) */
@@ -822,9 +853,9 @@ __global__ __launch_bounds__(256) void k4_order_kernel(BatchArgs a)
 }
 
 constexpr int ENCODE_WAVES_PER_WG = 2;      /* blocks per workgroup; measured 1: 53.1, 2: 54.2, 4: 54.3 GiB/s on the bench batch */
-__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_num_vgpr(80))) void k4_encode_fast_kernel(BatchArgs a)
+template <bool MORE>
+__device__ __forceinline__ void encode_fast_kernel_body(const BatchArgs &a, uint32_t (*tabs)[ENCODE_LDS_DWORDS])
 {
-    __shared__ __attribute__((aligned(16))) uint32_t tabs[ENCODE_WAVES_PER_WG][ENCODE_LDS_DWORDS];
     const int lane = lane_id();
     const uint32_t wave = uni(threadIdx.x >> 6);
     const long long slot = (long long)blockIdx.x * ENCODE_WAVES_PER_WG + (long long)wave;
@@ -836,8 +867,25 @@ __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_num
     const uint8_t *src = a.src + a.srcOff[b];
     uint8_t *dst = a.dst + a.dstOff[b];
     int ret = 0;
-    if (src_len > 0 || (a.flags & FLAG_RAW_RETURN)) ret = compress_fast_block(src, src_len, dst, cap < 0 ? 0 : cap, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0);
+    if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
+        ret = compress_fast_block<true, MORE>(src, src_len, dst, cap < 0 ? 0 : cap, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0);
     if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
+}
+
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_num_vgpr(80))) void k4_encode_fast_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tabs[ENCODE_WAVES_PER_WG][ENCODE_LDS_DWORDS];
+    encode_fast_kernel_body<false>(a, tabs);
+}
+
+/* For batches that leave the chip half empty (at most 8 blocks per CU: every block's own latency is what counts, not the
+ * instruction slots it shares): the same kernel knowing 28 bytes behind every probe and candidate instead of 12, so that
+ * matches of up to 28 bytes are measured from registers.  +4.6 % on a 512-block batch; on the full 4096-block batch the
+ * 15 extra instructions per round and four more VGPRs cost 1.8 %, which is why it is a kernel of its own. */
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) void k4_encode_fast_more_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tabs[ENCODE_WAVES_PER_WG][ENCODE_LDS_DWORDS];
+    encode_fast_kernel_body<true>(a, tabs);
 }
 
 /* the same encoder with its hash table in global memory (a.gtab: 16 KiB per workgroup slot) and

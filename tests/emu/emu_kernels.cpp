@@ -74,6 +74,18 @@ int k4emu_encode_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t
     return 0;
 }
 
+/* the variant the launcher picks for half-empty batches: 28 known bytes behind every probe and candidate */
+int k4emu_encode_more_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                            const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int level,
+                            int accel, int flags, int threads)
+{
+    k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, accel, flags, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (n <= 0) return 0;
+    k4emu::launch_fn(dim3((unsigned)((n + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG),
+                     [=] { k4::k4_encode_fast_more_kernel(a); }, threads);
+    return 0;
+}
+
 /* the same blocks through the variant with its hash tables in (here: host) memory, 16 KiB per block */
 int k4emu_encode_gtab_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
                             const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int level,

@@ -52,6 +52,8 @@ class Emu:
         self.lib.k4emu_decode_batch.argtypes = b + [C.c_int, C.c_int]
         self.lib.k4emu_encode_batch.argtypes = b + [C.c_int, C.c_int, C.c_int, C.c_int]
         self.lib.k4emu_encode_gtab_batch.argtypes = b + [C.c_int, C.c_int, C.c_int, C.c_int]
+        self.lib.k4emu_encode_more_batch.argtypes = b + [C.c_int, C.c_int, C.c_int, C.c_int]
+        self.more = False      # True: encode_batch runs the 28-known-bytes variant of the LDS-table kernel
         self.lib.k4emu_decode_dict_batch.argtypes = b + [C.c_int, _u8p, C.c_void_p, C.c_void_p, C.c_int]
         self.lib.k4emu_decode_pair_batch.argtypes = b + [C.c_int, _u8p, C.c_void_p, C.c_void_p, C.c_int]
         self.pair = False      # True: decode_batch / decode_dict_batch run the two-waves-per-block kernel
@@ -84,9 +86,10 @@ class Emu:
         assert rc == 0
         return out
 
-    def encode_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, level=0, accel=1, flags=0, threads=0, gtab=False):
+    def encode_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, level=0, accel=1, flags=0, threads=0, gtab=False, more=False):
         out = np.full(len(src_len), -12345, dtype=np.int32)
-        rc = (self.lib.k4emu_encode_gtab_batch if gtab else self.lib.k4emu_encode_batch)(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
+        fn = self.lib.k4emu_encode_gtab_batch if gtab else (self.lib.k4emu_encode_more_batch if more or self.more else self.lib.k4emu_encode_batch)
+        rc = fn(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
                                          dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data,
                                          len(src_len), level, accel, flags, threads)
         assert rc == 0

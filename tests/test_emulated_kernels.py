@@ -35,14 +35,16 @@ def _fixture_blocks():
     return b
 
 
-@pytest.mark.parametrize("gtab", [False, True], ids=["lds_table", "global_table"])
-def test_encode_fast_matches_oracle(emu, oracle, gtab):
-    """both builds of the encoder: table in LDS (chain with the pair fall-back inside), table in memory (plain chain)"""
+@pytest.mark.parametrize("variant", ["lds_table", "global_table", "lds_table_28_known_bytes"])
+def test_encode_fast_matches_oracle(emu, oracle, variant):
+    """the three builds of the encoder: table in LDS (chain with the pair fall-back inside), table in memory (plain chain),
+    and the LDS-table kernel that knows 28 bytes behind every probe (what small batches run)"""
     blocks = _fixture_blocks()
+    blocks += [corpus.class_bytes(name, 65536, 21) for name in ("nci", "samba", "osdb", "xml")]      # matches of 13 .. 28 bytes and beyond
     src, soff, slen = pack(blocks)
     caps = [oracle.compress_bound(b.size) for b in blocks]
     dst, doff, dcap = arena(caps)
-    out = emu.encode_batch(src, soff, slen, dst, doff, dcap, gtab=gtab)
+    out = emu.encode_batch(src, soff, slen, dst, doff, dcap, gtab=variant == "global_table", more=variant.endswith("bytes"))
     for i, b in enumerate(blocks):
         want = oracle.encode(b)
         if b.size == 0:
@@ -467,6 +469,20 @@ def test_decode_with_dictionary_issue64_and_synthetic(emu, oracle):
         if n > 0:
             assert buf[d.size:d.size + n].tobytes() == ref[:n].tobytes(), i
         assert (buf[d.size + cap:] == 0xCD).all() and buf[:d.size].tobytes() == d.tobytes()
+
+
+def test_encode_random_stress_28_known_bytes(emu, oracle):
+    """the same stress through the small-batch variant of the LDS-table kernel (k4_encode_fast_more_kernel)"""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "emu_stress_encode.py")
+    spec = importlib.util.spec_from_file_location("emu_stress_encode", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    emu.more = True
+    try:
+        mod.run(2, 9, oracle, emu, verbose=False)
+    finally:
+        emu.more = False
 
 
 def test_encode_random_stress(emu, oracle):
