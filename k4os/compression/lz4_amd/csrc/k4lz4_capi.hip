@@ -42,6 +42,7 @@ struct k4lz4_ctx {
     int accel = 1;                  /* fast-encoder acceleration of the next launch (LLxx-level calls only) */
     unsigned long long *prof = nullptr;   /* diagnostic counters of the next launch (k4lz4_profile_batch_device) */
     bool prof_pair = false;               /* ... of the two-waves-per-block decoder (32 counters per block) */
+    bool prof_stamp = false;              /* ... or only start / end / placement of every block, written by the ordinary kernels */
     /* grow-only device / pinned scratch for the host-pointer calls */
     uint8_t *d_src = nullptr; size_t d_src_cap = 0;
     uint8_t *d_dst = nullptr; size_t d_dst_cap = 0;
@@ -84,6 +85,7 @@ struct k4lz4_ctx {
     uint32_t *d_status = nullptr;   /* this context's status word: DEV_STATUS_* bits raised by its kernels (k4lz4_common.hpp) */
     int split_pct = -1;
     bool no_pair = false;
+    bool prof_gtab = false;               /* K4LZ4_PROF_GTAB: the instrumented encoder keeps its table in global memory */
     bool trace = false;         /* K4LZ4_TRACE: host-pointer calls print where their time went (stderr) */
 };
 
@@ -371,7 +373,17 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
         const unsigned wg4 = (unsigned)((cnt + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
         switch (kind) {
         case KIND_ENCODE:
-            if (a.prof) hipLaunchKernelGGL(k4::k4_encode_fast_prof_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a);
+            if (a.prof && !ctx->prof_stamp) {
+                if (ctx->prof_gtab) {    /* diagnostics: the instrumented encoder with its table in global memory, like the global-table kernel */
+                    if ((size_t)cnt * 16384 > ctx->d_gtab_cap) {
+                        K4_HIP(ctx, hipStreamSynchronize(ctx->aux));
+                        int rc2 = grow(ctx, &ctx->d_gtab, &ctx->d_gtab_cap, (size_t)cnt * 16384, false);
+                        if (rc2 != K4LZ4_OK) return rc2;
+                    }
+                    a.gtab = (uint32_t *)ctx->d_gtab;
+                }
+                hipLaunchKernelGGL(k4::k4_encode_fast_prof_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a);
+            }
             else if (reorder && cnt > 512 && !(flags & K4LZ4_FLAG_NO_SPLIT)) {
                 /* Only 8 blocks per CU fit with their hash table in LDS.  The most expensive blocks
                  * (front of the dispatch order) take those slots; the others are encoded at the same
@@ -419,11 +431,11 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
                                     dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, a);
             break;
         case KIND_DECODE:
-            if (a.prof && ctx->prof_pair) {
+            if (a.prof && ctx->prof_pair && !ctx->prof_stamp) {
                 hipLaunchKernelGGL(k4::k4_decode_pair_prof_kernel, dim3((unsigned)((cnt + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
                                    dim3(128 * k4::DECODE_PAIRS_PER_WG), 0, stream, a);
             }
-            else if (a.prof) hipLaunchKernelGGL(k4::k4_decode_prof_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
+            else if (a.prof && !ctx->prof_stamp) hipLaunchKernelGGL(k4::k4_decode_prof_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
             else if (cnt > 24 * (int64_t)ctx->cu_count)   /* more blocks than can be resident (6 waves x 4 SIMDs per CU) */
                 hipLaunchKernelGGL(k4::k4_decode_dense_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
             else if (cnt <= 16 * (int64_t)ctx->cu_count && !ctx->no_pair) {
@@ -1009,6 +1021,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->dlq, hipStreamNonBlocking);
     if (const char *pct = getenv("K4LZ4_SPLIT_PCT")) { const int v = atoi(pct); ctx->split_pct = v < 1 ? 1 : (v > 100 ? 100 : v); }
     ctx->no_pair = getenv("K4LZ4_NO_PAIR") != nullptr;
+    ctx->prof_gtab = getenv("K4LZ4_PROF_GTAB") != nullptr;
     if (const char *e = getenv("K4LZ4_STAGE_THREADS")) ctx->stage_threads = std::max(0, std::min(63, atoi(e) - 1));
     ctx->trace = getenv("K4LZ4_TRACE") != nullptr;
     if (e != hipSuccess) { delete ctx; return hip_fail(nullptr, e, "hipStreamCreate"); }
@@ -1225,9 +1238,11 @@ int k4lz4_profile_batch_device(k4lz4_ctx *ctx, int decode, const uint8_t *src, c
     if (!ctx || !counters) return fail(ctx, K4LZ4_E_ARG, "bad argument");
     ctx->prof = (unsigned long long *)counters;
     ctx->prof_pair = decode == 2;        /* 2: the two-waves-per-block decoder, 32 counters per block (parsing wave, copying wave) */
-    const int rc = run_device(ctx, decode ? KIND_DECODE : KIND_ENCODE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n,
+    ctx->prof_stamp = decode >= 4;       /* 4 / 5: the ordinary encode / decode kernels, which only record [8] start, [9] end, [10] HW_ID, [11] kernel */
+    const int rc = run_device(ctx, (decode && decode != 4) ? KIND_DECODE : KIND_ENCODE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n,
                               K4LZ4_L00_FAST, 0, stream);
     ctx->prof = nullptr;
+    ctx->prof_stamp = false;
     return rc;
 }
 

@@ -121,6 +121,17 @@ template <bool PROF> __device__ __forceinline__ unsigned long long prof_now()
     return (unsigned long long)__builtin_readcyclecounter();
 }
 
+/* The lanes where `p` holds.  HIP's __ballot takes an int: the predicate is widened into a vector register and compared
+ * with zero again (two vector instructions per ballot where the predicate was a lane mask already); the builtin takes it as it is. */
+__device__ __forceinline__ unsigned long long ballot(bool p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(p);
+#else
+    return __ballot(p ? 1 : 0);
+#endif
+}
+
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 /* the builtin returns int: widening its result directly would sign-extend */
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane(v, l); }

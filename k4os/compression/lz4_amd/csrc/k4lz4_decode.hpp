@@ -435,9 +435,9 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 if (op + (int64_t)__builtin_amdgcn_readlane(incl, 63) <= oend - 64) {
                     /* every chosen sequence ends at least 64 bytes before the end of the output: the three
                      * end-of-block rules hold for all of them, only the offset can be wrong */
-                    bad = __ballot(in_t && offset > v_o + L);
+                    bad = ballot(in_t && offset > v_o + L);
                 } else {
-                    bad = __ballot(in_t && ((cls_g ? mdst_l > oend - MFLIMIT : v_o64 > shortoend) || (int64_t)offset > mdst_l ||
+                    bad = ballot(in_t && ((cls_g ? mdst_l > oend - MFLIMIT : v_o64 > shortoend) || (int64_t)offset > mdst_l ||
                                             (general && mdst_l + (int64_t)mlen > oend - MATCH_SAFEGUARD)));
                 }
                 int64_t cur_op;
@@ -624,7 +624,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
         const uint32_t o0 = (uint32_t)op_batch, T = (uint32_t)(op - op_batch);
         const bool has_m = mine && v_mlen != 0u;
         /* matches that start before the block (dictionary) keep the general path below */
-        const unsigned long long neg_m = __ballot(has_m && v_moff > v_out + v_llen);
+        const unsigned long long neg_m = ballot(has_m && v_moff > v_out + v_llen);
         unsigned long long t2 = t1;
         if (T <= (uint32_t)DECODE_STAGE_BYTES && neg_m == 0ull && !gap) {
             /* ======================= STAGED: the batch's output lives in LDS while it is assembled ==========
@@ -664,8 +664,8 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             if (PROF) c_search += prof_now<PROF>() - t1;
             if (mine && v_llen != 0u && !lit_long) lane_run_store(stg + (v_out - o0), L, v_llen);
             if (before != 0u && !bef_long) lane_run_store(stg + (mdst - o0), M, before);
-            if (__ballot(lit_long)) long_pieces(stg, w_out, in, v_lpos, lit_long ? v_llen : 0u, v_out - o0, lane);
-            if (__ballot(bef_long)) long_pieces(stg, w_out, out, msrc, bef_long ? before : 0u, mdst - o0, lane);
+            if (ballot(lit_long)) long_pieces(stg, w_out, in, v_lpos, lit_long ? v_llen : 0u, v_out - o0, lane);
+            if (ballot(bef_long)) long_pieces(stg, w_out, out, msrc, bef_long ? before : 0u, mdst - o0, lane);
             if (PROF) t2 = prof_now<PROF>();
             /* the part of every match that comes out of the stage: stage[src_s ..) -> stage[dst_s ..), `n` bytes */
             const uint32_t n = later ? v_mlen - before : 0u;
@@ -674,11 +674,11 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             const bool by_wave = later && (n > (uint32_t)K4_DEC_WAVE_AT || (overlap && v_moff < 8u));
             const uint32_t piece = overlap && v_moff < LANE_COPY_MAX ? v_moff : LANE_COPY_MAX;    /* what one round of the lane may move */
             uint32_t moved = 0;
-            unsigned long long pend = __ballot(later);
+            unsigned long long pend = ballot(later);
             while (pend) {
                 if (PROF) n_round++;
                 const bool ready = ((pend >> lane) & 1ull) != 0 && (deps & pend) == 0;
-                unsigned long long fin = __ballot(ready && by_wave);
+                unsigned long long fin = ballot(ready && by_wave);
                 lds_sync();
                 if (ready && !by_wave) {
                     const uint32_t c = n - moved < piece ? n - moved : piece;
@@ -689,7 +689,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                     const int g = ctz64(big);
                     stage_wave_copy(stg, readlane_u32(dst_s, g), readlane_u32(v_moff, g), readlane_u32(n, g), lane);
                 }
-                fin |= __ballot(ready && !by_wave && moved == n);
+                fin |= ballot(ready && !by_wave && moved == n);
                 pend &= ~fin;
             }
             lds_sync();
@@ -715,7 +715,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
         {
             if (mine && v_llen != 0u && v_llen <= LANE_COPY_MAX)
                 lane_copy32(out + v_out, in + v_lpos, v_llen, (uint32_t)src_size - v_lpos);
-            unsigned long long big = __ballot(mine && v_llen > LANE_COPY_MAX);
+            unsigned long long big = ballot(mine && v_llen > LANE_COPY_MAX);
             while (big) {
                 const int f = ctz64(big);
                 big &= big - 1;
@@ -752,16 +752,16 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
              * moved by the whole wave */
             const bool neg = has && v_moff > mdst;
             if (neg) deps = lane == 0 ? 0ull : ((1ull << lane) - 1ull);
-            const unsigned long long negmask = __ballot(neg);
+            const unsigned long long negmask = ballot(neg);
             const bool coop = v_mlen > LANE_COPY_MAX || v_moff < v_mlen || neg;
-            unsigned long long pend = __ballot(has);
+            unsigned long long pend = ballot(has);
             while (pend) {
                 if (PROF) n_round++;
                 const bool ready = ((pend >> lane) & 1ull) != 0 && (deps & pend) == 0;
-                const unsigned long long rmask = __ballot(ready);
+                const unsigned long long rmask = ballot(ready);
                 wave_sync();
                 if (ready && !coop) lane_copy32(out + mdst, out + msrc, v_mlen, (uint32_t)out_size - msrc);
-                unsigned long long big = __ballot(ready && coop);
+                unsigned long long big = ballot(ready && coop);
                 while (big) {
                     const int g = ctz64(big);
                     big &= big - 1;
@@ -871,11 +871,13 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
     const bool partial = (a.flags & FLAG_PARTIAL) != 0;
     const DecodeDict dict = block_dict(a, b, out);
     if (role == 0) {
+        if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 8, lane);
         if (run) decode_block<false, 1>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, nullptr, partial, dict, pipe);
     } else {
         int ret = 0;
         if (run) ret = decode_block<false, 2>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, nullptr, partial, dict, pipe);
         if (lane == 0) a.outLen[b] = codec_decode_result(src_len, ret, a.flags);
+        if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 9, lane);
     }
 }
 

@@ -24,6 +24,22 @@
 
 namespace k4 {
 
+#ifndef K4_N2
+#define K4_N2 1
+#endif
+#ifndef K4_GTAB_N2
+#define K4_GTAB_N2 0
+#endif
+#ifndef K4_GTAB_PAIRS
+#define K4_GTAB_PAIRS 0
+#endif
+#ifndef K4_GTAB_WPE
+#define K4_GTAB_WPE 6
+#endif
+#ifndef K4_GTAB_DUTY
+#define K4_GTAB_DUTY 3
+#endif
+
 /* TYPE 0: byU32 + hash5 (LL64), 1: byU16 + hash4, 2: byU32 + hash4 (LL32 in a 64-bit process, LZ4Codec.Enforce32) */
 template <int TYPE> struct FastTable;
 
@@ -79,7 +95,7 @@ __device__ __forceinline__ uint32_t wave_count(const uint8_t *a, const uint8_t *
             const uint32_t e = x ? (uint32_t)(__ffs(x) - 1) >> 3 : 4u;
             neq = e < avail ? e : avail;
         }
-        const unsigned long long notfull = __ballot(neq != 4u);
+        const unsigned long long notfull = ballot(neq != 4u);
         if (!notfull) { done += 256u; continue; }
         const int fl = ctz64(notfull);
         return done + 4u * (uint32_t)fl + __builtin_amdgcn_readlane(neq, fl);
@@ -128,17 +144,23 @@ __device__ __forceinline__ Around load_around(const uint8_t *src, uint32_t p)
 __device__ __forceinline__ unsigned long long geq_of(uint32_t q) { return ~0ull << q; }
 
 /* What the 16+16 bytes around a position and its candidate say about the match extension:
- * bits 0-4 forward bytes beyond MINMATCH (0..8, or 0..24 with the 16 further bytes `ax` / `bx` of both, `more`; capped at
- * fwd_max), bits 5-7 equal bytes backwards (0..4), 0x100 forward run continues past the known bytes, 0x200 the 4 bytes
- * before both are known */
+ * bits 0-4 forward bytes beyond MINMATCH (0..8; 0..12 where the four bytes after those are known as well, `has2` with `a_n2` /
+ * `b_n2`; 0..24 with the 16 further bytes `ax` / `bx` of both, `more`; capped at fwd_max), bits 5-7 equal bytes backwards
+ * (0..4), 0x100 forward run continues past the known bytes, 0x200 the 4 bytes before both are known */
 constexpr uint32_t EXT_FWD_MASK = 31u, EXT_BACK_SHIFT = 5u;
 __device__ __forceinline__ uint32_t extension_info(uint32_t a_pre, uint32_t a_n0, uint32_t a_n1, bool a_ok, uint32_t b_pre, uint32_t b_n0,
                                                    uint32_t b_n1, bool b_ok, uint32_t fwd_max, bool more = false,
-                                                   uint4 ax = make_uint4(0u, 0u, 0u, 0u), uint4 bx = make_uint4(0u, 0u, 0u, 0u))
+                                                   uint4 ax = make_uint4(0u, 0u, 0u, 0u), uint4 bx = make_uint4(0u, 0u, 0u, 0u),
+                                                   bool has2 = false, uint32_t a_n2 = 0u, uint32_t b_n2 = 0u)
 {
     const uint32_t x0 = a_n0 ^ b_n0, x1 = a_n1 ^ b_n1;
     uint32_t e = x0 ? (uint32_t)(__ffs((int)x0) - 1) >> 3 : (x1 ? 4u + ((uint32_t)(__ffs((int)x1) - 1) >> 3) : 8u);
     uint32_t known = 8u;
+    if (has2 && !more) {
+        const uint32_t x2 = a_n2 ^ b_n2;
+        if (e == 8u) e += x2 ? (uint32_t)(__ffs((int)x2) - 1) >> 3 : 4u;
+        known = 12u;
+    }
     if (more) {
         const uint32_t y0 = ax.x ^ bx.x, y1 = ax.y ^ bx.y, y2 = ax.z ^ bx.z, y3 = ax.w ^ bx.w;
         const uint32_t e2 = y0 ? (uint32_t)(__ffs((int)y0) - 1) >> 3
@@ -219,7 +241,7 @@ __device__ __forceinline__ void hop_chain_pairs_ref(unsigned long long &hmx, uns
             if (t != 0x400u) break;
             const uint32_t qn = hv & 63u;
             lostC |= (~1ull << f) & ~(~0ull << qn) & ~(1ull << ((qn - 2u) & 63u));
-            const unsigned long long now = __ballot((long long)(lostC << j1c) < 0);
+            const unsigned long long now = ballot((long long)(lostC << j1c) < 0);
             hmx ^= (hmx ^ hmB) & now;
             if (((now >> lane_id()) & 1ull) && (uint32_t)lane_id() >= qn) hopv = hopB;   /* below the cursor: final already */
         }
@@ -315,14 +337,14 @@ __device__ __forceinline__ void hop_chain_pairs(unsigned long long &hmx, unsigne
  * After 64 misses the schedule's step grows (LL64.fast.cs:156-172); those rounds probe the strided
  * positions and stop at their first sequence.
  */
-template <bool BYU16, bool PROF = false, bool X32 = false, bool PAIRS = true, bool MORE = false>
+template <bool BYU16, bool PROF = false, bool X32 = false, bool PAIRS = true, bool MORE = false, bool N2 = true>
 __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
                                                  uint32_t accel, uint32_t *ldsw, int lane, unsigned long long *pc = nullptr,
                                                  bool dry = false, uint32_t *seq_count = nullptr, uint32_t *gtab = nullptr)
 {
     uint32_t sequences = 0;
     unsigned long long c_probe = 0, c_ext = 0, c_emit = 0, n_seq = 0, n_round = 0, n_dup = 0, n_rt3 = 0;
-    unsigned long long c_s1 = 0, c_s2 = 0, c_s3 = 0, c_s4 = 0;
+    unsigned long long c_s1 = 0, c_s2 = 0, c_s3 = 0, c_s4 = 0, n_cont = 0;
     prof_place<PROF>(pc, 8, lane);
     const unsigned long long t_begin = prof_now<PROF>();
     if ((uint32_t)src_len > (uint32_t)MAX_INPUT_SIZE) return 0;     /* LL64.fast.cs:90 */
@@ -360,7 +382,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
         const uint2 r = rec[slot];
         const uint32_t pos = r.x, cpos = r.x - (r.y & 0xffffu), binfo = (r.y >> 16) & 15u;
         uint32_t code = r.y >> 20;
-        unsigned long long longer = __ballot(mine && code == REC_CODE_MAX);     /* :326-329 once more, from where the record stops */
+        unsigned long long longer = ballot(mine && code == REC_CODE_MAX);     /* :326-329 once more, from where the record stops */
         while (longer) {
             const int g = ctz64(longer);
             longer &= longer - 1ull;
@@ -375,7 +397,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
         const uint32_t maxback = lit0 < cpos ? lit0 : cpos;                /* 0 right after a match */
         const uint32_t nb = binfo & 7u;
         uint32_t back = nb < maxback ? nb : maxback;
-        unsigned long long slow = __ballot(mine && (!(binfo & 8u) || nb == 4u) && back < maxback);
+        unsigned long long slow = ballot(mine && (!(binfo & 8u) || nb == 4u) && back < maxback);
         while (slow) {
             const int g = ctz64(slow);
             slow &= slow - 1ull;
@@ -384,7 +406,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             while (b < mb) {
                 const uint32_t i = b + (uint32_t)lane;
                 const bool eq = i < mb && src[p - 1u - i] == src[match - 1u - i];
-                const unsigned long long ne2 = ~__ballot(eq);
+                const unsigned long long ne2 = ~ballot(eq);
                 const int run = ne2 ? ctz64(ne2) : 64;
                 b += (uint32_t)run;
                 if (run < 64) break;
@@ -403,7 +425,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
         if (limited) {                                      /* :251-255, :346-350 */
             const bool fail = mine && ((uint64_t)o_tok + 1u + ll + (2 + 1 + LASTLITERALS) + ll / 255u > olimit ||
                                        (uint64_t)o_mx + (1 + LASTLITERALS) + (mc + 240u) / 255u > olimit);
-            if (__ballot(fail)) return false;
+            if (ballot(fail)) return false;
         }
         if (mine) {
             dst[o_tok] = (uint8_t)(((ll < (uint32_t)RUN_MASK ? ll : (uint32_t)RUN_MASK) << ML_BITS) |
@@ -413,7 +435,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             if (mx == 1u) dst[o_mx] = (uint8_t)(mc - ML_MASK);
         }
         if (short_run) lane_copy32(dst + o_lit, src + ls, ll, U - ls);
-        unsigned long long big = __ballot(mine && (ll > LANE_COPY_MAX || lx > 1u || mx > 1u));
+        unsigned long long big = ballot(mine && (ll > LANE_COPY_MAX || lx > 1u || mx > 1u));
         while (big) {
             const int g = ctz64(big);
             big &= big - 1ull;
@@ -485,6 +507,15 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             const bool contig = fresh && accel == 1u;               /* lane l probes position ip + l */
             const uint32_t shift = (fresh && test) ? 1u : 0u;       /* lane 0 = the test probe */
             const uint32_t ip0 = ip;
+#if K4_GTAB_DUTY
+            /* A SIMD issues for its oldest wave first, and the global-table kernel is launched second: its waves lost every
+             * arbitration to the LDS-table waves on the same SIMD and ran 1.2-1.6x longer per block than those (4.08 ms
+             * against 3.52 for the two kernels of the bench batch, per-block time stamps in profiles/r15_stamp_*.txt).  With
+             * the higher priority all the time they win every arbitration instead and the LDS-table kernel becomes the long
+             * one (3.76 / 4.10 ms); taking it for three of every four 64-byte steps of the cursor -- a round's cursor is as
+             * good as a coin here -- evens the two out (3.90 / 3.93 ms, +4.5 % on the encode call). */
+            if (gtab) { if (((ip0 >> 6) & 3u) < (uint32_t)K4_GTAB_DUTY) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
             const uint32_t pos = pos_n;
             const bool valid = valid_n;
             const Around pa = pa_n;
@@ -497,7 +528,10 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 tab.put(Table::hash_of(seq2, n2), ip - 2u);
             }
             wave_sync();
-            if (PROF) { n_round++; }
+            if (PROF) { n_round++; if (!fresh) n_cont++; }
+            /* (taken here, before the candidate fetch is issued: a first use of the probe's bytes after it would make the
+             * compiler wait for every load in flight, the fetch included) */
+            const uint32_t pn2 = (uint32_t)__shfl_down((int)pa.n1, 4);
             uint32_t h = 0, cand = 0;
             bool flagged = false;              /* another lane of this window has the same hash (at least one lane of every group sees it) */
             if (valid) {
@@ -508,6 +542,13 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             }
             const Around ca = load_around(src, cand);       /* the round's one dependent trip to memory: everything below that
                                                              * does not need the candidate bytes runs while it is under way */
+            /* Four more bytes behind both (positions 12 .. 15 after the probe): a match of up to 15 bytes is then measured
+             * from registers -- most of the "long" matches of text (LL64.fast.cs:326-329 costs a trip to memory in the middle
+             * of the chain otherwise).  The probe's come out of the lane four positions on, the candidate's are one more
+             * dword of the same trip; lanes without such a neighbour, and strided rounds, stay at 12 known bytes. */
+            const uint32_t fwd_max = matchlimit - (pos + MINMATCH);
+            const bool has2 = K4_N2 && N2 && !MORE && contig && lane < 60 && valid && fwd_max > 8u && fwd_max < 0x80000000u;
+            const uint32_t cn2 = ld32u(src + (has2 ? cand + 12u : 0u));      /* cand + 16 <= pos + 15 < U where fwd_max > 8 */
             uint4 cx = make_uint4(0u, 0u, 0u, 0u);
             if (MORE) {                                     /* (cand < pos, so cand + 28 <= U where pos + 28 <= U) */
                 const U128u v = ld128u(src + (more ? cand + 12u : 0u));
@@ -517,31 +558,30 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             /* ---------------- groups: lanes of the window with equal hashes ---------------- */
             unsigned long long G = me;
             {
-                unsigned long long fl = __ballot(flagged);
+                unsigned long long fl = ballot(flagged);
                 if (valid) seen[h >> (5u + SEEN_SHIFT)] = 0u;      /* every lane has recorded its hash by now: wipe the words this window touched */
                 while (fl) {
                     const int j = ctz64(fl);
                     const uint32_t hj = __builtin_amdgcn_readlane(h, j);
                     const bool same = valid && h == hj;
-                    const unsigned long long m = __ballot(same);
+                    const unsigned long long m = ballot(same);
                     if (same) G = m;
                     fl &= ~m;
                 }
             }
-            const unsigned long long dirty = __ballot(G != me);
+            const unsigned long long dirty = ballot(G != me);
 
             /* ---------------- resolve: every sequence that starts in the window ---------------- */
             const unsigned long long t1 = prof_now<PROF>();
-            const unsigned long long inv_m = __ballot(!valid), preok_m = __ballot(pa.pre_ok);
-            const uint32_t fwd_max = matchlimit - (pos + MINMATCH);
+            const unsigned long long inv_m = ballot(!valid), preok_m = ballot(pa.pre_ok);
             /* the common group is a pair: the later lane's candidate is the earlier lane while that one counts
              * as visited, else the table entry -- both known up front, so losing a candidate is a select */
             const unsigned long long gb = G & below_me;
             const int j1 = gb ? 63 - (int)__clzll((long long)gb) : -1;
-            const unsigned long long cand0 = __ballot((G & ~(below_me | me)) != 0ull);
+            const unsigned long long cand0 = ballot((G & ~(below_me | me)) != 0ull);
             /* now the candidate bytes */
             const bool hit_tab = valid && (BYU16 || cand + (uint32_t)DISTANCE_MAX >= pos) && ca.seq == pa.seq;
-            const uint32_t info = extension_info(pa.pre, pa.n0, pa.n1, pa.pre_ok, ca.pre, ca.n0, ca.n1, ca.pre_ok, fwd_max, more, px, cx);
+            const uint32_t info = extension_info(pa.pre, pa.n0, pa.n1, pa.pre_ok, ca.pre, ca.n0, ca.n1, ca.pre_ok, fwd_max, more, px, cx, has2, pn2, cn2);
             /* per lane: the candidate as the table and the visited positions of this round define it */
             uint32_t cpos = cand, cinfo = info;
             bool chit = hit_tab;
@@ -583,7 +623,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 return (valid ? 0u : 0x800u) | qn | long_flag | (pos + MINMATCH + c8 >= mflimit_plus_one ? 0x200u : 0u) | (trig ? 0x400u : 0u);
             };
             auto publish = [&]() {
-                hmx = __ballot(chit) | inv_m;
+                hmx = ballot(chit) | inv_m;
                 const bool counted = xcode != 0xffffffffu;          /* this lane's long match has been measured already */
                 const uint32_t c8 = counted ? xcode : (cinfo & EXT_FWD_MASK);
                 epos = pos + MINMATCH + c8;
@@ -597,7 +637,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 const int ph = hb ? 63 - (int)__clzll((long long)hb) : 0;
                 const uint32_t qp = (uint32_t)__shfl((int)hopv, ph) & 127u;       /* lane after the match of the hit below */
                 const bool in = hb != 0ull && (uint32_t)lane < qp;
-                skipped = __ballot(in && (uint32_t)lane + 2u != qp);
+                skipped = ballot(in && (uint32_t)lane + 2u != qp);
             };
             bool general = false;
             if (dirty) {
@@ -611,7 +651,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
              * then worked out in full (`general`) for the rest of the round. */
             const bool many = (gb & (gb - 1ull)) != 0ull;
             const uint32_t hop_tab = many ? 0x1040u : (dirty ? hop_word(info & EXT_FWD_MASK, info & 0x100u) : hopv);
-            const unsigned long long hmB = dirty ? (__ballot(hit_tab || many) | inv_m) : hmx;
+            const unsigned long long hmB = dirty ? (ballot(hit_tab || many) | inv_m) : hmx;
             const uint32_t j1c = 63u - (uint32_t)(j1 >= 0 ? j1 : lane);
             const unsigned long long ta = prof_now<PROF>();
             if (PROF) c_s1 += ta - t1;
@@ -633,9 +673,9 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 lost_cands |= sk;
                 const bool lost = (long long)(lost_cands << j1c) < 0;
                 if (general) {
-                    if (__ballot(lost) & (~0ull << q)) go_general();   /* lanes behind the cursor no longer matter */
+                    if (ballot(lost) & (~0ull << q)) go_general();   /* lanes behind the cursor no longer matter */
                 } else {
-                    hmx ^= (hmx ^ hmB) & __ballot(lost);
+                    hmx ^= (hmx ^ hmB) & ballot(lost);
                     if (lost && (uint32_t)lane >= q) {              /* what the lanes below the cursor hold is final */
                         hopv = hop_tab;
                         chit = hit_tab;
@@ -772,21 +812,21 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
     if (PROF && pc && lane == 0) {
         pc[0] = prof_now<PROF>() - t_begin; pc[1] = c_probe; pc[2] = c_ext; pc[3] = c_emit;
         pc[4] = n_seq; pc[5] = n_round; pc[6] = n_dup; pc[7] = n_rt3;
-        pc[11] = c_s1; pc[12] = c_s2; pc[13] = c_s3; pc[14] = c_s4;
+        pc[11] = c_s1; pc[12] = c_s2; pc[13] = c_s3; pc[14] = c_s4; pc[15] = n_cont;
     }
     prof_place<PROF>(pc, 9, lane);
     return (int)op;
 }
 
 /* LL64.LZ4_compress_fast (LL64.fast.cs:517-576): table type by input size */
-template <bool PAIRS = true, bool MORE = false>
+template <bool PAIRS = true, bool MORE = false, bool N2 = true>
 __device__ __forceinline__ int compress_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
                                                    int accel, uint32_t *ldsw, int lane, uint32_t *gtab = nullptr, bool x32 = false)
 {
     const uint32_t a = accel < 1 ? 1u : (accel > 65536 ? 65536u : (uint32_t)accel);
-    if (src_len < LIMIT_64K) return encode_fast_block<true, false, false, PAIRS, MORE>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
-    if (x32) return encode_fast_block<false, false, true, PAIRS, MORE>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
-    return encode_fast_block<false, false, false, PAIRS, MORE>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
+    if (src_len < LIMIT_64K) return encode_fast_block<true, false, false, PAIRS, MORE, N2>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
+    if (x32) return encode_fast_block<false, false, true, PAIRS, MORE, N2>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
+    return encode_fast_block<false, false, false, PAIRS, MORE, N2>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
 }
 
 /* LZ4Codec.Encode mapping (LZ4Codec.cs:40-52) */
@@ -867,9 +907,11 @@ __device__ __forceinline__ void encode_fast_kernel_body(const BatchArgs &a, uint
     const uint8_t *src = a.src + a.srcOff[b];
     uint8_t *dst = a.dst + a.dstOff[b];
     int ret = 0;
+    if (a.prof) { prof_place<true>(a.prof + PROF_STRIDE * b, 8, lane); if (lane == 0) a.prof[PROF_STRIDE * b + 11] = MORE ? 3u : 1u; }
     if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
         ret = compress_fast_block<true, MORE>(src, src_len, dst, cap < 0 ? 0 : cap, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0);
     if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
+    if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 9, lane);
 }
 
 __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_num_vgpr(80))) void k4_encode_fast_kernel(BatchArgs a)
@@ -892,7 +934,7 @@ __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) void k4_encode_fast_more_
  * only the output stage in LDS: twice as many blocks resident per CU, each a little slower */
 /* waves_per_eu(6): at most 80 VGPRs.  Two LDS-table waves and four of these fit one SIMD's register file only
  * below that line; one register more costs 20 % of the batch rate (measured). */
-__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void k4_encode_fast_gtab_kernel(BatchArgs a)
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(K4_GTAB_WPE, K4_GTAB_WPE))) void k4_encode_fast_gtab_kernel(BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t stages[ENCODE_WAVES_PER_WG][ENCODE_STAGE_DWORDS];
     const int lane = lane_id();
@@ -904,10 +946,12 @@ __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_wav
     const int src_len = a.srcLen[b];
     const int cap = a.dstCap[b];
     int ret = 0;
+    if (a.prof) { prof_place<true>(a.prof + PROF_STRIDE * b, 8, lane); if (lane == 0) a.prof[PROF_STRIDE * b + 11] = 2u; }
     if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
-        ret = compress_fast_block<false>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.accel, stage, lane,
+        ret = compress_fast_block<K4_GTAB_PAIRS != 0, false, K4_GTAB_N2 != 0>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.accel, stage, lane,
                                          a.gtab + 4096ull * (unsigned long long)slot, (a.flags & FLAG_X32) != 0);
     if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
+    if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 9, lane);
 }
 
 /* diagnostic twin (blocks < 65547 B only): per-phase cycle counters (a.prof, 8 per block) */
@@ -920,7 +964,8 @@ __global__ __launch_bounds__(64) void k4_encode_fast_prof_kernel(BatchArgs a)
     const int cap = a.dstCap[b];
     int ret = 0;
     if (src_len > 0 && src_len < LIMIT_64K)
-        ret = encode_fast_block<true, true>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, 1u, tab, lane, a.prof + PROF_STRIDE * b);
+        ret = encode_fast_block<true, true>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, 1u, tab, lane, a.prof + PROF_STRIDE * b,
+                                            false, nullptr, a.gtab ? a.gtab + 4096ull * (unsigned long long)blockIdx.x : nullptr);
     if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
 }
 

@@ -125,7 +125,8 @@ class DeviceCodec:
 
     def profile(self, decode: bool, src: DeviceBatch, dst: DeviceBatch, out_len: Optional[torch.Tensor] = None):
         """instrumented twin kernels: returns (out_len, counters[n, 16] int64 tensor); decode == 2: the two-waves-per-block
-        decoder, counters[n, 32] (parsing wave, copying wave)"""
+        decoder, counters[n, 32] (parsing wave, copying wave); decode == 4 / 5: the ordinary encode / decode kernels, which
+        then only stamp every block's start, end and placement (counters[:, 8:12])"""
         out_len = self.new_out_len(src.n) if out_len is None else out_len
         counters = torch.zeros((src.n, 32 if int(decode) == 2 else 16), dtype=torch.int64, device=self.device)
         rc = self.lib.k4lz4_profile_batch_device(self.ctx.handle, int(decode), _dp(src.data), _dp(src.off),

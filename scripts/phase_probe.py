@@ -52,6 +52,11 @@ for decode in (False, True):
         d = c[np.arange(0, n, 12)].mean(axis=0)
         print("dickens resolve split per round: initial candidates %.0f  hop loop %.0f  recompute %.0f  post %.0f ; recomputes/round %.2f" % (tuple(d[11:15] / d[5]) + (d[6] / d[5],)))
         print("ALL     resolve split per round: initial %.0f hop %.0f recompute %.0f post %.0f" % tuple(m[11:15] / m[5]))
+        print("per class and round: probe initial hop recompute post emit | sequences, long counts, fall-backs per round, share of rounds that continue a search")
+        for ci, name in enumerate(names):
+            d = c[np.arange(ci, n, 12)].mean(axis=0)
+            r = max(d[5], 1)
+            print("%-8s %6.0f %6.0f %6.0f %6.0f %6.0f %6.0f | %5.2f %5.2f %5.2f %5.2f" % (name, d[1] / r, d[11] / r, d[12] / r, d[13] / r, d[14] / r, d[3] / r, d[4] / r, d[7] / r, d[6] / r, d[15] / r))
     if decode:
         for name in ("dickens", "ALL"):
             sel = np.arange(n) if name == "ALL" else np.array([i for i in range(n) if names[i % len(names)] == name])

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit timing every build ab/v_*.so on the bench batch (and on a 512-block batch, where a block's own
-# latency shows): encode / decode GiB/s per build, alternating, REPS times.  Usage: scripts/variants_round.sh [tag] [reps]
+# latency shows): encode / decode GiB/s per build, alternating, REPS times.  Usage: scripts/variants_round.sh [tag] [reps] [sizes]
 TAG=${1:-var}
 REPS=${2:-2}
 SIZES=${3:-"4096 512"}
@@ -19,3 +19,9 @@ for r in $(seq $REPS); do
   done
 done
 cp /tmp/keep.so $L
+if [ -n "$SPLITS" ]; then
+  for s in $SPLITS; do
+    echo -n "split=$s " | tee -a $OUT/variants.txt
+    K4LZ4_SPLIT_PCT=$s timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-host-path 2>&1 | tail -1 | grep -o '"encode_GiBs_per_gpu[^,]*,[^,]*' | tee -a $OUT/variants.txt
+  done
+fi
