@@ -82,9 +82,11 @@ struct k4lz4_ctx {
     int stage_threads = 7;      /* helper threads of the staging copies (K4LZ4_STAGE_THREADS - 1, read once at creation) */
     /* diagnostic switches, read once at creation: K4LZ4_SPLIT_PCT (1..100, share of an encode batch on the LDS-table kernel),
      * K4LZ4_NO_PAIR (decode with one wave per block) */
+    uint32_t *d_pace = nullptr;     /* the per-SIMD slots of the late-blocks-first priorities (k4lz4_common.hpp, Pace) */
     uint32_t *d_status = nullptr;   /* this context's status word: DEV_STATUS_* bits raised by its kernels (k4lz4_common.hpp) */
     int split_pct = -1;
     bool no_pair = false;
+    bool use_pace = true;                 /* K4LZ4_NO_PACE: without the late-blocks-first priorities */
     bool prof_gtab = false;               /* K4LZ4_PROF_GTAB: the instrumented encoder keeps its table in global memory */
     bool trace = false;         /* K4LZ4_TRACE: host-pointer calls print where their time went (stderr) */
 };
@@ -359,6 +361,10 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
         a.flags = flags | (g_enforce32.load(std::memory_order_relaxed) ? K4LZ4_FLAG_X32 : 0);
         a.prof = ctx->prof ? ctx->prof + k4::PROF_STRIDE * first : nullptr;
         a.status = ctx->d_status;
+        if (kind == KIND_ENCODE && ctx->use_pace && ctx->d_pace && cnt > 8 * (int64_t)ctx->cu_count) {   /* k4lz4_common.hpp, Pace: more than two blocks per SIMD */
+            a.pace = ctx->d_pace;
+            K4_HIP(ctx, hipMemsetAsync(a.pace, 0, k4::PACE_BYTES, stream));
+        }
         if (dd && dd->dict) {
             a.dict = dd->dict; a.dictOff = dd->off + first; a.dictLen = dd->len + first;
             a.dictMode = dd->mode ? dd->mode + first : nullptr;
@@ -1005,6 +1011,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_status, 64);
     if (e == hipSuccess) e = hipMemset(ctx->d_status, 0, 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_pace, k4::PACE_BYTES);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copyq, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
@@ -1022,6 +1029,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (const char *pct = getenv("K4LZ4_SPLIT_PCT")) { const int v = atoi(pct); ctx->split_pct = v < 1 ? 1 : (v > 100 ? 100 : v); }
     ctx->no_pair = getenv("K4LZ4_NO_PAIR") != nullptr;
     ctx->prof_gtab = getenv("K4LZ4_PROF_GTAB") != nullptr;
+    ctx->use_pace = getenv("K4LZ4_NO_PACE") == nullptr;
     if (const char *e = getenv("K4LZ4_STAGE_THREADS")) ctx->stage_threads = std::max(0, std::min(63, atoi(e) - 1));
     ctx->trace = getenv("K4LZ4_TRACE") != nullptr;
     if (e != hipSuccess) { delete ctx; return hip_fail(nullptr, e, "hipStreamCreate"); }
@@ -1055,6 +1063,7 @@ void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
     delete ctx->pool;
     delete ctx->pool_dl;
     if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->d_pace) (void)hipFree(ctx->d_pace);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
     if (ctx->d_dict) (void)hipFree(ctx->d_dict);
     if (ctx->d_src) (void)hipFree(ctx->d_src);

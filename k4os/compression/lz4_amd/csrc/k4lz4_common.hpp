@@ -59,6 +59,7 @@ struct BatchArgs {
     const int32_t *dictLen;
     const signed char *dictMode;   /* optional: 1 = prefix semantics, 2 = external (host staging); nullptr = by address */
     uint32_t *status;              /* the context's status word (DEV_STATUS_* bits, raised with dev_status_raise), or nullptr */
+    uint32_t *pace;                /* three zeroed words shared by the waves of a launch (Pace below), or nullptr */
 };
 
 struct __attribute__((packed, aligned(1))) U16u { uint16_t v; };
@@ -136,6 +137,104 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_re
 /* the builtin returns int: widening its result directly would sign-extend */
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ int ctz64(unsigned long long m) { return __ffsll(m) - 1; }
+
+/*
+ * Late blocks first.  A launch is as long as its last block, all blocks of a batch are resident from the start, and what a
+ * wave gets of its SIMD's issue slots is decided by priority, then age -- luck of placement, which spreads the finishing
+ * times of equally expensive blocks by +-10 %.  Priorities only arbitrate between the waves of ONE SIMD, so that is the
+ * scope: every wave estimates, each time its block has advanced another PACE_STEP bytes, when the block will be done at the
+ * pace so far (F = start + elapsed * total / done on the 100 MHz real-time counter, relative to the first start seen on
+ * this SIMD), reports it to the SIMD's slot (atomic max into the word of the running EPOCH, tagged with the epoch number so
+ * that a new epoch's reports supersede the old ones), reads what the epoch before arrived at, and takes an issue priority
+ * by how close it is to that: on every SIMD the block that would finish last runs first.  One round trip to the L2 per
+ * PACE_STEP bytes of a block (a slot is touched by the handful of waves of one SIMD: no contention; one word for the whole
+ * launch was tried first and cost 35 %); nothing depends on it but timing.  Measured on the bench batch (4096 x 64 KiB, both
+ * encoder kernels side by side): 62.2 -> 63.3 GiB/s over giving the younger kernel's waves the priority three steps in four;
+ * tiers at 1/32 of the latest estimate, a report every 2 KiB, epochs of 164 us (1/16 and 1/8 tiers, 4 KiB steps measured
+ * 62.9 / 61.8 / 63.0).  The pair decoder gained nothing from it (its spread is not an issue-slot matter) and does not use it.
+ *   slot (16 bytes, index from XCC_ID and HW_ID: se, sh, cu, simd):  [0], [1]  epoch << 20 | F in 80 ns units, even / odd
+ *   epochs      [2]  ~(earliest start on this SIMD)
+ */
+#ifndef K4_PACE_DEN
+#define K4_PACE_DEN 32u
+#endif
+#ifndef K4_PACE_STEP
+#define K4_PACE_STEP 11
+#endif
+#ifndef K4_PACE_EPOCH
+#define K4_PACE_EPOCH 14
+#endif
+constexpr uint32_t PACE_STEP_LOG2 = K4_PACE_STEP, PACE_EPOCH_LOG2 = K4_PACE_EPOCH;          /* the encoders' (a 64 KiB block takes milliseconds) */
+constexpr uint32_t PACE_SLOTS = 8192, PACE_BYTES = PACE_SLOTS * 16;
+struct Pace {
+    __device__ __forceinline__ static uint32_t now()
+    {
+#ifndef K4_HOST_EMU
+        return (uint32_t)__builtin_amdgcn_s_memrealtime();
+#else
+        return 0u;
+#endif
+    }
+    __device__ __forceinline__ static uint32_t *slot_of(uint32_t *base)
+    {
+#ifndef K4_HOST_EMU
+        const uint32_t hw = __builtin_amdgcn_s_getreg((16 << 11) | 4);          /* HW_ID[15:0]: wave, simd, pipe, cu, sh, se */
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((4 << 11) | 20);         /* XCC_ID[3:0] */
+        const uint32_t idx = ((hw >> 4) & 3u) | (((hw >> 8) & 0xffu) << 2) | ((xcc & 7u) << 10);
+        return base + 4u * idx;
+#else
+        return base;
+#endif
+    }
+    /* `mine`: a dword of LDS this wave keeps (its start time lives there, not in a register the round loop is short of) */
+    __device__ __forceinline__ static void begin(uint32_t *base, uint32_t *mine, int lane)
+    {
+#ifndef K4_HOST_EMU
+        if (!base) return;
+        const uint32_t t = now();
+        if (lane == 0) {
+            *mine = t;
+            atomicMax(slot_of(base) + 2, ~t);
+        }
+#else
+        (void)base; (void)mine; (void)lane;
+#endif
+    }
+    /* `done` of `total` units of the block are behind this wave (0 < done <= total) */
+    template <uint32_t EPOCH_LOG2 = PACE_EPOCH_LOG2>
+    __device__ __forceinline__ static void update(uint32_t *base, const uint32_t *mine, uint32_t done, uint32_t total, int lane)
+    {
+#ifndef K4_HOST_EMU
+        if (!base) return;
+        uint32_t *w = slot_of(base);
+        uint32_t ref = 0, t0inv = 0, cur = 0;
+        if (lane == 0) {
+            cur = __hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ref = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t0inv = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint32_t t_start = uni(*mine);
+        const uint32_t w0 = uni(cur), w1 = uni(ref), t0i = uni(t0inv), t0 = t0i ? ~t0i : t_start;
+        const uint32_t t = now();
+        const float own = (float)(t - t_start) * ((float)total / (float)done);
+        const uint32_t own_u = own < 4.0e9f ? (uint32_t)own : 4000000000u;
+        const uint32_t f = (t_start - t0) + own_u;                      /* ticks from the first start on this SIMD to this block's end */
+        const uint32_t fs = (f >> 3) < 0xfffffu ? (f >> 3) : 0xfffffu;
+        const uint32_t epoch = ((t - t0) >> EPOCH_LOG2) & 0xfffu;
+        if (lane == 0) atomicMax(w + (epoch & 1u), (epoch << 20) | fs);
+        const uint32_t before = (epoch & 1u) ? w0 : w1;                 /* the other word: the epoch before, if anybody reported in it */
+        if ((before >> 20) != ((epoch - 1u) & 0xfffu)) return;
+        const uint32_t last = before & 0xfffffu;
+        if (fs * K4_PACE_DEN >= last * (K4_PACE_DEN - 1u)) __builtin_amdgcn_s_setprio(3);
+        else if (fs * K4_PACE_DEN >= last * (K4_PACE_DEN - 2u)) __builtin_amdgcn_s_setprio(2);
+        else if (fs * K4_PACE_DEN >= last * (K4_PACE_DEN - 3u)) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+#else
+        (void)base; (void)mine; (void)done; (void)total; (void)lane;
+#endif
+    }
+};
+
 
 /* Inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS):
  * Hillis-Steele inside each row of 16, then row 15 -> row 1/3 and lane 31 -> rows 2,3. */

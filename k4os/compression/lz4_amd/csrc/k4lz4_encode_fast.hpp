@@ -39,6 +39,9 @@ namespace k4 {
 #ifndef K4_GTAB_DUTY
 #define K4_GTAB_DUTY 3
 #endif
+#ifndef K4_PACE
+#define K4_PACE 1
+#endif
 
 /* TYPE 0: byU32 + hash5 (LL64), 1: byU16 + hash4, 2: byU32 + hash4 (LL32 in a 64-bit process, LZ4Codec.Enforce32) */
 template <int TYPE> struct FastTable;
@@ -110,7 +113,7 @@ constexpr int ENCODE_SCRATCH_BYTES = 512;      /* same-hash detection: 4096 bits
 constexpr int ENCODE_REC_SLOTS = 64;
 constexpr int ENCODE_REC_DWORDS = 2 * ENCODE_REC_SLOTS;
 constexpr uint32_t REC_CODE_MAX = 4095u;
-constexpr int ENCODE_STAGE_DWORDS = ENCODE_SCRATCH_BYTES / 4 + ENCODE_REC_DWORDS;   /* what every encoder wave needs besides its table */
+constexpr int ENCODE_STAGE_DWORDS = ENCODE_SCRATCH_BYTES / 4 + ENCODE_REC_DWORDS + 4;   /* + the wave's word for Pace */   /* what every encoder wave needs besides its table */
 constexpr int ENCODE_LDS_DWORDS = 4096 + ENCODE_STAGE_DWORDS;                       /* hash table + the above */
 
 /* length field tail: `rem` encoded as 255-run + final byte (LL64.fast.cs:262-272,:365-381,:484-495) */
@@ -340,9 +343,11 @@ __device__ __forceinline__ void hop_chain_pairs(unsigned long long &hmx, unsigne
 template <bool BYU16, bool PROF = false, bool X32 = false, bool PAIRS = true, bool MORE = false, bool N2 = true>
 __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
                                                  uint32_t accel, uint32_t *ldsw, int lane, unsigned long long *pc = nullptr,
-                                                 bool dry = false, uint32_t *seq_count = nullptr, uint32_t *gtab = nullptr)
+                                                 bool dry = false, uint32_t *seq_count = nullptr, uint32_t *gtab = nullptr,
+                                                 uint32_t *pace_words = nullptr)
 {
     uint32_t sequences = 0;
+
     unsigned long long c_probe = 0, c_ext = 0, c_emit = 0, n_seq = 0, n_round = 0, n_dup = 0, n_rt3 = 0;
     unsigned long long c_s1 = 0, c_s2 = 0, c_s3 = 0, c_s4 = 0, n_cont = 0;
     prof_place<PROF>(pc, 8, lane);
@@ -358,6 +363,8 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
     tab.t = (decltype(tab.t))tabmem;
     uint32_t *const seen = gtab ? ldsw : ldsw + 4096;       /* bit h: a lane of the current window hashed to h */
     uint2 *const rec = (uint2 *)(seen + ENCODE_SCRATCH_BYTES / 4);        /* the pending sequences */
+    uint32_t *const pace_mine = seen + ENCODE_SCRATCH_BYTES / 4 + ENCODE_REC_DWORDS;
+    if (K4_PACE) Pace::begin(pace_words, pace_mine, lane);
     constexpr uint32_t REC_SLOTS = (uint32_t)ENCODE_REC_SLOTS, REC_FLUSH_AT = REC_SLOTS - 16u;
     constexpr uint32_t SEEN_SHIFT = BYU16 ? 1u : 0u;        /* hash value -> bit of `seen` */
     const unsigned long long me = 1ull << lane, below_me = me - 1ull;
@@ -513,8 +520,9 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
              * against 3.52 for the two kernels of the bench batch, per-block time stamps in profiles/r15_stamp_*.txt).  With
              * the higher priority all the time they win every arbitration instead and the LDS-table kernel becomes the long
              * one (3.76 / 4.10 ms); taking it for three of every four 64-byte steps of the cursor -- a round's cursor is as
-             * good as a coin here -- evens the two out (3.90 / 3.93 ms, +4.5 % on the encode call). */
-            if (gtab) { if (((ip0 >> 6) & 3u) < (uint32_t)K4_GTAB_DUTY) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+             * good as a coin here -- evens the two out (3.90 / 3.93 ms, +4.5 % on the encode call).  Only without the
+             * late-blocks-first priorities (Pace, k4lz4_common.hpp: K4LZ4_NO_PACE), which do the same and more by measurement. */
+            if (gtab && !(K4_PACE && pace_words)) { if (((ip0 >> 6) & 3u) < (uint32_t)K4_GTAB_DUTY) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #endif
             const uint32_t pos = pos_n;
             const bool valid = valid_n;
@@ -760,6 +768,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 }
             }
             prepare();                                      /* also when the block ends here: every lane is invalid then and reads offset 0 */
+            if (K4_PACE && ((ip ^ ip0) >> PACE_STEP_LOG2) != 0u && outcome != 2) Pace::update(pace_words, pace_mine, ip, U, lane);
 
             /* the k sequences of this round join the pending ones */
             const bool mine = ((hits >> lane) & 1ull) != 0ull;
@@ -821,12 +830,13 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
 /* LL64.LZ4_compress_fast (LL64.fast.cs:517-576): table type by input size */
 template <bool PAIRS = true, bool MORE = false, bool N2 = true>
 __device__ __forceinline__ int compress_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
-                                                   int accel, uint32_t *ldsw, int lane, uint32_t *gtab = nullptr, bool x32 = false)
+                                                   int accel, uint32_t *ldsw, int lane, uint32_t *gtab = nullptr, bool x32 = false,
+                                                   uint32_t *pace = nullptr)
 {
     const uint32_t a = accel < 1 ? 1u : (accel > 65536 ? 65536u : (uint32_t)accel);
-    if (src_len < LIMIT_64K) return encode_fast_block<true, false, false, PAIRS, MORE, N2>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
-    if (x32) return encode_fast_block<false, false, true, PAIRS, MORE, N2>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
-    return encode_fast_block<false, false, false, PAIRS, MORE, N2>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab);
+    if (src_len < LIMIT_64K) return encode_fast_block<true, false, false, PAIRS, MORE, N2>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab, pace);
+    if (x32) return encode_fast_block<false, false, true, PAIRS, MORE, N2>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab, pace);
+    return encode_fast_block<false, false, false, PAIRS, MORE, N2>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab, pace);
 }
 
 /* LZ4Codec.Encode mapping (LZ4Codec.cs:40-52) */
@@ -909,7 +919,7 @@ __device__ __forceinline__ void encode_fast_kernel_body(const BatchArgs &a, uint
     int ret = 0;
     if (a.prof) { prof_place<true>(a.prof + PROF_STRIDE * b, 8, lane); if (lane == 0) a.prof[PROF_STRIDE * b + 11] = MORE ? 3u : 1u; }
     if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
-        ret = compress_fast_block<true, MORE>(src, src_len, dst, cap < 0 ? 0 : cap, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0);
+        ret = compress_fast_block<true, MORE>(src, src_len, dst, cap < 0 ? 0 : cap, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0, a.pace);
     if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
     if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 9, lane);
 }
@@ -949,7 +959,7 @@ __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_wav
     if (a.prof) { prof_place<true>(a.prof + PROF_STRIDE * b, 8, lane); if (lane == 0) a.prof[PROF_STRIDE * b + 11] = 2u; }
     if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
         ret = compress_fast_block<K4_GTAB_PAIRS != 0, false, K4_GTAB_N2 != 0>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.accel, stage, lane,
-                                         a.gtab + 4096ull * (unsigned long long)slot, (a.flags & FLAG_X32) != 0);
+                                         a.gtab + 4096ull * (unsigned long long)slot, (a.flags & FLAG_X32) != 0, a.pace);
     if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
     if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 9, lane);
 }
