@@ -30,6 +30,7 @@
 #include "k4lz4_decode.hpp"
 #include "k4lz4_encode_fast.hpp"
 #include "k4lz4_pickle.hpp"
+#include "k4lz4_segments.hpp"
 #include "k4lz4_encode_hc.hpp"
 #include "k4lz4_frame.hpp"
 #include "k4lz4_xxh32.hpp"
@@ -53,10 +54,19 @@ struct k4lz4_ctx {
     uint8_t *d_dict = nullptr; size_t d_dict_cap = 0;         /* host-pointer decode with dictionaries: staged dictionaries + their metadata */
     uint8_t *d_gtab = nullptr; size_t d_gtab_cap = 0;         /* fast encoder: hash tables of the blocks encoded without an LDS table */
     hipStream_t aux = nullptr;                                /* second queue: those blocks run beside the LDS-table kernel */
+    hipStream_t aux2 = nullptr;                               /* third queue: the later segments of blocks cut into segments (k4lz4_segments.hpp) */
+    hipEvent_t ev_join2 = nullptr;
+    uint8_t *d_seg = nullptr; size_t d_seg_cap = 0;           /* segment records, work list, snapshots, tables */
+    uint8_t *d_seg_first = nullptr; size_t d_seg_first_cap = 0;   /* per block: its first segment's record or -1 */
+    bool use_segments = true;                                 /* K4LZ4_NO_SEGMENTS */
+    uint32_t seg_min = 1536u << 10, seg_target = 768u << 10, seg_warm = 384u << 10;   /* K4LZ4_SEG_MIN / _TARGET / _WARM (bytes) */
+    uint32_t seg_div = 2500;                                  /* K4LZ4_SEG_DIV: blocks shorter than the batch's bytes / this stay whole */
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint8_t *d_hc_hash = nullptr; size_t d_hc_hash_cap = 0;   /* HC: per-block hash tables of one launch chunk */
     uint8_t *d_hc_work = nullptr; size_t d_hc_work_cap = 0;   /* HC: prev[] / cand[] of one launch chunk */
     uint8_t *d_hc_meta = nullptr; size_t d_hc_meta_cap = 0;   /* HC: work offsets, pickle slots */
+    uint8_t *d_pk_meta = nullptr; size_t d_pk_meta_cap = 0;   /* fast-level pickles through the encoder kernels: encoder slots and results */
+    int pickle_split_min = 512;           /* K4LZ4_PICKLE_SPLIT_MIN: batches of more messages than this go that way */
     /* The scratch above is shared by all calls on this context but ordered only by the stream a call runs on: the end of
      * every launch is recorded here and the next launch on a DIFFERENT stream waits for it before it touches the scratch
      * (calls on one context are serialised across streams). */
@@ -170,6 +180,7 @@ int hip_fail(k4lz4_ctx *ctx, hipError_t e, const char *what)
     } while (0)
 
 enum Kind { KIND_ENCODE, KIND_DECODE, KIND_PICKLE, KIND_UNPICKLE };
+constexpr int FLAG_SEGMENTS_OK = 1 << 20;   /* launch_inner, fast encode: big blocks may be cut into segments (k4lz4_segments.hpp); not part of the API */
 
 /* LL.Enforce32 (Engine/LL.tools.cs:19-27): a process-wide switch in the reference, so here too */
 std::atomic<int> g_enforce32{0};
@@ -335,6 +346,33 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
         K4_HIP(ctx, hipGetLastError());
         return K4LZ4_OK;
     }
+    if (kind == KIND_PICKLE && (n > (int64_t)ctx->pickle_split_min || ctx->use_segments) && !ctx->prof) {
+        /* Fast-level pickles of a batch go the encoders' way: slots prepared (block = envelope + 5, cap U - 1, exactly what
+         * k4_pickle_kernel hands its encoder), the batch encoded by the two encoder kernels side by side -- the expensive
+         * messages with their tables in LDS, the others with tables in memory, which puts a ragged batch on all the
+         * chip's wave slots instead of the nine per CU that have room for a table in LDS --, envelopes closed afterwards. */
+        for (int64_t first = 0; first < n; first += chunk_max) {
+            const int64_t cnt = std::min<int64_t>(chunk_max, n - first);
+            const size_t need_meta = (size_t)cnt * 16 + 64;
+            if (need_meta > ctx->d_pk_meta_cap) K4_HIP(ctx, hipStreamSynchronize(stream));
+            int rc = grow(ctx, &ctx->d_pk_meta, &ctx->d_pk_meta_cap, need_meta, false);
+            if (rc != K4LZ4_OK) return rc;
+            uint64_t *d_encoff = (uint64_t *)ctx->d_pk_meta;
+            int32_t *d_enccap = (int32_t *)(d_encoff + cnt);
+            int32_t *d_enclen = d_enccap + cnt;
+            k4::BatchArgs a{};
+            a.src = src; a.srcOff = srcOff + first; a.srcLen = srcLen + first; a.dst = dst; a.dstOff = dstOff + first;
+            a.dstCap = dstCap + first; a.outLen = outLen + first; a.n = cnt; a.level = level; a.accel = 1;
+            a.flags = flags | (g_enforce32.load(std::memory_order_relaxed) ? K4LZ4_FLAG_X32 : 0);
+            hipLaunchKernelGGL(k4::k4_pickle_prep_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, a, d_encoff, d_enccap);
+            rc = launch_inner(ctx, KIND_ENCODE, src, srcOff + first, srcLen + first, dst, d_encoff, d_enccap, d_enclen, cnt, level,
+                              (flags & K4LZ4_FLAG_NO_REORDER) | K4LZ4_FLAG_RAW_RETURN | FLAG_SEGMENTS_OK, stream, nullptr, hostLen ? hostLen + first : nullptr);
+            if (rc != K4LZ4_OK) return rc;
+            hipLaunchKernelGGL(k4::k4_pickle_finish_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a, d_enclen);
+            K4_HIP(ctx, hipGetLastError());
+        }
+        return K4LZ4_OK;
+    }
     /* cost-ordered dispatch (most expensive blocks first): encoders by default, decoders on request */
     const bool reorder = n > 1 &&
                          (encode_like ? !(flags & K4LZ4_FLAG_NO_REORDER)
@@ -344,12 +382,12 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
     uint32_t *d_cost = nullptr, *d_order = nullptr, *d_hist = nullptr;
     if (reorder) {
         const size_t cnt_max = (size_t)std::min<int64_t>(chunk_max, n);
-        const size_t need = cnt_max * 8 + 2 * k4::COST_BUCKETS * 4 + 64;
+        const size_t need = cnt_max * 8 + (2 * k4::COST_BUCKETS + 16) * 4 + 64;
         if (need > ctx->d_sched_cap) K4_HIP(ctx, hipStreamSynchronize(stream));   /* scratch may still be in use */
         int rc = grow(ctx, &ctx->d_sched, &ctx->d_sched_cap, need, false);
         if (rc != K4LZ4_OK) return rc;
         d_hist = (uint32_t *)ctx->d_sched;
-        d_cost = d_hist + 2 * k4::COST_BUCKETS;
+        d_cost = d_hist + 2 * k4::COST_BUCKETS + 16;     /* [2 * COST_BUCKETS]: where the second encoder kernel's part of the order begins */
         d_order = d_cost + cnt_max;
     }
     for (int64_t first = 0; first < n; first += chunk_max) {
@@ -365,16 +403,62 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             a.pace = ctx->d_pace;
             K4_HIP(ctx, hipMemsetAsync(a.pace, 0, k4::PACE_BYTES, stream));
         }
+        /* big blocks in several segments (k4lz4_segments.hpp): the plan is made on the device, the later segments run on a queue of
+         * their own beside the ordinary kernels (which take a cut block's first segment), the pieces are joined afterwards */
+        k4::SegArgs sg{};
+        bool seg = false;
+        if (kind == KIND_ENCODE && (flags & FLAG_SEGMENTS_OK) && ctx->use_segments && !a.prof && !(flags & K4LZ4_FLAG_ALLOW_COPY)) {
+            const size_t o_items = 256, o_work = o_items + (size_t)k4::SEG_MAX_ITEMS * sizeof(k4::SegItem);
+            const size_t o_blocks = o_work + (size_t)k4::SEG_MAX_ITEMS * 4, o_snaps = (o_blocks + (size_t)k4::SEG_MAX_BLOCKS * 4 + 255) & ~(size_t)255;
+            const size_t o_tables = o_snaps + (size_t)k4::SEG_MAX_ITEMS * k4::SEG_SNAP_DWORDS * 4, total = o_tables + (size_t)k4::SEG_MAX_ITEMS * 16384;
+            if (total > ctx->d_seg_cap || (size_t)cnt * 4 > ctx->d_seg_first_cap) {
+                K4_HIP(ctx, hipStreamSynchronize(stream));
+                K4_HIP(ctx, hipStreamSynchronize(ctx->aux2));
+            }
+            int rc = grow(ctx, &ctx->d_seg, &ctx->d_seg_cap, total, false);
+            if (rc == K4LZ4_OK) rc = grow(ctx, &ctx->d_seg_first, &ctx->d_seg_first_cap, (size_t)cnt * 4, false);
+            if (rc != K4LZ4_OK) return rc;
+            sg.hdr = (k4::SegHdr *)ctx->d_seg; sg.items = (k4::SegItem *)(ctx->d_seg + o_items); sg.work = (uint32_t *)(ctx->d_seg + o_work);
+            sg.blocks = (uint32_t *)(ctx->d_seg + o_blocks); sg.snaps = (uint32_t *)(ctx->d_seg + o_snaps); sg.tables = (uint32_t *)(ctx->d_seg + o_tables);
+            sg.first = (int32_t *)ctx->d_seg_first;
+            sg.seg_min = ctx->seg_min; sg.seg_target = ctx->seg_target; sg.seg_warm = ctx->seg_warm; sg.seg_div = ctx->seg_div;
+            hipLaunchKernelGGL(k4::k4_seg_plan_kernel, dim3(1), dim3(256), 0, stream, a, sg);
+            a.seg_first = sg.first; a.seg_items = sg.items; a.seg_snaps = sg.snaps;
+            seg = true;
+        }
+        /* the later segments: on their queue, before the ordinary kernels are launched (their waves are the ones others wait for) */
+        auto segments_start = [&]() -> int {
+            if (!seg) return K4LZ4_OK;
+            K4_HIP(ctx, hipEventRecord(ctx->ev_fork, stream));
+            K4_HIP(ctx, hipStreamWaitEvent(ctx->aux2, ctx->ev_fork, 0));
+            hipLaunchKernelGGL(k4::k4_encode_seg_kernel, dim3((unsigned)(k4::SEG_MAX_ITEMS / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, ctx->aux2, a, sg);
+            K4_HIP(ctx, hipEventRecord(ctx->ev_join2, ctx->aux2));
+            return K4LZ4_OK;
+        };
+        auto segments_join = [&]() -> int {
+            if (!seg) return K4LZ4_OK;
+            K4_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_join2, 0));
+            hipLaunchKernelGGL(k4::k4_seg_join_kernel, dim3((unsigned)k4::SEG_MAX_BLOCKS), dim3(64), 0, stream, a, sg);
+            return K4LZ4_OK;
+        };
         if (dd && dd->dict) {
             a.dict = dd->dict; a.dictOff = dd->off + first; a.dictLen = dd->len + first;
             a.dictMode = dd->mode ? dd->mode + first : nullptr;
         }
         if (reorder) {
             a.cost = d_cost; a.hist = d_hist; a.order_out = d_order;
-            K4_HIP(ctx, hipMemsetAsync(d_hist, 0, 2 * k4::COST_BUCKETS * 4, stream));
+            K4_HIP(ctx, hipMemsetAsync(d_hist, 0, (2 * k4::COST_BUCKETS + 16) * 4, stream));
             hipLaunchKernelGGL(k4::k4_cost_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a, encode_like ? 0 : 1);
-            hipLaunchKernelGGL(k4::k4_order_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, a);
+            /* the split between the two encoder kernels by cost (see k4_order_kernel): 48 % of it, at least one residency of
+             * the LDS-table kernel; K4LZ4_SPLIT_PCT fixes a share of the NUMBER of blocks instead */
+            const bool two_kernels = kind == KIND_ENCODE && !a.prof && cnt > 512 && !(flags & K4LZ4_FLAG_NO_SPLIT) &&
+                                     cnt > 8 * (int64_t)ctx->cu_count && ctx->split_pct <= 0;
+            k4::BatchArgs ao = a;
+            ao.first = two_kernels ? 48u : 0u;
+            ao.total = (uint32_t)(8 * (int64_t)ctx->cu_count);
+            hipLaunchKernelGGL(k4::k4_order_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, ao);
             a.order = d_order;
+            if (two_kernels) a.split = d_hist + 2 * k4::COST_BUCKETS;
         }
         const unsigned wg4 = (unsigned)((cnt + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
         switch (kind) {
@@ -400,28 +484,37 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
                 const int64_t lds_slots = 8 * (int64_t)ctx->cu_count;
                 const int64_t n_lds = ctx->split_pct > 0 ? std::min<int64_t>(cnt, std::max<int64_t>(1, cnt * ctx->split_pct / 100))
                                                          : std::min<int64_t>(cnt, std::max<int64_t>(lds_slots, cnt * 48 / 100));
-                const int64_t n_g = cnt - n_lds;
+                /* (with the split decided on the device, a.split: n_lds is the most the LDS-table kernel can get -- the share of
+                 * the cost is never a larger share of the number -- and the other kernel is sized for the least) */
+                const int64_t n_g = cnt - (a.split ? std::min<int64_t>(cnt, lds_slots) : n_lds);
                 const int64_t gchunk = 8192;
                 if (n_g > 0 && (size_t)std::min(n_g, gchunk) * 16384 > ctx->d_gtab_cap) {
                     K4_HIP(ctx, hipStreamSynchronize(ctx->aux));
                     int rc2 = grow(ctx, &ctx->d_gtab, &ctx->d_gtab_cap, (size_t)std::min(n_g, gchunk) * 16384, false);
                     if (rc2 != K4LZ4_OK) return rc2;
                 }
+                { const int rcs = segments_start(); if (rcs != K4LZ4_OK) return rcs; }
                 K4_HIP(ctx, hipEventRecord(ctx->ev_fork, stream));
                 K4_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
                 for (int64_t g0 = 0; g0 < n_g; g0 += gchunk) {
                     k4::BatchArgs ag = a;
-                    ag.order = a.order + n_lds + g0;
+                    ag.first = (uint32_t)((a.split ? 0 : n_lds) + g0);
+                    ag.total = (uint32_t)cnt;
                     ag.gtab = (uint32_t *)ctx->d_gtab;
                     ag.n = std::min(gchunk, n_g - g0);
-                    hipLaunchKernelGGL(k4::k4_encode_fast_gtab_kernel, dim3((unsigned)((ag.n + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)),
+                    if (seg) hipLaunchKernelGGL(k4::k4_encode_fast_gtab_seg_kernel, dim3((unsigned)((ag.n + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)),
+                                                dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, ctx->aux, ag);
+                    else hipLaunchKernelGGL(k4::k4_encode_fast_gtab_kernel, dim3((unsigned)((ag.n + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)),
                                        dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, ctx->aux, ag);
                 }
                 K4_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
                 {
                     k4::BatchArgs al = a;
                     al.n = n_lds;
-                    if (n_g == 0 && cnt <= lds_slots)
+                    if (seg)
+                        hipLaunchKernelGGL(k4::k4_encode_fast_seg_kernel, dim3((unsigned)((n_lds + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)),
+                                           dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, al);
+                    else if (n_g == 0 && cnt <= lds_slots)
                         hipLaunchKernelGGL(k4::k4_encode_fast_more_kernel, dim3((unsigned)((n_lds + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)),
                                            dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, al);
                     else
@@ -429,6 +522,13 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
                                            dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, al);
                 }
                 K4_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_join, 0));
+                { const int rcs = segments_join(); if (rcs != K4LZ4_OK) return rcs; }
+            }
+            else if (seg) {
+                { const int rcs = segments_start(); if (rcs != K4LZ4_OK) return rcs; }
+                hipLaunchKernelGGL(k4::k4_encode_fast_seg_kernel, dim3((unsigned)((cnt + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)),
+                                   dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, a);
+                { const int rcs = segments_join(); if (rcs != K4LZ4_OK) return rcs; }
             }
             else if (cnt <= 8 * (int64_t)ctx->cu_count)       /* a half-empty chip: the variant that buys latency with instructions */
                 hipLaunchKernelGGL(k4::k4_encode_fast_more_kernel, dim3((unsigned)((cnt + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)),
@@ -664,6 +764,7 @@ int run_host(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcO
         if (ctx->copyq) (void)hipStreamSynchronize(ctx->copyq);
         if (ctx->dlq) (void)hipStreamSynchronize(ctx->dlq);
         if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
+        if (ctx->aux2) (void)hipStreamSynchronize(ctx->aux2);
         (void)hipGetLastError();
         (void)take_device_status(ctx);
         ctx->error = why;
@@ -1014,6 +1115,8 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_pace, k4::PACE_BYTES);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copyq, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_busy, hipEventDisableTiming);
@@ -1030,6 +1133,12 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     ctx->no_pair = getenv("K4LZ4_NO_PAIR") != nullptr;
     ctx->prof_gtab = getenv("K4LZ4_PROF_GTAB") != nullptr;
     ctx->use_pace = getenv("K4LZ4_NO_PACE") == nullptr;
+    ctx->use_segments = getenv("K4LZ4_NO_SEGMENTS") == nullptr;
+    if (const char *e = getenv("K4LZ4_SEG_MIN")) ctx->seg_min = (uint32_t)std::max(65536 + 4096, atoi(e));
+    if (const char *e = getenv("K4LZ4_SEG_TARGET")) ctx->seg_target = (uint32_t)std::max(8192, atoi(e));
+    if (const char *e = getenv("K4LZ4_SEG_WARM")) ctx->seg_warm = (uint32_t)std::max(0, atoi(e));
+    if (const char *e = getenv("K4LZ4_SEG_DIV")) ctx->seg_div = (uint32_t)std::max(0, atoi(e));
+    if (const char *e = getenv("K4LZ4_PICKLE_SPLIT_MIN")) ctx->pickle_split_min = std::max(0, atoi(e));
     if (const char *e = getenv("K4LZ4_STAGE_THREADS")) ctx->stage_threads = std::max(0, std::min(63, atoi(e) - 1));
     ctx->trace = getenv("K4LZ4_TRACE") != nullptr;
     if (e != hipSuccess) { delete ctx; return hip_fail(nullptr, e, "hipStreamCreate"); }
@@ -1043,6 +1152,10 @@ void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+    if (ctx->aux2) { (void)hipStreamSynchronize(ctx->aux2); (void)hipStreamDestroy(ctx->aux2); }
+    if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
+    if (ctx->d_seg) (void)hipFree(ctx->d_seg);
+    if (ctx->d_seg_first) (void)hipFree(ctx->d_seg_first);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev_busy) (void)hipEventDestroy(ctx->ev_busy);
@@ -1074,6 +1187,7 @@ void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
     if (ctx->d_hc_hash) (void)hipFree(ctx->d_hc_hash);
     if (ctx->d_hc_work) (void)hipFree(ctx->d_hc_work);
     if (ctx->d_hc_meta) (void)hipFree(ctx->d_hc_meta);
+    if (ctx->d_pk_meta) (void)hipFree(ctx->d_pk_meta);
     delete ctx;
 }
 

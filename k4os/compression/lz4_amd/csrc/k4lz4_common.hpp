@@ -60,6 +60,13 @@ struct BatchArgs {
     const signed char *dictMode;   /* optional: 1 = prefix semantics, 2 = external (host staging); nullptr = by address */
     uint32_t *status;              /* the context's status word (DEV_STATUS_* bits, raised with dev_status_raise), or nullptr */
     uint32_t *pace;                /* three zeroed words shared by the waves of a launch (Pace below), or nullptr */
+    const uint32_t *split;         /* the two encoder kernels of one batch: where in the dispatch order the second one's part begins
+                                    * (hist[2 * COST_BUCKETS], written by k4_order_kernel), or nullptr: `first` alone says */
+    uint32_t first;                /* global-table kernel: its slot 0 is entry first (+ *split) of the order */
+    uint32_t total;                /* ... and the order has this many entries */
+    const int32_t *seg_first;      /* big blocks cut into segments (k4lz4_segments.hpp): per block its first segment's record, or -1; or nullptr */
+    void *seg_items;               /* ... the records (SegItem) */
+    uint32_t *seg_snaps;           /* ... and where the segments' runs publish their cuts */
 };
 
 struct __attribute__((packed, aligned(1))) U16u { uint16_t v; };
@@ -137,6 +144,33 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_re
 /* the builtin returns int: widening its result directly would sign-extend */
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ int ctz64(unsigned long long m) { return __ffsll(m) - 1; }
+
+/* a word in memory that one wave publishes and waves of other workgroups read (release / acquire at agent scope) */
+__device__ __forceinline__ void agent_publish(uint32_t *p, uint32_t v)
+{
+#ifndef K4_HOST_EMU
+    __threadfence();
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    __atomic_store_n(p, v, __ATOMIC_RELEASE);
+#endif
+}
+__device__ __forceinline__ void agent_acquire()             /* what other workgroups published before the word just seen may be read plainly now */
+{
+#ifndef K4_HOST_EMU
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+#endif
+}
+__device__ __forceinline__ uint32_t agent_peek(const uint32_t *p)
+{
+#ifndef K4_HOST_EMU
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return __atomic_load_n(p, __ATOMIC_ACQUIRE);
+#endif
+}
 
 /*
  * Late blocks first.  A launch is as long as its last block, all blocks of a batch are resident from the start, and what a
@@ -266,6 +300,30 @@ __device__ __forceinline__ void wave_copy(uint8_t *d, const uint8_t *s, uint32_t
         done = nv << 4;
     }
     for (uint32_t k = done + (uint32_t)lane; k < n; k += 64) d[k] = s[k];
+}
+
+/* move n bytes down to a lower address that may lie inside them (d < s): ascending 1 KiB steps, every step loaded by all the
+ * lanes before any of them stores */
+__device__ __forceinline__ void wave_shift_down(uint8_t *d, const uint8_t *s, uint32_t n, int lane)
+{
+    for (uint32_t k0 = 0; k0 < n; k0 += 1024u) {
+        const uint32_t k = k0 + 16u * (uint32_t)lane;
+        U128u v = {{0, 0, 0, 0}};
+        uint8_t tail[16];
+        const bool full = k + 16u <= n;
+        if (full) {
+            v = ld128u(s + k);
+        } else {
+            for (uint32_t i = 0; i < 16u; i++) tail[i] = (k + i < n) ? s[k + i] : (uint8_t)0;
+        }
+        wave_sync();
+        if (full) {
+            st128u(d + k, v);
+        } else {
+            for (uint32_t i = 0; i < 16u; i++) if (k + i < n) d[k + i] = tail[i];
+        }
+        wave_sync();
+    }
 }
 
 /* n bytes of value `b` */

@@ -305,6 +305,31 @@ __device__ __forceinline__ void hop_chain_pairs(unsigned long long &hmx, unsigne
 }
 
 /*
+ * A big block by several wavefronts (k4lz4_segments.hpp says who gets what): the encoder's state between two sequences is
+ * its cursor and its hash table, and of the table only the entries that can still be used (at most 65 535 bytes back,
+ * LL64.fast.cs:219-224).  A wave that starts `warm` bytes before a boundary with an empty table ("warm run") usually has
+ * that very state when it crosses the boundary (experiments/speculative_segments: always, on text, with 384 KiB), and
+ * whether it has can be checked exactly.  So the warm run writes nothing until its first match end at or behind the
+ * boundary (its CUT), publishes cut + table there and encodes on from it; the run before it, the true one, stops at ITS
+ * first match end at or behind the boundary, and if that is the published cut and every usable table entry is equal,
+ * the two outputs put one behind the other are the block's encoding byte for byte -- if not, the block is encoded again
+ * the plain way.  A round may end at any match end (that is what a match running out of the window does), which is all the
+ * round-based encoder needs for it.
+ */
+constexpr uint32_t SEG_NONE = 0xffffffffu;
+constexpr int SEG_SNAP_DWORDS = 4096 + 16;          /* [0] cut + 1 (0: not there yet, SEG_NONE: this run never found one), [16..] the table */
+constexpr uint32_t SEG_SPIN_MAX = 1u << 22;
+struct SegRun {
+    uint32_t begin;             /* where the run starts probing: 0, or the start of the warm-up */
+    uint32_t emit_from;         /* 0: output from the start; else nothing is written before the first match end at or behind this position */
+    uint32_t stop_at;           /* SEG_NONE: to the end of the block; else stop at the first match end at or behind this position ... */
+    uint32_t *snap_pub;         /* where a warm run publishes its cut and table, or nullptr */
+    const uint32_t *snap_chk;   /* ... if it is the cut published here, with an equal table; or nullptr */
+    uint32_t cut, stop, state;  /* results: first position of the output (the cut; 0), one past its last (verified cut, or U),
+                                 * 1 stopped at a verified cut, 2 ran to the end of the block, 3 no use (not in step, no cut, no room) */
+};
+
+/*
  * LL64.LZ4_compress_generic for one block.  `ldsw`: ENCODE_LDS_DWORDS dwords of LDS owned by this
  * wave (16 KiB hash table, zeroed here = LZ4_initStream, LL.tools.cs:235-239; then the 1 KiB bit set
  * of the same-hash detection).  Returns bytes written, 0 when the output does not fit.
@@ -343,9 +368,15 @@ __device__ __forceinline__ void hop_chain_pairs(unsigned long long &hmx, unsigne
 template <bool BYU16, bool PROF = false, bool X32 = false, bool PAIRS = true, bool MORE = false, bool N2 = true>
 __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
                                                  uint32_t accel, uint32_t *ldsw, int lane, unsigned long long *pc = nullptr,
-                                                 bool dry = false, uint32_t *seq_count = nullptr, uint32_t *gtab = nullptr,
-                                                 uint32_t *pace_words = nullptr)
+                                                 bool dry_arg = false, uint32_t *seq_count = nullptr, uint32_t *gtab = nullptr,
+                                                 uint32_t *pace_words = nullptr, SegRun *sr = nullptr)
 {
+    /* (what comes out of *sr is the same in every lane; uni() says so to the compiler, which would otherwise refuse it as an
+     * operand of the scalar chains below) */
+    const uint32_t sr_emit_from = sr ? uni(sr->emit_from) : 0u, sr_stop_at = sr ? uni(sr->stop_at) : SEG_NONE, sr_begin = sr ? uni(sr->begin) : 0u;
+    bool dry = dry_arg || sr_emit_from != 0u;      /* a warm run writes nothing before its cut */
+    uint32_t cut_pos = sr_emit_from ? sr_emit_from : sr_stop_at;   /* the next match end at or behind this ends the round (outcome 3) */
+    if (sr) { sr->cut = 0u; sr->stop = 0u; sr->state = 3u; }
     uint32_t sequences = 0;
 
     unsigned long long c_probe = 0, c_ext = 0, c_emit = 0, n_seq = 0, n_round = 0, n_dup = 0, n_rt3 = 0;
@@ -463,9 +494,12 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
         const uint32_t mflimit_plus_one = U - MFLIMIT + 1;
         const uint32_t matchlimit = U - LASTLITERALS;
 
-        if (lane == 0) tab.put(Table::hash(src), 0);     /* :119-122 */
-        uint32_t ip = 1;       /* cursor of a fresh round */
-        uint32_t sbase = 1;    /* where the current search loop started (:466) */
+        const uint32_t begin = sr_begin;      /* (a warm run: the block as if it began here) */
+        anchor = begin;
+        if (lane == 0) tab.put(Table::hash(src + begin), begin);     /* :119-122 */
+        uint32_t ip = begin + 1u;       /* cursor of a fresh round */
+        uint32_t sbase = begin + 1u;    /* where the current search loop started (:466) */
+        uint32_t flag_pos = cut_pos < mflimit_plus_one ? cut_pos : mflimit_plus_one;   /* hits whose match ends here or later leave the chain */
         uint32_t jbase = 0;    /* probes of the current search already done (0: fresh round) */
         bool test = false;     /* fresh round only: `ip` is the position right after a match (:393-463) */
 
@@ -628,7 +662,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 /* lanes lane+1 .. qn-1 except qn-2 are never visited if this lane is a hit */
                 const unsigned long long inside = ~(below_me | me) & ((1ull << (qn & 63u)) - 1ull) & ~(1ull << ((qn - 2u) & 63u));
                 const bool trig = qn < 64u && (inside & cand_m) != 0ull;
-                return (valid ? 0u : 0x800u) | qn | long_flag | (pos + MINMATCH + c8 >= mflimit_plus_one ? 0x200u : 0u) | (trig ? 0x400u : 0u);
+                return (valid ? 0u : 0x800u) | qn | long_flag | (pos + MINMATCH + c8 >= flag_pos ? 0x200u : 0u) | (trig ? 0x400u : 0u);
             };
             auto publish = [&]() {
                 hmx = ballot(chit) | inv_m;
@@ -732,6 +766,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 }
                 anchor = e_end;
                 if (e_end >= mflimit_plus_one) { outcome = 2; break; }   /* :391 */
+                if (e_end >= cut_pos) { outcome = 3; break; }            /* a segment's cut: the round ends at this match end */
                 if (!contig || e_end - ip0 >= 64u) { outcome = 1; break; }
                 q = e_end - ip0;
                 lose((~1ull << f) & ((1ull << q) - 1ull) & ~(1ull << (q - 2u)));
@@ -742,7 +777,8 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 cinfo = info;
             }
             if (hits) derive(hits);
-            const unsigned long long I = ~skipped; /* lanes whose position has been put into the table this round */
+            unsigned long long I = ~skipped; /* lanes whose position has been put into the table this round */
+            if (outcome == 3 && anchor - ip0 < 64u) I &= (1ull << (anchor - ip0)) - 1ull;    /* the lanes behind a cut were not visited */
             const bool q_test = shift != 0u || hits != 0ull;       /* the cursor is a position right after a match */
             const unsigned long long tb = prof_now<PROF>();
             if (PROF) { c_s2 += tb - ta - t_rec; c_s3 += t_rec; }
@@ -751,7 +787,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             if (PROF) n_seq += k;
 
             /* ---------------- where the next round starts; its source loads go out now ---------------- */
-            if (outcome == 1) {
+            if (outcome == 1 || outcome == 3) {
                 ip = anchor;
                 test = true;
                 jbase = 0;
@@ -794,10 +830,56 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             if (rec_count >= REC_FLUSH_AT && !flush()) return 0;
             if (PROF) { const unsigned long long t3 = prof_now<PROF>(); c_probe += t1 - t0; c_ext += t2 - t1; c_emit += t3 - t2; }
 
+            if (outcome == 3) {
+                const uint32_t cut = anchor;        /* the cursor, right behind a match; the table holds every visited position before it */
+                /* ... and position cut - 2, which the reference puts right behind a match (:394) and this encoder at the top of
+                 * the round that follows, or with this round's other positions when the match ended inside the window: here,
+                 * so that both runs hold it whichever way their windows fell (the round that follows puts it once more) */
+                if (lane == 0) tab.put(Table::hash(src + cut - 2u), cut - 2u);
+                wave_sync();
+                if (dry) {
+                    /* the warm run has reached its cut: publish it with the table, write from here on */
+                    for (int k = lane; k < 4096; k += 64) sr->snap_pub[16 + k] = tabmem[k];
+                    wave_sync();
+                    if (lane == 0) agent_publish(sr->snap_pub, cut + 1u);
+                    dry = false;
+                    emitted_to = cut;
+                    sr->cut = cut;
+                    cut_pos = sr_stop_at;
+                    flag_pos = cut_pos < mflimit_plus_one ? cut_pos : mflimit_plus_one;
+                } else {
+                    /* the true run has reached a match end behind the next segment's boundary: is that segment's run in step here? */
+                    uint32_t theirs = 0u;
+                    for (uint32_t spin = 0; spin < SEG_SPIN_MAX; spin++) {
+                        theirs = uni(agent_peek(sr->snap_chk));
+                        if (theirs != 0u) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    bool same = theirs == cut + 1u;
+                    if (same) {
+                        agent_acquire();
+                        bool differ = false;
+                        for (int k = lane; k < 4096; k += 64) {
+                            const uint32_t mine = tabmem[k], other = sr->snap_chk[16 + k];
+                            differ = differ || (mine != other && !(cut - mine > (uint32_t)DISTANCE_MAX && cut - other > (uint32_t)DISTANCE_MAX));
+                        }
+                        same = ballot(differ) == 0ull;
+                    }
+                    if (!same) return 0;            /* state stays 3: the block is encoded again the plain way */
+                    while (rec_count) if (!flush()) return 0;
+                    sr->stop = cut;
+                    sr->state = 1u;
+                    return (int)op;
+                }
+            }
             if (outcome == 2) break;
         }
     }
 
+    if (sr && sr_emit_from != 0u && dry) {             /* a warm run that never found its cut: nothing to offer */
+        if (lane == 0) agent_publish(sr->snap_pub, SEG_NONE);
+        return 0;
+    }
     while (rec_count) if (!flush()) return 0;
 
     /* ---- _last_literals (:469-503) ---- */
@@ -818,6 +900,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
         op += last_run;
     }
     if (seq_count) *seq_count = sequences;
+    if (sr) { sr->stop = U; sr->state = 2u; }
     if (PROF && pc && lane == 0) {
         pc[0] = prof_now<PROF>() - t_begin; pc[1] = c_probe; pc[2] = c_ext; pc[3] = c_emit;
         pc[4] = n_seq; pc[5] = n_round; pc[6] = n_dup; pc[7] = n_rt3;
@@ -831,12 +914,12 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
 template <bool PAIRS = true, bool MORE = false, bool N2 = true>
 __device__ __forceinline__ int compress_fast_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap,
                                                    int accel, uint32_t *ldsw, int lane, uint32_t *gtab = nullptr, bool x32 = false,
-                                                   uint32_t *pace = nullptr)
+                                                   uint32_t *pace = nullptr, SegRun *sr = nullptr)
 {
     const uint32_t a = accel < 1 ? 1u : (accel > 65536 ? 65536u : (uint32_t)accel);
-    if (src_len < LIMIT_64K) return encode_fast_block<true, false, false, PAIRS, MORE, N2>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab, pace);
-    if (x32) return encode_fast_block<false, false, true, PAIRS, MORE, N2>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab, pace);
-    return encode_fast_block<false, false, false, PAIRS, MORE, N2>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab, pace);
+    if (src_len < LIMIT_64K) return encode_fast_block<true, false, false, PAIRS, MORE, N2>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab, pace);   /* (never cut) */
+    if (x32) return encode_fast_block<false, false, true, PAIRS, MORE, N2>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab, pace, sr);
+    return encode_fast_block<false, false, false, PAIRS, MORE, N2>(src, src_len, dst, dst_cap, a, ldsw, lane, nullptr, false, nullptr, gtab, pace, sr);
 }
 
 /* LZ4Codec.Encode mapping (LZ4Codec.cs:40-52) */
@@ -890,9 +973,35 @@ __global__ __launch_bounds__(64) void k4_cost_kernel(BatchArgs a, int by_length)
     }
 }
 
-/* order[] = block indices, most expensive bucket first */
+/* what a block of cost bucket `bkt` costs, in the units cost_bucket() cut into buckets (the middle of the bucket) */
+__device__ __forceinline__ unsigned long long bucket_cost(uint32_t bkt)
+{
+    if (bkt < 4u) return bkt ? (unsigned long long)bkt * 4ull : 1ull;
+    const uint32_t l = bkt >> 1;
+    return ((bkt & 1u) ? 7ull : 5ull) << (l - 1u);            /* 1.25 x 2^l / 1.75 x 2^l, times four */
+}
+
+/* order[] = block indices, most expensive bucket first.  Its first thread also says where the second encoder kernel's part of
+ * that order begins (hist[2 * COST_BUCKETS]): the most expensive blocks that hold `first` hundredths of the batch's COST go
+ * to the LDS-table kernel -- for blocks of one size that is the same share of their number, for a ragged batch a few big
+ * ones --, but never fewer than `total` of them (one residency of that kernel), when the batch has that many. */
 __global__ __launch_bounds__(256) void k4_order_kernel(BatchArgs a)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.first != 0u) {
+        unsigned long long all = 0;
+        for (uint32_t k = 0; k < (uint32_t)COST_BUCKETS; k++) all += (unsigned long long)a.hist[k] * bucket_cost(k);
+        const unsigned long long want = all / 100ull * (unsigned long long)a.first;
+        unsigned long long have = 0, cnt = 0;
+        for (int k = COST_BUCKETS - 1; k >= 0 && have < want; k--) {
+            const unsigned long long c = a.hist[k], w = bucket_cost((uint32_t)k);
+            if (have + c * w <= want) { have += c * w; cnt += c; }
+            else { const unsigned long long part = (want - have + w - 1ull) / w; cnt += part; have = want; }
+        }
+        const unsigned long long floor_n = (unsigned long long)a.total < (unsigned long long)a.n ? (unsigned long long)a.total : (unsigned long long)a.n;
+        if (cnt < floor_n) cnt = floor_n;
+        if (cnt > (unsigned long long)a.n) cnt = (unsigned long long)a.n;
+        a.hist[2 * COST_BUCKETS] = (uint32_t)cnt;
+    }
     const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
     if (b >= a.n) return;
     const uint32_t bkt = a.cost[b];
@@ -903,13 +1012,38 @@ __global__ __launch_bounds__(256) void k4_order_kernel(BatchArgs a)
 }
 
 constexpr int ENCODE_WAVES_PER_WG = 2;      /* blocks per workgroup; measured 1: 53.1, 2: 54.2, 4: 54.3 GiB/s on the bench batch */
-template <bool MORE>
+/* the first segment of a block that is cut into segments (k4lz4_segments.hpp; SegItem's leading fields are read here as words) */
+struct SegFirst { SegRun run; uint32_t cap; bool cut; };
+__device__ __forceinline__ SegFirst seg_first_of(const BatchArgs &a, long long b)
+{
+    SegFirst f;
+    f.cut = false; f.cap = 0u;
+    f.run.begin = 0u; f.run.emit_from = 0u; f.run.stop_at = SEG_NONE; f.run.snap_pub = nullptr; f.run.snap_chk = nullptr;
+    f.run.cut = 0u; f.run.stop = 0u; f.run.state = 3u;
+    if (!a.seg_first) return f;
+    const int32_t it = (int32_t)uni((uint32_t)a.seg_first[b]);
+    if (it < 0) return f;
+    const uint32_t *w = (const uint32_t *)a.seg_items + 10u * (uint32_t)it;     /* block, k, nseg, start, next_start, warm_from, cut, stop, state, bytes */
+    f.cut = true;
+    f.run.stop_at = uni(w[4]);
+    f.cap = f.run.stop_at;                                          /* its piece may not reach into the next segment's */
+    f.run.snap_chk = a.seg_snaps + (size_t)(it + 1) * SEG_SNAP_DWORDS;
+    return f;
+}
+__device__ __forceinline__ void seg_first_done(const BatchArgs &a, long long b, const SegFirst &f, int ret, int lane)
+{
+    if (!f.cut || lane != 0) return;
+    uint32_t *w = (uint32_t *)a.seg_items + 10u * (uint32_t)a.seg_first[b];
+    w[6] = f.run.cut; w[7] = f.run.stop; w[8] = ret > 0 ? f.run.state : 3u; w[9] = (uint32_t)ret;
+}
+
+template <bool MORE, bool SEG = false>
 __device__ __forceinline__ void encode_fast_kernel_body(const BatchArgs &a, uint32_t (*tabs)[ENCODE_LDS_DWORDS])
 {
     const int lane = lane_id();
     const uint32_t wave = uni(threadIdx.x >> 6);
     const long long slot = (long long)blockIdx.x * ENCODE_WAVES_PER_WG + (long long)wave;
-    if (slot >= a.n) return;
+    if (slot >= a.n || (a.split && slot >= (long long)uni(*a.split))) return;      /* the rest is the other kernel's */
     uint32_t *tab = tabs[wave];
     const long long b = a.order ? (long long)uni(a.order[slot]) : slot;
     const int src_len = a.srcLen[b];
@@ -918,6 +1052,13 @@ __device__ __forceinline__ void encode_fast_kernel_body(const BatchArgs &a, uint
     uint8_t *dst = a.dst + a.dstOff[b];
     int ret = 0;
     if (a.prof) { prof_place<true>(a.prof + PROF_STRIDE * b, 8, lane); if (lane == 0) a.prof[PROF_STRIDE * b + 11] = MORE ? 3u : 1u; }
+    if (SEG) {
+        SegFirst f = seg_first_of(a, b);
+        const int c = cap < 0 ? 0 : (f.cut && (uint32_t)cap > f.cap ? (int)f.cap : cap);
+        if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
+            ret = compress_fast_block<true, MORE>(src, src_len, dst, c, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0, a.pace, f.cut ? &f.run : nullptr);
+        seg_first_done(a, b, f, ret, lane);
+    } else
     if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
         ret = compress_fast_block<true, MORE>(src, src_len, dst, cap < 0 ? 0 : cap, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0, a.pace);
     if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
@@ -944,24 +1085,52 @@ __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) void k4_encode_fast_more_
  * only the output stage in LDS: twice as many blocks resident per CU, each a little slower */
 /* waves_per_eu(6): at most 80 VGPRs.  Two LDS-table waves and four of these fit one SIMD's register file only
  * below that line; one register more costs 20 % of the batch rate (measured). */
-__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(K4_GTAB_WPE, K4_GTAB_WPE))) void k4_encode_fast_gtab_kernel(BatchArgs a)
+template <bool SEG>
+__device__ __forceinline__ void encode_fast_gtab_kernel_body(const BatchArgs &a, uint32_t (*stages)[ENCODE_STAGE_DWORDS])
 {
-    __shared__ __attribute__((aligned(16))) uint32_t stages[ENCODE_WAVES_PER_WG][ENCODE_STAGE_DWORDS];
     const int lane = lane_id();
     const uint32_t wave = uni(threadIdx.x >> 6);
     const long long slot = (long long)blockIdx.x * ENCODE_WAVES_PER_WG + (long long)wave;
     if (slot >= a.n) return;
     uint32_t *stage = stages[wave];
-    const long long b = a.order ? (long long)uni(a.order[slot]) : slot;
+    /* its part of the order begins where the LDS-table kernel's ends (*split, on top of `first`) */
+    const long long at = (long long)a.first + (a.split ? (long long)uni(*a.split) : 0ll) + slot;
+    if (a.order && at >= (long long)a.total) return;
+    const long long b = a.order ? (long long)uni(a.order[at]) : slot;
     const int src_len = a.srcLen[b];
     const int cap = a.dstCap[b];
     int ret = 0;
     if (a.prof) { prof_place<true>(a.prof + PROF_STRIDE * b, 8, lane); if (lane == 0) a.prof[PROF_STRIDE * b + 11] = 2u; }
+    if (SEG) {
+        SegFirst f = seg_first_of(a, b);
+        const int c = cap < 0 ? 0 : (f.cut && (uint32_t)cap > f.cap ? (int)f.cap : cap);
+        if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
+            ret = compress_fast_block<K4_GTAB_PAIRS != 0, false, K4_GTAB_N2 != 0>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], c, a.accel, stage, lane,
+                                             a.gtab + 4096ull * (unsigned long long)slot, (a.flags & FLAG_X32) != 0, a.pace, f.cut ? &f.run : nullptr);
+        seg_first_done(a, b, f, ret, lane);
+    } else
     if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
         ret = compress_fast_block<K4_GTAB_PAIRS != 0, false, K4_GTAB_N2 != 0>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.accel, stage, lane,
                                          a.gtab + 4096ull * (unsigned long long)slot, (a.flags & FLAG_X32) != 0, a.pace);
     if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
     if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 9, lane);
+}
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(K4_GTAB_WPE, K4_GTAB_WPE))) void k4_encode_fast_gtab_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t stages[ENCODE_WAVES_PER_WG][ENCODE_STAGE_DWORDS];
+    encode_fast_gtab_kernel_body<false>(a, stages);
+}
+/* the two kernels once more for launches in which big blocks are cut into segments (k4lz4_segments.hpp): a cut block's first
+ * segment comes their way like any block, with the rule where to stop; kernels of their own so that the others carry none of it */
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(K4_GTAB_WPE, K4_GTAB_WPE))) void k4_encode_fast_gtab_seg_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t stages[ENCODE_WAVES_PER_WG][ENCODE_STAGE_DWORDS];
+    encode_fast_gtab_kernel_body<true>(a, stages);
+}
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_num_vgpr(88))) void k4_encode_fast_seg_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tabs[ENCODE_WAVES_PER_WG][ENCODE_LDS_DWORDS];
+    encode_fast_kernel_body<false, true>(a, tabs);
 }
 
 /* diagnostic twin (blocks < 65547 B only): per-phase cycle counters (a.prof, 8 per block) */

@@ -30,29 +30,6 @@ __device__ __forceinline__ int effective_size_of(int value)
     return (value > 0xffff || value < 0) ? 4 : (value > 0xff ? 2 : 1);
 }
 
-/* move n bytes down by `shift` (1..3) bytes: d = s - shift, ascending 1 KiB steps */
-__device__ __forceinline__ void wave_shift_down(uint8_t *d, const uint8_t *s, uint32_t n, int lane)
-{
-    for (uint32_t k0 = 0; k0 < n; k0 += 1024u) {
-        const uint32_t k = k0 + 16u * (uint32_t)lane;
-        U128u v = {{0, 0, 0, 0}};
-        uint8_t tail[16];
-        const bool full = k + 16u <= n;
-        if (full) {
-            v = ld128u(s + k);
-        } else {
-            for (uint32_t i = 0; i < 16u; i++) tail[i] = (k + i < n) ? s[k + i] : (uint8_t)0;
-        }
-        wave_sync();
-        if (full) {
-            st128u(d + k, v);
-        } else {
-            for (uint32_t i = 0; i < 16u; i++) if (k + i < n) d[k + i] = tail[i];
-        }
-        wave_sync();
-    }
-}
-
 /* envelope around an already encoded block sitting at dst + 5 (C = encoder result with cap U - 1) */
 __device__ __forceinline__ int pickle_finish(const uint8_t *src, int U, uint8_t *dst, int C, int flags, int lane)
 {

@@ -1,0 +1,192 @@
+/*
+ * k4lz4_segments.hpp -- a big block by several wavefronts (fast levels).
+ *
+ * One wavefront encodes about 20 MB/s, so a 4 MiB message is 165 ms long whatever else the batch holds, and a ragged batch
+ * (BASELINE configs[3]: LZ4Pickler over messages of 1 KiB .. 4 MiB, LZ4Pickler.pickle.cs:51-106 -> LL64.fast.cs:526-544, the
+ * byU32 arm) is as slow as its biggest message.  k4lz4_encode_fast.hpp (SegRun) says why a block can be cut: a wave that
+ * starts SEG_WARM bytes before a boundary with an empty table is, at its first match end behind the boundary, in the state
+ * the wave before it arrives in -- and that is checked, table entry by table entry, before the two outputs are joined; a block
+ * with a boundary that does not verify is encoded again by one wave (k4_seg_join_kernel), so the bytes are the reference's
+ * either way.
+ *
+ *   k4_seg_plan_kernel     which blocks are cut (length >= seg_min, room for the pieces in their own output slot), into how
+ *                          many segments; the segments' records (SegItem), the work list of the segments behind the first
+ *   k4_encode_seg_kernel   one wave per such segment (hash table in memory, like the global-table kernel): warm-up, cut,
+ *                          output into the block's slot at the segment's own offset (a piece never outgrows its span: a
+ *                          segment that does not shrink gives up), stop at the next segment's verified cut
+ *   the ordinary kernels   take the first segment of a cut block like any block, with the stop rule (their *_seg twins)
+ *   k4_seg_join_kernel     per cut block: every boundary verified -> the pieces moved down next to each other, total
+ *                          length; otherwise the whole block once more, plainly
+ */
+#pragma once
+#include "k4lz4_encode_fast.hpp"
+
+namespace k4 {
+
+constexpr int SEG_MAX_ITEMS = 8192;          /* segments of all cut blocks of a launch */
+constexpr int SEG_MAX_BLOCKS = 4096;         /* cut blocks of a launch */
+
+struct SegItem {
+    uint32_t block;                          /* the block this is a segment of */
+    uint32_t k, nseg;
+    uint32_t start, next_start, warm_from;   /* [start, next_start) is its range (next_start = SEG_NONE: to the end); the run starts at warm_from */
+    uint32_t cut, stop, state;               /* SegRun's results */
+    int32_t bytes;                           /* what it wrote at slot + start (at the slot's beginning for segment 0) */
+};
+
+struct SegHdr {
+    uint32_t n_items, n_work, n_blocks, pad;
+};
+
+struct SegArgs {
+    SegHdr *hdr;
+    SegItem *items;              /* SEG_MAX_ITEMS */
+    uint32_t *work;              /* SEG_MAX_ITEMS: item indices for k4_encode_seg_kernel, a block's later segments first */
+    uint32_t *blocks;            /* SEG_MAX_BLOCKS: the cut blocks */
+    int32_t *first;              /* per block of the batch: its segment 0's item, or -1 */
+    uint32_t *snaps;             /* SEG_MAX_ITEMS x SEG_SNAP_DWORDS */
+    uint32_t *tables;            /* SEG_MAX_ITEMS x 4096: the hash tables of k4_encode_seg_kernel's waves */
+    uint32_t seg_min, seg_target, seg_warm;
+    uint32_t seg_div;            /* a block is cut only if it is longer than the batch's bytes / seg_div: a wave encodes ~25 MB/s, the whole chip
+                                  * ~2 500 times that, so shorter blocks are over before the batch is and cutting them only adds their warm-ups */
+};
+
+/* One workgroup.  Every thread takes a contiguous range of the blocks; what a block gets (items, places in the work list, its
+ * number among the cut blocks) follows from the counts of the ranges before it, so the plan does not depend on timing, and
+ * when the tables are full the blocks behind simply stay whole. */
+__global__ __launch_bounds__(256) void k4_seg_plan_kernel(BatchArgs a, SegArgs g)
+{
+    __shared__ uint32_t items_of[256], blocks_of[256];
+    __shared__ unsigned long long bytes_of[256];
+    const int t = (int)threadIdx.x;
+    const long long per = (a.n + 255) / 256;
+    const long long lo = (long long)t * per, hi = lo + per < a.n ? lo + per : a.n;
+    unsigned long long mine = 0;
+    for (long long b = lo; b < hi; b++) mine += a.srcLen[b] > 0 ? (unsigned long long)a.srcLen[b] : 0ull;
+    bytes_of[t] = mine;
+    __syncthreads();
+    unsigned long long all = 0;
+    for (int k = 0; k < 256; k++) all += bytes_of[k];
+    const unsigned long long by_share = g.seg_div ? all / (unsigned long long)g.seg_div : 0ull;
+    const uint32_t min_len = by_share > (unsigned long long)g.seg_min ? (by_share > 0x7fffffffull ? 0x7fffffffu : (uint32_t)by_share) : g.seg_min;
+    auto segments_of = [&](long long b) -> uint32_t {
+        const int U = a.srcLen[b], cap = a.dstCap[b];
+        if (U < (int)min_len || U < LIMIT_64K || cap < U - 1) return 0u;
+        const uint32_t nseg = ((uint32_t)U + g.seg_target - 1u) / g.seg_target;
+        return nseg >= 2u ? nseg : 0u;
+    };
+    uint32_t ni = 0, nb = 0;
+    for (long long b = lo; b < hi; b++) { const uint32_t k = segments_of(b); ni += k; nb += k ? 1u : 0u; }
+    items_of[t] = ni; blocks_of[t] = nb;
+    if (t == 0) { g.hdr->n_items = 0u; g.hdr->n_work = 0u; g.hdr->n_blocks = 0u; }
+    __syncthreads();
+    uint32_t base = 0, bi = 0;
+    for (int k = 0; k < t; k++) { base += items_of[k]; bi += blocks_of[k]; }
+    for (long long b = lo; b < hi; b++) {
+        const uint32_t nseg = segments_of(b);
+        int32_t at = -1;
+        if (nseg && base + nseg <= (uint32_t)SEG_MAX_ITEMS && bi < (uint32_t)SEG_MAX_BLOCKS) {
+            const uint32_t U = (uint32_t)a.srcLen[b];
+            const uint32_t span = ((U + nseg - 1u) / nseg + 63u) & ~63u;
+            const uint32_t w0 = base - bi;                  /* every cut block before this one took one item more than places in the work list */
+            at = (int32_t)base;
+            g.blocks[bi] = (uint32_t)b;
+            for (uint32_t k = 0; k < nseg; k++) {
+                SegItem it;
+                it.block = (uint32_t)b; it.k = k; it.nseg = nseg;
+                it.start = k * span;
+                it.next_start = k + 1u < nseg ? (k + 1u) * span : SEG_NONE;
+                it.warm_from = it.start > g.seg_warm ? it.start - g.seg_warm : 0u;
+                it.cut = 0u; it.stop = 0u; it.state = 3u; it.bytes = 0;
+                g.items[base + k] = it;
+                g.snaps[(size_t)(base + k) * SEG_SNAP_DWORDS] = 0u;
+                if (k) g.work[w0 + (nseg - 1u - k)] = base + k;      /* later segments first: a wave never waits for one behind it */
+            }
+            atomicMax(&g.hdr->n_items, base + nseg);
+            atomicMax(&g.hdr->n_work, w0 + nseg - 1u);
+            atomicMax(&g.hdr->n_blocks, bi + 1u);
+        }
+        if (nseg) { base += nseg; bi++; }
+        g.first[b] = at;
+    }
+}
+
+/* the run of item `it` of a cut block: what encode_fast_block needs to know */
+__device__ __forceinline__ SegRun seg_run_of(const SegArgs &g, uint32_t it, const SegItem &s)
+{
+    SegRun r;
+    r.begin = s.k ? s.warm_from : 0u;
+    r.emit_from = s.k ? s.start : 0u;
+    r.stop_at = s.next_start;
+    r.snap_pub = s.k ? g.snaps + (size_t)it * SEG_SNAP_DWORDS : nullptr;
+    r.snap_chk = s.next_start != SEG_NONE ? g.snaps + (size_t)(it + 1u) * SEG_SNAP_DWORDS : nullptr;
+    r.cut = 0u; r.stop = 0u; r.state = 3u;
+    return r;
+}
+
+/* the segments behind the first: a wave each, table in memory */
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(K4_GTAB_WPE, K4_GTAB_WPE))) void k4_encode_seg_kernel(BatchArgs a, SegArgs g)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t stages[ENCODE_WAVES_PER_WG][ENCODE_STAGE_DWORDS];
+    const int lane = lane_id();
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t w = blockIdx.x * (uint32_t)ENCODE_WAVES_PER_WG + wave;
+    const uint32_t n_work = uni(g.hdr->n_work);
+    if (w >= n_work) return;
+    const uint32_t it = uni(g.work[w]);
+    const SegItem s = g.items[it];
+    const long long b = (long long)s.block;
+    const int U = a.srcLen[b];
+    SegRun r = seg_run_of(g, it, s);
+    const uint32_t end = s.next_start != SEG_NONE ? s.next_start : (uint32_t)U;
+    const int ret = compress_fast_block<false, false, false>(a.src + a.srcOff[b], U, a.dst + a.dstOff[b] + s.start, (int)(end - s.start), a.accel, stages[wave], lane,
+                                                             g.tables + 4096ull * (unsigned long long)w, (a.flags & FLAG_X32) != 0, nullptr, &r);
+    if (lane == 0) {
+        g.items[it].cut = r.cut; g.items[it].stop = r.stop; g.items[it].state = ret > 0 ? r.state : 3u; g.items[it].bytes = ret;
+    }
+}
+
+/* Per cut block, after every encoder kernel of the launch: join or encode again.  outLen gets what the block's encoder call
+ * returns (LLxx level with FLAG_RAW_RETURN, else the LZ4Codec mapping). */
+__global__ __launch_bounds__(64) void k4_seg_join_kernel(BatchArgs a, SegArgs g)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tab[ENCODE_LDS_DWORDS];
+    const int lane = lane_id();
+    const uint32_t n_blocks = uni(g.hdr->n_blocks);
+    if (blockIdx.x >= n_blocks) return;
+    const long long b = (long long)uni(g.blocks[blockIdx.x]);
+    const int32_t base = g.first[b];
+    if (base < 0) return;
+    const int U = a.srcLen[b], cap = a.dstCap[b];
+    const uint8_t *src = a.src + a.srcOff[b];
+    uint8_t *dst = a.dst + a.dstOff[b];
+    const uint32_t nseg = uni(g.items[base].nseg);
+    /* every segment must begin where the one before it stopped, and the last must have run to the end */
+    bool ok = true;
+    uint32_t at = 0u;
+    long long total = 0;
+    for (uint32_t k = 0; k < nseg && ok; k++) {
+        const SegItem s = g.items[(uint32_t)base + k];
+        ok = s.bytes > 0 && s.cut == at && (k + 1u < nseg ? s.state == 1u : s.state == 2u);
+        at = s.stop;
+        total += s.bytes;
+    }
+    ok = ok && total <= (long long)cap;
+    int ret;
+    if (ok) {
+        uint32_t out = (uint32_t)uni((uint32_t)g.items[base].bytes);
+        for (uint32_t k = 1; k < nseg; k++) {                /* a piece lies at or behind where it belongs: forward copies */
+            const uint32_t start = uni(g.items[(uint32_t)base + k].start), nb = uni((uint32_t)g.items[(uint32_t)base + k].bytes);
+            wave_sync();
+            if (out != start) wave_shift_down(dst + out, dst + start, nb, lane);
+            out += nb;
+        }
+        ret = (int)out;
+    } else {
+        wave_sync();
+        ret = compress_fast_block<true, false>(src, U, dst, cap < 0 ? 0 : cap, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0);
+    }
+    if (lane == 0) a.outLen[b] = codec_encode_result(U, ret, a.flags);
+}
+
+}  // namespace k4

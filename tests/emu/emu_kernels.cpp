@@ -4,6 +4,7 @@
 #include "k4lz4_decode.hpp"
 #include "k4lz4_encode_fast.hpp"
 #include "k4lz4_pickle.hpp"
+#include "k4lz4_segments.hpp"
 #include "k4lz4_encode_hc.hpp"
 #include "k4lz4_frame.hpp"
 #include "k4lz4_xxh32.hpp"
@@ -144,6 +145,60 @@ int k4emu_pickle_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t
     k4::BatchArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, 1, flags, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n <= 0) return 0;
     k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_pickle_kernel(a); }, threads);
+    return 0;
+}
+
+/* Fast-level pickles the way the launcher sends a batch that may hold big messages: slots prepared, big messages cut into
+ * segments (plan on the "device"), their later segments by k4_encode_seg_kernel, everything else -- first segments included --
+ * by the LDS-table kernel's segment twin, pieces joined, envelopes closed.  stats[0..2] = cut blocks, segments, blocks whose
+ * every boundary verified (the others were encoded again by the join kernel). */
+int k4emu_pickle_seg_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                           const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int flags,
+                           unsigned seg_min, unsigned seg_target, unsigned seg_warm, unsigned *stats, int threads)
+{
+    if (n <= 0) return 0;
+    std::vector<uint64_t> encOff((size_t)n);
+    std::vector<int32_t> encCap((size_t)n), encLen((size_t)n, 0), first((size_t)n, -1);
+    k4::BatchArgs a{};
+    a.src = src; a.srcOff = srcOff; a.srcLen = srcLen; a.dst = dst; a.dstOff = dstOff; a.dstCap = dstCap; a.outLen = outLen;
+    a.n = n; a.accel = 1; a.flags = flags;
+    uint64_t *eo = encOff.data(); int32_t *ec = encCap.data();
+    k4emu::launch_fn(dim3((unsigned)((n + 255) / 256)), dim3(256), [=] { k4::k4_pickle_prep_kernel(a, eo, ec); }, 1);
+    k4::BatchArgs e = a;
+    e.dstOff = encOff.data(); e.dstCap = encCap.data(); e.outLen = encLen.data(); e.flags = (flags & k4::FLAG_X32) | k4::FLAG_RAW_RETURN;
+    k4::SegHdr hdr{};
+    std::vector<k4::SegItem> items((size_t)k4::SEG_MAX_ITEMS);
+    std::vector<uint32_t> work((size_t)k4::SEG_MAX_ITEMS), blocks((size_t)k4::SEG_MAX_BLOCKS);
+    k4::SegArgs g{};
+    g.hdr = &hdr; g.items = items.data(); g.work = work.data(); g.blocks = blocks.data(); g.first = first.data();
+    g.seg_min = seg_min; g.seg_target = seg_target; g.seg_warm = seg_warm; g.seg_div = 0u;
+    std::vector<uint32_t> snaps(64), tables(64);
+    /* the plan first with room for the flags only, then the real arrays sized by what it planned */
+    snaps.assign((size_t)k4::SEG_MAX_ITEMS * k4::SEG_SNAP_DWORDS, 0u);
+    g.snaps = snaps.data();
+    k4emu::launch_fn(dim3(1), dim3(256), [=] { k4::k4_seg_plan_kernel(e, g); }, 1);
+    tables.assign((size_t)(hdr.n_work + 2u) * 4096u, 0u);
+    g.tables = tables.data();
+    e.seg_first = g.first; e.seg_items = g.items; e.seg_snaps = g.snaps;
+    if (hdr.n_work)
+        k4emu::launch_fn(dim3((hdr.n_work + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG), dim3(64 * k4::ENCODE_WAVES_PER_WG), [=] { k4::k4_encode_seg_kernel(e, g); }, 1);
+    k4emu::launch_fn(dim3((unsigned)((n + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG), [=] { k4::k4_encode_fast_seg_kernel(e); }, threads);
+    if (stats) {
+        stats[0] = hdr.n_blocks; stats[1] = hdr.n_items; stats[2] = 0;
+        for (uint32_t i = 0; i < hdr.n_blocks; i++) {
+            const int32_t base = first[blocks[i]];
+            bool ok = true; uint32_t at = 0;
+            for (uint32_t k = 0; k < items[base].nseg && ok; k++) {
+                const k4::SegItem &s = items[base + k];
+                ok = s.bytes > 0 && s.cut == at && (k + 1 < s.nseg ? s.state == 1u : s.state == 2u);
+                at = s.stop;
+            }
+            stats[2] += ok ? 1u : 0u;
+        }
+    }
+    if (hdr.n_blocks) k4emu::launch_fn(dim3(hdr.n_blocks), dim3(64), [=] { k4::k4_seg_join_kernel(e, g); }, threads);
+    const int32_t *el = encLen.data();
+    k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_pickle_finish_kernel(a, el); }, threads);
     return 0;
 }
 

@@ -64,6 +64,7 @@ class Emu:
         self.lib.k4emu_encode_hc_batch.argtypes = b + [C.c_int, C.c_int, C.c_int]
         self.lib.k4emu_order.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         self.lib.k4emu_pickle_batch.argtypes = b + [C.c_int, C.c_int, C.c_int]
+        self.lib.k4emu_pickle_seg_batch.argtypes = b + [C.c_int, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_int]
         self.lib.k4emu_unpickle_batch.argtypes = b + [C.c_int, C.c_int]
         self.lib.k4emu_unpickle_pair_batch.argtypes = b + [C.c_int, C.c_int]
         self.lib.k4emu_unpickle_sizes.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int]
@@ -102,6 +103,16 @@ class Emu:
                                          len(src_len), level, flags, threads)
         assert rc == 0
         return out
+
+    def pickle_seg_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, seg_min, seg_target, seg_warm, flags=0, threads=0):
+        """pickles with big messages cut into segments (k4lz4_segments.hpp): returns (lengths, [cut blocks, segments, blocks joined])"""
+        out = np.zeros(src_len.size, np.int32)
+        stats = np.zeros(4, np.uint32)
+        rc = self.lib.k4emu_pickle_seg_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
+                                             dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data, src_len.size, flags,
+                                             seg_min, seg_target, seg_warm, stats.ctypes.data, threads)
+        assert rc == 0
+        return out, stats
 
     def unpickle_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, flags=0, threads=0):
         out = np.full(len(src_len), -12345, dtype=np.int32)

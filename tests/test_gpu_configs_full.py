@@ -79,6 +79,45 @@ def test_config3_pickle_one_ranks_share_every_envelope_vs_oracle(oracle):
     assert not bad, f"{len(bad)} of {n} messages differ, first {bad[:5]} (packed={packed})"
 
 
+def test_big_messages_in_segments_every_envelope_vs_oracle(oracle, monkeypatch):
+    """k4lz4_segments.hpp on the device: messages cut into segments that are encoded by a wave each and joined -- with the
+    shipped sizes (1.5 MiB and more, 384 KiB of warm-up: the text-like ones join) and with tiny segments and warm-ups (most
+    boundaries do not verify: those messages are encoded again by the join kernel).  Every envelope equals oracle.pickle,
+    nothing outside a slot's envelope is written, and a batch of one big message alone takes the same path."""
+    import torch
+    from k4os.compression.lz4_amd.device import DeviceBatch, DeviceCodec
+    names = ["dickens", "xml", "samba", "webster", "nci", "mozilla", "reymont", "osdb"]
+    sizes = [4 << 20, 3 << 20, (5 << 19) + 12345, 2 << 20, 1600000, 4 << 20, 1 << 20, 3500000, 700000, 65536 + 4096, 2500000, 1000]
+    msgs = [corpus.class_bytes(names[i % len(names)], s, 7 + i) if i != 5 else corpus.random_bytes(s, 3) for i, s in enumerate(sizes)]
+    msgs.append(np.concatenate([corpus.class_bytes("dickens", 1500000, 1), corpus.random_bytes(900000, 4), corpus.class_bytes("dickens", 1200000, 2)]))
+    lens = np.array([m.size for m in msgs], np.int32)
+    off = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.uint64)
+    data = np.concatenate(msgs)
+    want = [oracle.pickle(m) for m in msgs]
+    for env_vars in ({}, {"K4LZ4_SEG_MIN": "70000", "K4LZ4_SEG_TARGET": "49152", "K4LZ4_SEG_WARM": "24576", "K4LZ4_SEG_DIV": "0"},
+                     {"K4LZ4_SEG_MIN": "300000", "K4LZ4_SEG_TARGET": "200000", "K4LZ4_SEG_WARM": "400000", "K4LZ4_SEG_DIV": "0"}):
+        for k in ("K4LZ4_SEG_MIN", "K4LZ4_SEG_TARGET", "K4LZ4_SEG_WARM", "K4LZ4_SEG_DIV"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env_vars.items():
+            monkeypatch.setenv(k, v)
+        dc = DeviceCodec(0)                                   # the switches are read when a context is created
+        src = DeviceBatch.from_host(data, off, lens, dc.device)
+        env = DeviceBatch.empty_slots(lens.astype(np.int64) + 5, dc.device, fill=0xCD)
+        plen = dc.pickle(src, env)
+        torch.cuda.synchronize()
+        eh, eoff, pl = env.data.cpu().numpy(), env.off.cpu().numpy(), plen.cpu().numpy()
+        for i, m in enumerate(msgs):
+            assert eh[eoff[i]:eoff[i] + pl[i]].tobytes() == want[i], f"message {i} ({m.size} B) with {env_vars}"
+            end = int(eoff[i + 1]) if i + 1 < len(msgs) else eh.size
+            assert (eh[eoff[i] + max(int(pl[i]), int(lens[i]) + 5):end] == 0xCD).all(), f"message {i}: bytes behind the slot touched"
+        one = DeviceBatch.from_host(msgs[0], np.zeros(1, np.uint64), lens[:1], dc.device)
+        env1 = DeviceBatch.empty_slots(lens[:1].astype(np.int64) + 5, dc.device, fill=0xCD)
+        p1 = dc.pickle(one, env1)
+        torch.cuda.synchronize()
+        o1 = int(env1.off.cpu().numpy()[0])
+        assert env1.data.cpu().numpy()[o1:o1 + int(p1.cpu().numpy()[0])].tobytes() == want[0]
+
+
 def test_config4_hc_l03_all_4096_blocks_vs_oracle(oracle):
     """configs[4]: L03_HC over the 4096 x 64 KiB batch: every block's bytes and the ratio equal the oracle's"""
     import torch
