@@ -438,7 +438,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
         auto segments_join = [&]() -> int {
             if (!seg) return K4LZ4_OK;
             K4_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_join2, 0));
-            hipLaunchKernelGGL(k4::k4_seg_join_kernel, dim3((unsigned)k4::SEG_MAX_BLOCKS), dim3(64), 0, stream, a, sg);
+            hipLaunchKernelGGL(k4::k4_seg_join_kernel, dim3((unsigned)std::min<int64_t>(k4::SEG_MAX_BLOCKS, cnt)), dim3(64), 0, stream, a, sg);
             return K4LZ4_OK;
         };
         if (dd && dd->dict) {

@@ -318,7 +318,7 @@ __device__ __forceinline__ void hop_chain_pairs(unsigned long long &hmx, unsigne
  */
 constexpr uint32_t SEG_NONE = 0xffffffffu;
 constexpr int SEG_SNAP_DWORDS = 4096 + 16;          /* [0] cut + 1 (0: not there yet, SEG_NONE: this run never found one), [16..] the table */
-constexpr uint32_t SEG_SPIN_MAX = 1u << 22;
+constexpr uint32_t SEG_SPIN_MAX = 1u << 20;          /* polls (with s_sleep 8 between them: some tenths of a second) before a run stops waiting for the next one's cut */
 struct SegRun {
     uint32_t begin;             /* where the run starts probing: 0, or the start of the warm-up */
     uint32_t emit_from;         /* 0: output from the start; else nothing is written before the first match end at or behind this position */
