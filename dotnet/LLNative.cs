@@ -16,7 +16,7 @@ namespace K4os.Compression.LZ4.Engine
 
 		// k4lz4_flags
 		public const int FLAG_RAW_RETURN = 1, FLAG_PICKLE_WRITER = 2, FLAG_NO_REORDER = 4, FLAG_REORDER = 8, FLAG_NO_SPLIT = 16,
-			FLAG_PARTIAL = 32, FLAG_ALLOW_COPY = 64, FLAG_X32 = 128;
+			FLAG_PARTIAL = 32, FLAG_ALLOW_COPY = 64, FLAG_X32 = 128, FLAG_SEGMENTS = 256;
 
 		[DllImport(Lib)] public static extern int k4lz4_version();
 		[DllImport(Lib)] public static extern int k4lz4_device_count();

@@ -75,7 +75,11 @@ enum k4lz4_flags {
                                      outLen = 0 where the reference throws "target buffer too small" (Encoders/LZ4EncoderBase.cs:66-88) */
     K4LZ4_FLAG_X32 = 128,         /* fast encode / pickle: the 32-bit engine's bytes (LZ4Codec.Enforce32, LZ4Codec.cs:14-25): inputs of
                                      64 KiB and more are hashed with LZ4_hash4 instead of LZ4_hash5 (x32/LL32.tools.cs:141-148) */
-    K4LZ4_FLAG_PARTIAL = 32       /* decode: LZ4Codec.PartialDecode -- stop once dstCap[i] bytes are produced (LZ4Codec.cs:123-173) */
+    K4LZ4_FLAG_PARTIAL = 32,      /* decode: LZ4Codec.PartialDecode -- stop once dstCap[i] bytes are produced (LZ4Codec.cs:123-173) */
+    K4LZ4_FLAG_SEGMENTS = 256     /* fast encode: blocks of 1.5 MiB and more that are also a large share of the batch may be encoded by several
+                                     wavefronts (segments whose joints are verified; a block that does not verify is encoded again by one), see
+                                     DESIGN.md 4.6 -- same bytes, a 4 MiB block in 50 ms instead of 165; needs dstCap[i] >= srcLen[i] - 1 and
+                                     may write anywhere inside a block's slot before outLen is final.  The pickle calls do this by themselves. */
 };
 
 K4LZ4_API int k4lz4_version(void);

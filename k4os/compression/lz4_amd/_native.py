@@ -20,6 +20,7 @@ FLAG_NO_SPLIT = 16
 FLAG_PARTIAL = 32
 FLAG_X32 = 128
 FLAG_ALLOW_COPY = 64
+FLAG_SEGMENTS = 256
 
 _u8p = C.c_void_p
 _BATCH = [C.c_void_p, _u8p, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]

@@ -407,7 +407,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
          * their own beside the ordinary kernels (which take a cut block's first segment), the pieces are joined afterwards */
         k4::SegArgs sg{};
         bool seg = false;
-        if (kind == KIND_ENCODE && (flags & FLAG_SEGMENTS_OK) && ctx->use_segments && !a.prof && !(flags & K4LZ4_FLAG_ALLOW_COPY)) {
+        if (kind == KIND_ENCODE && (flags & (FLAG_SEGMENTS_OK | K4LZ4_FLAG_SEGMENTS)) && ctx->use_segments && !a.prof && !(flags & K4LZ4_FLAG_ALLOW_COPY)) {
             const size_t o_items = 256, o_work = o_items + (size_t)k4::SEG_MAX_ITEMS * sizeof(k4::SegItem);
             const size_t o_blocks = o_work + (size_t)k4::SEG_MAX_ITEMS * 4, o_snaps = (o_blocks + (size_t)k4::SEG_MAX_BLOCKS * 4 + 255) & ~(size_t)255;
             const size_t o_tables = o_snaps + (size_t)k4::SEG_MAX_ITEMS * k4::SEG_SNAP_DWORDS * 4, total = o_tables + (size_t)k4::SEG_MAX_ITEMS * 16384;

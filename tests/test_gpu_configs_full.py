@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from k4os.compression.lz4_amd import LZ4Codec, LZ4Level, corpus, make_arena
-from k4os.compression.lz4_amd._native import FLAG_RAW_RETURN
+from k4os.compression.lz4_amd._native import FLAG_RAW_RETURN, FLAG_SEGMENTS
 from k4os.compression.lz4_amd.sharding import byte_balanced_ranges
 
 pytestmark = pytest.mark.gpu
@@ -110,6 +110,13 @@ def test_big_messages_in_segments_every_envelope_vs_oracle(oracle, monkeypatch):
             assert eh[eoff[i]:eoff[i] + pl[i]].tobytes() == want[i], f"message {i} ({m.size} B) with {env_vars}"
             end = int(eoff[i + 1]) if i + 1 < len(msgs) else eh.size
             assert (eh[eoff[i] + max(int(pl[i]), int(lens[i]) + 5):end] == 0xCD).all(), f"message {i}: bytes behind the slot touched"
+        # ... and LZ4Codec.Encode of the same blocks with K4LZ4_FLAG_SEGMENTS
+        comp = DeviceBatch.empty_slots([LZ4Codec.MaximumOutputSize(int(n)) for n in lens], dc.device, fill=0xCD)
+        clen = dc.encode(src, comp, flags=FLAG_SEGMENTS)
+        torch.cuda.synchronize()
+        ch, coff, cl = comp.data.cpu().numpy(), comp.off.cpu().numpy(), clen.cpu().numpy()
+        for i, m in enumerate(msgs):
+            assert ch[coff[i]:coff[i] + cl[i]].tobytes() == oracle.encode(m), f"block {i} ({m.size} B) with {env_vars}"
         one = DeviceBatch.from_host(msgs[0], np.zeros(1, np.uint64), lens[:1], dc.device)
         env1 = DeviceBatch.empty_slots(lens[:1].astype(np.int64) + 5, dc.device, fill=0xCD)
         p1 = dc.pickle(one, env1)
