@@ -1115,7 +1115,15 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_pace, k4::PACE_BYTES);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copyq, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux2, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        /* the later segments of cut blocks are the longest jobs of their launch and others wait for their cuts: the queue they
+         * are dispatched from comes first when the chip is full (K4LZ4_SEG_PRIO=0: an ordinary queue) */
+        int least = 0, greatest = 0;
+        const char *pe = getenv("K4LZ4_SEG_PRIO");
+        if ((!pe || atoi(pe) != 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            e = hipStreamCreateWithPriority(&ctx->aux2, hipStreamNonBlocking, greatest);
+        else { (void)hipGetLastError(); e = hipStreamCreateWithFlags(&ctx->aux2, hipStreamNonBlocking); }
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);

@@ -325,6 +325,8 @@ struct SegRun {
     uint32_t stop_at;           /* SEG_NONE: to the end of the block; else stop at the first match end at or behind this position ... */
     uint32_t *snap_pub;         /* where a warm run publishes its cut and table, or nullptr */
     const uint32_t *snap_chk;   /* ... if it is the cut published here, with an equal table; or nullptr */
+    const uint32_t *resume;     /* nullptr, or the table published at position `begin`, a verified cut: the run goes on from there as the
+                                 * true run would (cursor right behind a match), writing from its first sequence */
     uint32_t cut, stop, state;  /* results: first position of the output (the cut; 0), one past its last (verified cut, or U),
                                  * 1 stopped at a verified cut, 2 ran to the end of the block, 3 no use (not in step, no cut, no room) */
 };
@@ -400,6 +402,9 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
     constexpr uint32_t SEEN_SHIFT = BYU16 ? 1u : 0u;        /* hash value -> bit of `seen` */
     const unsigned long long me = 1ull << lane, below_me = me - 1ull;
 
+    const bool resumed = sr && uni(sr->resume != nullptr ? 1u : 0u) != 0u;
+    if (resumed) { for (int k = lane; k < 4096; k += 64) tabmem[k] = sr->resume[k]; }
+    else
     for (int k = lane; k < 1024; k += 64) ((uint4 *)tabmem)[k] = make_uint4(0u, 0u, 0u, 0u);
     for (int k = lane; k < ENCODE_SCRATCH_BYTES / 4; k += 64) seen[k] = 0u;
     wave_sync();
@@ -496,12 +501,13 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
 
         const uint32_t begin = sr_begin;      /* (a warm run: the block as if it began here) */
         anchor = begin;
-        if (lane == 0) tab.put(Table::hash(src + begin), begin);     /* :119-122 */
-        uint32_t ip = begin + 1u;       /* cursor of a fresh round */
+        emitted_to = begin;
+        if (lane == 0 && !resumed) tab.put(Table::hash(src + begin), begin);     /* :119-122 */
+        uint32_t ip = resumed ? begin : begin + 1u;       /* cursor of a fresh round */
         uint32_t sbase = begin + 1u;    /* where the current search loop started (:466) */
         uint32_t flag_pos = cut_pos < mflimit_plus_one ? cut_pos : mflimit_plus_one;   /* hits whose match ends here or later leave the chain */
         uint32_t jbase = 0;    /* probes of the current search already done (0: fresh round) */
-        bool test = false;     /* fresh round only: `ip` is the position right after a match (:393-463) */
+        bool test = resumed;   /* fresh round only: `ip` is the position right after a match (:393-463) */
 
         /* the 64 probe positions of a round and their source bytes; issued for the NEXT round before the
          * current one commits and emits, so that the loads fly during that work */
@@ -1018,7 +1024,7 @@ __device__ __forceinline__ SegFirst seg_first_of(const BatchArgs &a, long long b
 {
     SegFirst f;
     f.cut = false; f.cap = 0u;
-    f.run.begin = 0u; f.run.emit_from = 0u; f.run.stop_at = SEG_NONE; f.run.snap_pub = nullptr; f.run.snap_chk = nullptr;
+    f.run.begin = 0u; f.run.emit_from = 0u; f.run.stop_at = SEG_NONE; f.run.snap_pub = nullptr; f.run.snap_chk = nullptr; f.run.resume = nullptr;
     f.run.cut = 0u; f.run.stop = 0u; f.run.state = 3u;
     if (!a.seg_first) return f;
     const int32_t it = (int32_t)uni((uint32_t)a.seg_first[b]);

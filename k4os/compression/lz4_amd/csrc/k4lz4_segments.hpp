@@ -15,8 +15,9 @@
  *                          output into the block's slot at the segment's own offset (a piece never outgrows its span: a
  *                          segment that does not shrink gives up), stop at the next segment's verified cut
  *   the ordinary kernels   take the first segment of a cut block like any block, with the stop rule (their *_seg twins)
- *   k4_seg_join_kernel     per cut block: every boundary verified -> the pieces moved down next to each other, total
- *                          length; otherwise the whole block once more, plainly
+ *   k4_seg_join_kernel     per cut block: the pieces up to the first boundary that did not verify are moved down next to each
+ *                          other; if that was all of them, their total is the block's length; otherwise one wave encodes the
+ *                          rest from the last verified cut (its table was published there), or the whole block if there is none
  */
 #pragma once
 #include "k4lz4_encode_fast.hpp"
@@ -120,6 +121,7 @@ __device__ __forceinline__ SegRun seg_run_of(const SegArgs &g, uint32_t it, cons
     r.stop_at = s.next_start;
     r.snap_pub = s.k ? g.snaps + (size_t)it * SEG_SNAP_DWORDS : nullptr;
     r.snap_chk = s.next_start != SEG_NONE ? g.snaps + (size_t)(it + 1u) * SEG_SNAP_DWORDS : nullptr;
+    r.resume = nullptr;
     r.cut = 0u; r.stop = 0u; r.state = 3u;
     return r;
 }
@@ -161,27 +163,39 @@ __global__ __launch_bounds__(64) void k4_seg_join_kernel(BatchArgs a, SegArgs g)
     const uint8_t *src = a.src + a.srcOff[b];
     uint8_t *dst = a.dst + a.dstOff[b];
     const uint32_t nseg = uni(g.items[base].nseg);
-    /* every segment must begin where the one before it stopped, and the last must have run to the end */
-    bool ok = true;
-    uint32_t at = 0u;
+    /* every segment must begin where the one before it stopped, and the last must have run to the end: `good` pieces do */
+    uint32_t good = 0, at = 0u;
     long long total = 0;
-    for (uint32_t k = 0; k < nseg && ok; k++) {
+    bool whole = false;
+    for (uint32_t k = 0; k < nseg; k++) {
         const SegItem s = g.items[(uint32_t)base + k];
-        ok = s.bytes > 0 && s.cut == at && (k + 1u < nseg ? s.state == 1u : s.state == 2u);
-        at = s.stop;
-        total += s.bytes;
+        if (!(s.bytes > 0 && s.cut == at && (s.state == 1u || s.state == 2u) && total + s.bytes <= (long long)cap)) break;
+        good = k + 1u; at = s.stop; total += s.bytes;
+        if (s.state == 2u) { whole = true; break; }
     }
-    ok = ok && total <= (long long)cap;
     int ret;
-    if (ok) {
-        uint32_t out = (uint32_t)uni((uint32_t)g.items[base].bytes);
-        for (uint32_t k = 1; k < nseg; k++) {                /* a piece lies at or behind where it belongs: forward copies */
+    uint32_t out = 0;
+    if (good) {
+        out = (uint32_t)uni((uint32_t)g.items[base].bytes);
+        for (uint32_t k = 1; k < good; k++) {                /* a piece lies at or behind where it belongs: forward copies */
             const uint32_t start = uni(g.items[(uint32_t)base + k].start), nb = uni((uint32_t)g.items[(uint32_t)base + k].bytes);
             wave_sync();
             if (out != start) wave_shift_down(dst + out, dst + start, nb, lane);
             out += nb;
         }
+    }
+    if (whole) {
         ret = (int)out;
+    } else if (good && good < nseg) {
+        /* a boundary did not verify (or a piece gave up): `at` is the last verified cut and segment `good` published the table there --
+         * one wave goes on from that state to the end of the block, behind the pieces that stand */
+        wave_sync();
+        SegRun r;
+        r.begin = at; r.emit_from = 0u; r.stop_at = SEG_NONE; r.snap_pub = nullptr; r.snap_chk = nullptr;
+        r.resume = g.snaps + (size_t)((uint32_t)base + good) * SEG_SNAP_DWORDS + 16u;
+        r.cut = 0u; r.stop = 0u; r.state = 3u;
+        const int more = compress_fast_block<true, false>(src, U, dst + out, cap - (int)out, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0, nullptr, &r);
+        ret = more > 0 ? (int)out + more : 0;
     } else {
         wave_sync();
         ret = compress_fast_block<true, false>(src, U, dst, cap < 0 ? 0 : cap, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0);
