@@ -399,7 +399,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
         a.flags = flags | (g_enforce32.load(std::memory_order_relaxed) ? K4LZ4_FLAG_X32 : 0);
         a.prof = ctx->prof ? ctx->prof + k4::PROF_STRIDE * first : nullptr;
         a.status = ctx->d_status;
-        if (kind == KIND_ENCODE && ctx->use_pace && ctx->d_pace && cnt > 8 * (int64_t)ctx->cu_count) {   /* k4lz4_common.hpp, Pace: more than two blocks per SIMD */
+        if ((kind == KIND_ENCODE || (K4_DEC_PACE && (kind == KIND_DECODE || kind == KIND_UNPICKLE))) && ctx->use_pace && ctx->d_pace && cnt > 8 * (int64_t)ctx->cu_count) {   /* k4lz4_common.hpp, Pace: more than two blocks per SIMD */
             a.pace = ctx->d_pace;
             K4_HIP(ctx, hipMemsetAsync(a.pace, 0, k4::PACE_BYTES, stream));
         }

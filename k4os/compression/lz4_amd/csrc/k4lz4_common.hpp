@@ -185,7 +185,9 @@ __device__ __forceinline__ uint32_t agent_peek(const uint32_t *p)
  * launch was tried first and cost 35 %); nothing depends on it but timing.  Measured on the bench batch (4096 x 64 KiB, both
  * encoder kernels side by side): 62.2 -> 63.3 GiB/s over giving the younger kernel's waves the priority three steps in four;
  * tiers at 1/32 of the latest estimate, a report every 2 KiB, epochs of 164 us (1/16 and 1/8 tiers, 4 KiB steps measured
- * 62.9 / 61.8 / 63.0).  The pair decoder gained nothing from it (its spread is not an issue-slot matter) and does not use it.
+ * 62.9 / 61.8 / 63.0).  The pair decoders use it with BOTH waves of a pair at the block's priority (the parsing wave decides, the
+ * copying wave reads the level from the pair's queue): 245 -> 290 GiB/s on the bench batch (k4lz4_decode.hpp, K4_DEC_PACE; with
+ * the parsing wave alone at the priority it had lost 2 %).
  *   slot (16 bytes, index from XCC_ID and HW_ID: se, sh, cu, simd):  [0], [1]  epoch << 20 | F in 80 ns units, even / odd
  *   epochs      [2]  ~(earliest start on this SIMD)
  */
@@ -235,11 +237,23 @@ struct Pace {
 #endif
     }
     /* `done` of `total` units of the block are behind this wave (0 < done <= total) */
-    template <uint32_t EPOCH_LOG2 = PACE_EPOCH_LOG2>
-    __device__ __forceinline__ static void update(uint32_t *base, const uint32_t *mine, uint32_t done, uint32_t total, int lane)
+    __device__ __forceinline__ static void set_level(int level)
     {
 #ifndef K4_HOST_EMU
-        if (!base) return;
+        if (level >= 3) __builtin_amdgcn_s_setprio(3);
+        else if (level == 2) __builtin_amdgcn_s_setprio(2);
+        else if (level == 1) __builtin_amdgcn_s_setprio(1);
+        else if (level == 0) __builtin_amdgcn_s_setprio(0);
+#else
+        (void)level;
+#endif
+    }
+    /* returns the priority taken (0..3), or -1 when there was nothing to compare with yet */
+    template <uint32_t EPOCH_LOG2 = PACE_EPOCH_LOG2, uint32_t DEN = K4_PACE_DEN>
+    __device__ __forceinline__ static int update(uint32_t *base, const uint32_t *mine, uint32_t done, uint32_t total, int lane)
+    {
+#ifndef K4_HOST_EMU
+        if (!base) return -1;
         uint32_t *w = slot_of(base);
         uint32_t ref = 0, t0inv = 0, cur = 0;
         if (lane == 0) {
@@ -257,14 +271,14 @@ struct Pace {
         const uint32_t epoch = ((t - t0) >> EPOCH_LOG2) & 0xfffu;
         if (lane == 0) atomicMax(w + (epoch & 1u), (epoch << 20) | fs);
         const uint32_t before = (epoch & 1u) ? w0 : w1;                 /* the other word: the epoch before, if anybody reported in it */
-        if ((before >> 20) != ((epoch - 1u) & 0xfffu)) return;
+        if ((before >> 20) != ((epoch - 1u) & 0xfffu)) return -1;
         const uint32_t last = before & 0xfffffu;
-        if (fs * K4_PACE_DEN >= last * (K4_PACE_DEN - 1u)) __builtin_amdgcn_s_setprio(3);
-        else if (fs * K4_PACE_DEN >= last * (K4_PACE_DEN - 2u)) __builtin_amdgcn_s_setprio(2);
-        else if (fs * K4_PACE_DEN >= last * (K4_PACE_DEN - 3u)) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
+        const int level = fs * DEN >= last * (DEN - 1u) ? 3 : fs * DEN >= last * (DEN - 2u) ? 2 : fs * DEN >= last * (DEN - 3u) ? 1 : 0;
+        set_level(level);
+        return level;
 #else
         (void)base; (void)mine; (void)done; (void)total; (void)lane;
+        return -1;
 #endif
     }
 };

@@ -49,6 +49,22 @@ namespace k4 {
 #ifndef K4_DEC_WAVE_AT
 #define K4_DEC_WAVE_AT 128
 #endif
+/* late blocks first for the decoder pairs (k4lz4_common.hpp, Pace): a report every 2^STEP compressed bytes, epochs of 2^EPOCH
+ * ticks of 10 ns, priority tiers 1/DEN apart.  Measured on the bench batch: 245 GiB/s without, 265 / 281 / 290 / 287 with steps of
+ * 4 / 2 / 1 / 0.5 KiB (epochs to match), 281 / 290 / 287 / 277 with tiers of 1/16 / 1/32 / 1/64 / 1/128; with the parsing wave
+ * alone taking the priority (the first attempt) 241. */
+#ifndef K4_DEC_PACE
+#define K4_DEC_PACE 1
+#endif
+#ifndef K4_DEC_PACE_STEP
+#define K4_DEC_PACE_STEP 10
+#endif
+#ifndef K4_DEC_PACE_EPOCH
+#define K4_DEC_PACE_EPOCH 10
+#endif
+#ifndef K4_DEC_PACE_DEN
+#define K4_DEC_PACE_DEN 32u
+#endif
 constexpr int DECODE_STAGE_BYTES = K4_DEC_STAGE;          /* a batch's output, kept in LDS while its matches resolve */
 constexpr int DECODE_LDS_DWORDS = RING_DWORDS + 5 * 64 + (DECODE_STAGE_BYTES + 64) / 4;   /* ring + 5 descriptor arrays + stage */
 constexpr int MAX_SEQ_PER_ROUND = 22;            /* 64 hypotheses, >= 3 stream bytes per sequence */
@@ -305,7 +321,7 @@ template <bool PROF = false, int ROLE = 0>
 __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uint8_t *out, int out_size, int lane,
                                             uint32_t *lds, unsigned long long *pc = nullptr, bool partial = false,
                                             DecodeDict dict = DecodeDict{nullptr, 0u, 0}, uint32_t *pipe = nullptr,
-                                            uint32_t *seq = nullptr)
+                                            uint32_t *seq = nullptr, uint32_t *pace = nullptr)
 {
     /* lowPrefix relative to out (<= 0), the size used by the offset check (:149,:338) */
     const int64_t low_prefix = dict.mode == 1 ? -(int64_t)dict.size : 0;
@@ -348,6 +364,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
         /* ======================= PARSE ======================= */
         const unsigned long long t0 = prof_now<PROF>();
         int64_t op_batch = op;
+        const uint32_t ip_batch = (uint32_t)ip;
         int nseq = 0;
         int err = 0;
         bool done = false;
@@ -370,6 +387,9 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 done = uni(meta[3]) != 0u;
                 err = (int)uni(meta[4]);                    /* the block's result, valid with `done` */
                 gap = uni(meta[5]) != 0u;
+#if K4_DEC_PACE
+                if (pace) { const uint32_t lv = uni(pipe[3]); if (lv) Pace::set_level((int)lv - 1); }
+#endif
             }
         }
         /* a batch is closed when it may not take another round's sequences, or when its output nears what the stage holds */
@@ -596,6 +616,14 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             }
             pipe_store(pipe + 0, batch_no + 1u, lane);
             batch_no++;
+#if K4_DEC_PACE
+            /* late blocks first (k4lz4_common.hpp, Pace): every K4_DEC_PACE_STEP compressed bytes the parsing wave takes its block's
+             * priority and leaves it in pipe[3] for the copying wave */
+            if (pace && (((uint32_t)ip ^ ip_batch) >> K4_DEC_PACE_STEP) != 0u && !done && !err) {
+                const int level = Pace::update<K4_DEC_PACE_EPOCH, K4_DEC_PACE_DEN>(pace, pipe + 2, (uint32_t)ip, (uint32_t)src_size, lane);
+                if (level >= 0 && lane == 0) pipe[3] = (uint32_t)level + 1u;
+            }
+#endif
             if (PROF) { c_parse += prof_now<PROF>() - t0; n_batch++; n_seq += (unsigned long long)nseq; }
             if (err || done) {
                 if (seq) *seq = batch_no;
@@ -872,10 +900,11 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
     const DecodeDict dict = block_dict(a, b, out);
     if (role == 0) {
         if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 8, lane);
-        if (run) decode_block<false, 1>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, nullptr, partial, dict, pipe);
+        if (K4_DEC_PACE) Pace::begin(a.pace, pipe + 2, lane);
+        if (run) decode_block<false, 1>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, nullptr, partial, dict, pipe, nullptr, a.pace);
     } else {
         int ret = 0;
-        if (run) ret = decode_block<false, 2>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, nullptr, partial, dict, pipe);
+        if (run) ret = decode_block<false, 2>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, nullptr, partial, dict, pipe, nullptr, a.pace);
         if (lane == 0) a.outLen[b] = codec_decode_result(src_len, ret, a.flags);
         if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 9, lane);
     }

@@ -90,7 +90,7 @@ __device__ __forceinline__ PickleHeader unpickle_header(const uint8_t *src, int 
  * -1 where the reference throws (unpickle.cs:115-128,:134,:143-144) */
 template <int ROLE = 0>
 __device__ __forceinline__ int unpickle_block(const uint8_t *src, int len, uint8_t *dst, int cap, int lane, uint32_t *lds,
-                                              uint32_t *pipe = nullptr)
+                                              uint32_t *pipe = nullptr, uint32_t *pace = nullptr)
 {
     if (len == 0) return 0;
     const PickleHeader h = unpickle_header(src, len);
@@ -104,7 +104,7 @@ __device__ __forceinline__ int unpickle_block(const uint8_t *src, int len, uint8
     int decoded = 0;                                        /* LZ4Codec.Decode: empty -> 0 */
     if (data_len > 0) {
         decoded = decode_block<false, ROLE>(src + h.data_offset, data_len, dst, cap, lane, lds, nullptr, false,
-                                            DecodeDict{nullptr, 0u, 0}, pipe);
+                                            DecodeDict{nullptr, 0u, 0}, pipe, nullptr, pace);
         if (decoded <= 0) decoded = -1;
     }
     return decoded == h.result_len ? decoded : -1;
@@ -151,9 +151,10 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
     uint8_t *dst = a.dst + a.dstOff[b];
     const int cap = a.dstCap[b];
     if (role == 0) {
-        unpickle_block<1>(src, len, dst, cap, lane, ring, pipe);
+        if (K4_DEC_PACE) Pace::begin(a.pace, pipe + 2, lane);
+        unpickle_block<1>(src, len, dst, cap, lane, ring, pipe, a.pace);
     } else {
-        const int r = unpickle_block<2>(src, len, dst, cap, lane, ring, pipe);
+        const int r = unpickle_block<2>(src, len, dst, cap, lane, ring, pipe, a.pace);
         if (lane == 0) a.outLen[b] = r;
     }
 }
