@@ -293,7 +293,13 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
             }
         }
         if (optimal) hipLaunchKernelGGL(k4::k4_hc_parse_opt_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
-        else hipLaunchKernelGGL(k4::k4_hc_parse_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
+        else {
+            if (ctx->use_pace && ctx->d_pace && cnt > 8 * (int64_t)ctx->cu_count) {
+                h.pace = ctx->d_pace;
+                K4_HIP(ctx, hipMemsetAsync(h.pace, 0, k4::PACE_BYTES, stream));
+            }
+            hipLaunchKernelGGL(k4::k4_hc_parse_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
+        }
         if (pickle) hipLaunchKernelGGL(k4::k4_pickle_finish_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a, d_enclen);
         K4_HIP(ctx, hipGetLastError());
     }

@@ -810,7 +810,8 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 }
             }
             prepare();                                      /* also when the block ends here: every lane is invalid then and reads offset 0 */
-            if (K4_PACE && ((ip ^ ip0) >> PACE_STEP_LOG2) != 0u && outcome != 2) Pace::update(pace_words, pace_mine, ip, U, lane);
+            if (K4_PACE && ((ip ^ ip0) >> PACE_STEP_LOG2) != 0u && outcome != 2)      /* (a segment's run: its own stretch of the block) */
+                Pace::update(pace_words, pace_mine, ip - sr_begin, (sr_stop_at != SEG_NONE && sr_stop_at < U ? sr_stop_at : U) - sr_begin, lane);
 
             /* the k sequences of this round join the pending ones */
             const bool mine = ((hits >> lane) & 1ull) != 0ull;

@@ -45,6 +45,9 @@
 
 namespace k4 {
 
+#ifndef K4_HC_PACE
+#define K4_HC_PACE 1
+#endif
 constexpr int HC_HASH_LOG = 15;
 constexpr uint32_t HC_NONE = 0xffffffffu;
 constexpr int HC_OPTIMAL_ML = (ML_MASK - 1) + MINMATCH;   /* LL.types.cs:74 */
@@ -67,6 +70,7 @@ struct HcArgs {
     unsigned long long workCap;    /* bytes behind `work` when the launch was sized without asking the device (0 = sized from [n]) */
     unsigned int maxLen;           /* the longest block the launch was sized for (same case) */
     uint32_t *status;              /* the context's status word (k4lz4_common.hpp), or nullptr */
+    uint32_t *pace;                /* the parse kernel's late-blocks-first slots (k4lz4_common.hpp, Pace), zeroed; or nullptr */
 };
 
 /* a launch sized from a reservation (k4lz4_ctx_reserve_hc) whose batch turned out bigger: nothing is touched, every block
@@ -922,7 +926,8 @@ __device__ __forceinline__ int hc_nb_searches(int level)
 /* LZ4HC_compress_hashChain (LL64.high.cs:512-800) for one block; returns bytes written, 0 = overflow */
 template <bool L3>
 __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap, int level,
-                                              const uint32_t *cand, const uint2 *flen, const uint2 *blen, int lane)
+                                              const uint32_t *cand, const uint2 *flen, const uint2 *blen, int lane,
+                                              uint32_t *pace = nullptr, uint32_t *pace_mine = nullptr)
 {
 #define K4_HC_SEARCH(P, LOW, LONGEST, MPOS, SPOS) \
     (L3 ? hc_search_l3(src, cand, hc_get_rec(win, cand, flen, blen, (P)), (P), (LOW), matchlimit, (LONGEST), (MPOS), (SPOS), lane) \
@@ -950,6 +955,7 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
              * records are in the second set already and move up, and the set after it is asked for -- unconditionally, at a
              * clamped address (records of positions past the last searchable one are never looked at), so that the load is
              * not waited for where it is issued.  After a long match the window starts afresh at the cursor. */
+            if (K4_HC_PACE && pace && ((ip ^ win.base) >> 11) != 0u && ip >= 2048u) Pace::update<13>(pace, pace_mine, ip, U, lane);   /* late blocks first */
             if (win.valid && ip - win.base - 64u < 64u) {
                 win.rc = win.rc2; win.f = win.f2; win.b = win.b2;
                 win.base += 64u;
@@ -1092,7 +1098,9 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
 
 __global__ __launch_bounds__(64) void k4_hc_parse_kernel(HcArgs a)
 {
+    __shared__ uint32_t pace_mine[4];
     const int lane = lane_id();
+    if (K4_HC_PACE) Pace::begin(a.pace, pace_mine, lane);
     const long long b = (long long)blockIdx.x;
     const int src_len = a.srcLen[b];
     const int cap = a.dstCap[b];
@@ -1105,7 +1113,7 @@ __global__ __launch_bounds__(64) void k4_hc_parse_kernel(HcArgs a)
         const uint2 *blen = flen + al;
         const uint8_t *s = a.src + a.srcOff[b];
         uint8_t *d = a.dst + a.dstOff[b];
-        if (hc_nb_searches(a.level) <= 4) ret = hc_parse_block<true>(s, src_len, d, cap < 0 ? 0 : cap, a.level, cand, flen, blen, lane);
+        if (hc_nb_searches(a.level) <= 4) ret = hc_parse_block<true>(s, src_len, d, cap < 0 ? 0 : cap, a.level, cand, flen, blen, lane, a.pace, pace_mine);
         else ret = hc_parse_block<false>(s, src_len, d, cap < 0 ? 0 : cap, a.level, cand, flen, blen, lane);
     }
     if (lane == 0) {

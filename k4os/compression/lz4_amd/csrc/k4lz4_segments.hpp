@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_wav
     SegRun r = seg_run_of(g, it, s);
     const uint32_t end = s.next_start != SEG_NONE ? s.next_start : (uint32_t)U;
     const int ret = compress_fast_block<false, false, false>(a.src + a.srcOff[b], U, a.dst + a.dstOff[b] + s.start, (int)(end - s.start), a.accel, stages[wave], lane,
-                                                             g.tables + 4096ull * (unsigned long long)w, (a.flags & FLAG_X32) != 0, nullptr, &r);
+                                                             g.tables + 4096ull * (unsigned long long)w, (a.flags & FLAG_X32) != 0, a.pace, &r);
     if (lane == 0) {
         g.items[it].cut = r.cut; g.items[it].stop = r.stop; g.items[it].state = ret > 0 ? r.state : 3u; g.items[it].bytes = ret;
     }
