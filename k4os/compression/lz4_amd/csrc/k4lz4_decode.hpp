@@ -877,7 +877,10 @@ __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_decode_kernel(Bat
 
 /* ... and with at most half as many blocks as the chip has wave slots, two waves per block: wave 2p parses block p of
  * the workgroup, wave 2p+1 copies (see the queue above).  8 waves per SIMD need <= 64 VGPRs. */
-constexpr int DECODE_PAIRS_PER_WG = 2;     /* measured: 4 pairs per workgroup 233 GiB/s on the bench batch, 2 pairs 242, 1 pair 223 */
+#ifndef K4_DEC_PAIRS
+#define K4_DEC_PAIRS 2
+#endif
+constexpr int DECODE_PAIRS_PER_WG = K4_DEC_PAIRS;     /* measured: 4 pairs per workgroup 233 GiB/s on the bench batch, 2 pairs 242, 1 pair 223; with the late-blocks-first priorities 260 / 290 / 265 */
 __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k4_decode_pair_kernel(BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];

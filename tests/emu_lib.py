@@ -18,8 +18,18 @@ _u8p = C.POINTER(C.c_uint8)
 def build_emu() -> str:
     srcs = glob.glob(os.path.join(EMU_DIR, "*.cpp")) + glob.glob(os.path.join(EMU_DIR, "hip", "*.h")) + \
         glob.glob(os.path.join(ROOT, "k4os", "compression", "lz4_amd", "csrc", "*.hpp"))
-    if not os.path.exists(EMU_SO) or any(os.path.getmtime(s) > os.path.getmtime(EMU_SO) for s in srcs):
-        subprocess.check_call(["make", "-C", EMU_DIR, "-s", "-B"])
+    def stale():
+        return not os.path.exists(EMU_SO) or any(os.path.getmtime(s) > os.path.getmtime(EMU_SO) for s in srcs)
+    if stale():
+        # several processes may want it at once (the two ranks of test_distributed_cpu): one builds, under a lock, into a file of
+        # its own that takes the library's name only when it is complete
+        import fcntl
+        with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if stale():
+                tmp = f"libk4lz4_emu.so.{os.getpid()}.tmp"
+                subprocess.check_call(["make", "-C", EMU_DIR, "-s", "-B", f"OUT={tmp}"])
+                os.replace(os.path.join(EMU_DIR, tmp), EMU_SO)
     return EMU_SO
 
 
