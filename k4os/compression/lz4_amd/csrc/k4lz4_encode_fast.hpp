@@ -24,18 +24,6 @@
 
 namespace k4 {
 
-#ifndef K4_N2
-#define K4_N2 1
-#endif
-#ifndef K4_GTAB_N2
-#define K4_GTAB_N2 0
-#endif
-#ifndef K4_GTAB_PAIRS
-#define K4_GTAB_PAIRS 0
-#endif
-#ifndef K4_GTAB_WPE
-#define K4_GTAB_WPE 6
-#endif
 #ifndef K4_GTAB_DUTY
 #define K4_GTAB_DUTY 3
 #endif
@@ -595,7 +583,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
              * of the chain otherwise).  The probe's come out of the lane four positions on, the candidate's are one more
              * dword of the same trip; lanes without such a neighbour, and strided rounds, stay at 12 known bytes. */
             const uint32_t fwd_max = matchlimit - (pos + MINMATCH);
-            const bool has2 = K4_N2 && N2 && !MORE && contig && lane < 60 && valid && fwd_max > 8u && fwd_max < 0x80000000u;
+            const bool has2 = N2 && !MORE && contig && lane < 60 && valid && fwd_max > 8u && fwd_max < 0x80000000u;
             const uint32_t cn2 = ld32u(src + (has2 ? cand + 12u : 0u));      /* cand + 16 <= pos + 15 < U where fwd_max > 8 */
             uint4 cx = make_uint4(0u, 0u, 0u, 0u);
             if (MORE) {                                     /* (cand < pos, so cand + 28 <= U where pos + 28 <= U) */
@@ -1091,7 +1079,10 @@ __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) void k4_encode_fast_more_
 /* the same encoder with its hash table in global memory (a.gtab: 16 KiB per workgroup slot) and
  * only the output stage in LDS: twice as many blocks resident per CU, each a little slower */
 /* waves_per_eu(6): at most 80 VGPRs.  Two LDS-table waves and four of these fit one SIMD's register file only
- * below that line; one register more costs 20 % of the batch rate (measured). */
+ * below that line; one register more costs 20 % of the batch rate (measured; round 3 once more:
+ * waves_per_eu(5) -27 %).  That line is also why this kernel runs without the pair chain (its scalar registers: mr blocks
+ * 9 % faster with it, osdb / samba 5 % slower, the call slower) and without the twelve known bytes (N2: one vector
+ * register too many). */
 template <bool SEG>
 __device__ __forceinline__ void encode_fast_gtab_kernel_body(const BatchArgs &a, uint32_t (*stages)[ENCODE_STAGE_DWORDS])
 {
@@ -1112,24 +1103,24 @@ __device__ __forceinline__ void encode_fast_gtab_kernel_body(const BatchArgs &a,
         SegFirst f = seg_first_of(a, b);
         const int c = cap < 0 ? 0 : (f.cut && (uint32_t)cap > f.cap ? (int)f.cap : cap);
         if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
-            ret = compress_fast_block<K4_GTAB_PAIRS != 0, false, K4_GTAB_N2 != 0>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], c, a.accel, stage, lane,
+            ret = compress_fast_block<false, false, false>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], c, a.accel, stage, lane,
                                              a.gtab + 4096ull * (unsigned long long)slot, (a.flags & FLAG_X32) != 0, a.pace, f.cut ? &f.run : nullptr);
         seg_first_done(a, b, f, ret, lane);
     } else
     if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
-        ret = compress_fast_block<K4_GTAB_PAIRS != 0, false, K4_GTAB_N2 != 0>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.accel, stage, lane,
+        ret = compress_fast_block<false, false, false>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.accel, stage, lane,
                                          a.gtab + 4096ull * (unsigned long long)slot, (a.flags & FLAG_X32) != 0, a.pace);
     if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
     if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 9, lane);
 }
-__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(K4_GTAB_WPE, K4_GTAB_WPE))) void k4_encode_fast_gtab_kernel(BatchArgs a)
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void k4_encode_fast_gtab_kernel(BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t stages[ENCODE_WAVES_PER_WG][ENCODE_STAGE_DWORDS];
     encode_fast_gtab_kernel_body<false>(a, stages);
 }
 /* the two kernels once more for launches in which big blocks are cut into segments (k4lz4_segments.hpp): a cut block's first
  * segment comes their way like any block, with the rule where to stop; kernels of their own so that the others carry none of it */
-__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(K4_GTAB_WPE, K4_GTAB_WPE))) void k4_encode_fast_gtab_seg_kernel(BatchArgs a)
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void k4_encode_fast_gtab_seg_kernel(BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t stages[ENCODE_WAVES_PER_WG][ENCODE_STAGE_DWORDS];
     encode_fast_gtab_kernel_body<true>(a, stages);
