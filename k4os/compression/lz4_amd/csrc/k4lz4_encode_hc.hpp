@@ -235,6 +235,11 @@ __global__ __launch_bounds__(256) void k4_hc_cand_kernel(HcArgs a)
             const uint32_t matchlimit = U - LASTLITERALS;
             const uint32_t maxn = p + MINMATCH < matchlimit ? matchlimit - (p + MINMATCH) : 0u;
             const uint32_t seq = ld32u(src + p);
+            /* the position's own eight bytes behind its first four and before it: read once, not once per candidate -- an
+             * eight-byte read at an address of its own per lane is what this kernel's time is made of (experiments/hc_cand_lds) */
+            const uint32_t lim0 = maxn < HC_FLEN_CAP - MINMATCH ? maxn : HC_FLEN_CAP - MINMATCH;
+            const uint64_t pf0 = lim0 >= 8u ? ld64u(src + p + MINMATCH) : 0ull;
+            const uint64_t pb0 = p >= 8u ? ld64u(src + p - 8u) : 0ull;
             uint32_t fl[4], bl[4];
             bool chain_ok = true;
 #pragma unroll
@@ -242,11 +247,11 @@ __global__ __launch_bounds__(256) void k4_hc_cand_kernel(HcArgs a)
                 const uint32_t c = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
                 chain_ok = chain_ok && c != HC_NONE && c >= lowest;
                 uint32_t f = 0;
+                const uint32_t lim = lim0;
                 if (chain_ok && ld32u(src + c) == seq) {
                     uint32_t i = 0;
-                    const uint32_t lim = maxn < HC_FLEN_CAP - MINMATCH ? maxn : HC_FLEN_CAP - MINMATCH;
                     while (i + 8u <= lim) {
-                        const uint64_t x = ld64u(src + p + MINMATCH + i) ^ ld64u(src + c + MINMATCH + i);
+                        const uint64_t x = (i == 0u ? pf0 : ld64u(src + p + MINMATCH + i)) ^ ld64u(src + c + MINMATCH + i);
                         if (x) { i += (uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3; break; }
                         i += 8u;
                     }
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(256) void k4_hc_cand_kernel(HcArgs a)
                 if (f) {
                     const uint32_t blim = c < HC_BLEN_CAP ? c : HC_BLEN_CAP;       /* c < p */
                     while (bk + 8u <= blim) {
-                        const uint64_t x = ld64u(src + p - 8u - bk) ^ ld64u(src + c - 8u - bk);
+                        const uint64_t x = (bk == 0u ? pb0 : ld64u(src + p - 8u - bk)) ^ ld64u(src + c - 8u - bk);
                         if (x) { bk += (uint32_t)__clzll((unsigned long long)x) >> 3; break; }
                         bk += 8u;
                     }
