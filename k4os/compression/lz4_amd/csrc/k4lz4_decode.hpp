@@ -52,7 +52,8 @@ namespace k4 {
 /* late blocks first for the decoder pairs (k4lz4_common.hpp, Pace): a report every 2^STEP compressed bytes, epochs of 2^EPOCH
  * ticks of 10 ns, priority tiers 1/DEN apart.  Measured on the bench batch: 245 GiB/s without, 265 / 281 / 290 / 287 with steps of
  * 4 / 2 / 1 / 0.5 KiB (epochs to match), 281 / 290 / 287 / 277 with tiers of 1/16 / 1/32 / 1/64 / 1/128; with the parsing wave
- * alone taking the priority (the first attempt) 241. */
+ * alone taking the priority (the first attempt) 241; with the copying wave one level below its block's 263, with the parsing wave
+ * one level above it 278: the two belong at the same level. */
 #ifndef K4_DEC_PACE
 #define K4_DEC_PACE 1
 #endif
