@@ -338,8 +338,18 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
                  const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level, int flags,
                  hipStream_t stream, const DictArgs *dd, const int32_t *hostLen)
 {
-    const int64_t chunk_max = 1 << 24;   /* blocks per launch (grid.x * blockDim.x must stay < 2^32) */
+    int64_t chunk_max = 1 << 24;   /* blocks per launch (grid.x * blockDim.x must stay < 2^32) */
     const bool encode_like = kind == KIND_ENCODE || kind == KIND_PICKLE;
+    /* Fast-level LZ4Codec.Encode batches beyond what is resident at once (16 blocks per CU: 8 LDS-table + 8 global-table waves)
+     * go in equal parts of at most that: a block takes its ~3.5 ms whatever the batch, so the rate is highest when every launch
+     * is one full residency -- 8192 x 64 KiB in one launch 55 GiB/s (the LDS-table kernel runs two passes, the other one is long
+     * done), as two launches of 4096 the bench batch's 63.  Not for batches that may be ragged (pickles, K4LZ4_FLAG_SEGMENTS):
+     * those need their one cost-ordered launch. */
+    if (kind == KIND_ENCODE && level < K4LZ4_L03_HC && !(flags & (FLAG_SEGMENTS_OK | K4LZ4_FLAG_SEGMENTS | K4LZ4_FLAG_NO_SPLIT)) &&
+        ctx->split_pct <= 0 && !ctx->prof && n > 16 * (int64_t)ctx->cu_count) {
+        const int64_t parts = (n + 16 * (int64_t)ctx->cu_count - 1) / (16 * (int64_t)ctx->cu_count);
+        chunk_max = (n + parts - 1) / parts;
+    }
     if (encode_like && level >= K4LZ4_L03_HC) {
         const int rc = launch_hc(ctx, kind == KIND_PICKLE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, stream, hostLen);
         if (rc != K4LZ4_OK || kind != KIND_ENCODE || !(flags & K4LZ4_FLAG_ALLOW_COPY)) return rc;
