@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from k4os.compression.lz4_amd import LZ4Codec, LZ4Level, corpus, make_arena
-from k4os.compression.lz4_amd._native import FLAG_RAW_RETURN, FLAG_SEGMENTS
+from k4os.compression.lz4_amd._native import FLAG_RAW_RETURN, FLAG_SEGMENTS, FLAG_X32
 from k4os.compression.lz4_amd.sharding import byte_balanced_ranges
 
 pytestmark = pytest.mark.gpu
@@ -117,12 +117,28 @@ def test_big_messages_in_segments_every_envelope_vs_oracle(oracle, monkeypatch):
         ch, coff, cl = comp.data.cpu().numpy(), comp.off.cpu().numpy(), clen.cpu().numpy()
         for i, m in enumerate(msgs):
             assert ch[coff[i]:coff[i] + cl[i]].tobytes() == oracle.encode(m), f"block {i} ({m.size} B) with {env_vars}"
+        # ... the same with the 32-bit engine's hash (K4LZ4_FLAG_X32): a subset is enough, the cut does not look at the hash
+        sub = [0, 2, 12]
+        slens = lens[sub]
+        soff = np.concatenate([[0], np.cumsum(slens[:-1].astype(np.int64))]).astype(np.uint64)
+        ssrc = DeviceBatch.from_host(np.concatenate([msgs[i] for i in sub]), soff, slens, dc.device)
+        scomp = DeviceBatch.empty_slots([LZ4Codec.MaximumOutputSize(int(n)) for n in slens], dc.device, fill=0xCD)
+        sclen = dc.encode(ssrc, scomp, flags=FLAG_SEGMENTS | FLAG_X32 | FLAG_RAW_RETURN)
+        torch.cuda.synchronize()
+        sh, so, sl = scomp.data.cpu().numpy(), scomp.off.cpu().numpy(), sclen.cpu().numpy()
+        for j, i in enumerate(sub):
+            r, w = oracle.compress_fast_x32(msgs[i])
+            assert int(sl[j]) == r and sh[so[j]:so[j] + r].tobytes() == w[:r].tobytes(), f"block {i} with the x32 hash and {env_vars}"
         one = DeviceBatch.from_host(msgs[0], np.zeros(1, np.uint64), lens[:1], dc.device)
         env1 = DeviceBatch.empty_slots(lens[:1].astype(np.int64) + 5, dc.device, fill=0xCD)
         p1 = dc.pickle(one, env1)
         torch.cuda.synchronize()
         o1 = int(env1.off.cpu().numpy()[0])
         assert env1.data.cpu().numpy()[o1:o1 + int(p1.cpu().numpy()[0])].tobytes() == want[0]
+    # ... and through the host-pointer API (LZ4Pickler.Pickle on host memory: staged up, pickled in segments, copied back)
+    from k4os.compression.lz4_amd import LZ4Pickler
+    for i in (0, 12, 9):
+        assert bytes(LZ4Pickler.Pickle(msgs[i])) == want[i], f"host-pointer pickle of message {i}"
 
 
 def test_config4_hc_l03_all_4096_blocks_vs_oracle(oracle):
