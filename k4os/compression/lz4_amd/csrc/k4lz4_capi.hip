@@ -96,6 +96,7 @@ struct k4lz4_ctx {
     uint32_t *d_status = nullptr;   /* this context's status word: DEV_STATUS_* bits raised by its kernels (k4lz4_common.hpp) */
     int split_pct = -1;
     bool no_pair = false;
+    int hc_mem_pct = 33;                  /* K4LZ4_HC_MEM_PCT: share of an HC chunk whose chains are built with the table in memory, beside the LDS-table kernel */
     int pace_min_per_cu = 6;              /* K4LZ4_PACE_MIN: batches of more blocks per CU than this use the priorities (measured: 8 per CU +3 % encode, +7 % decode; 4 per CU -1 %, -4 %) */
     bool use_pace = true;                 /* K4LZ4_NO_PACE: without the late-blocks-first priorities */
     bool prof_gtab = false;               /* K4LZ4_PROF_GTAB: the instrumented encoder keeps its table in global memory */
@@ -278,8 +279,22 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
         }
         h.work = ctx->d_hc_work;
         if (tail[1] <= 65536) {
-            /* no block over 64 KiB (known from the host lengths, the reservation or the device): hash tables in LDS */
-            hipLaunchKernelGGL(k4::k4_hc_chain_lds_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
+            /* no block over 64 KiB (known from the host lengths, the reservation or the device): hash tables in LDS -- two blocks
+             * per CU, a wave each, which leaves the CU's other wave slots empty; so the last third of a big chunk goes through the
+             * table-in-memory kernel on the second queue at the same time (its tables: 128 KiB per block, cleared here) */
+            const int64_t n_mem = cnt >= 8 * (int64_t)ctx->cu_count ? cnt * ctx->hc_mem_pct / 100 : 0;
+            const int64_t n_lds = cnt - n_mem;
+            if (n_mem > 0) {
+                K4_HIP(ctx, hipEventRecord(ctx->ev_fork, stream));
+                K4_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+                K4_HIP(ctx, hipMemsetAsync(ctx->d_hc_hash + ((size_t)n_lds << (k4::HC_HASH_LOG + 2)), 0, (size_t)n_mem << (k4::HC_HASH_LOG + 2), ctx->aux));
+                k4::HcArgs hm = h;
+                hm.blockBase = (unsigned)n_lds;
+                hipLaunchKernelGGL(k4::k4_hc_chain_kernel, dim3((unsigned)n_mem), dim3(64), 0, ctx->aux, hm);
+                K4_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+            }
+            hipLaunchKernelGGL(k4::k4_hc_chain_lds_kernel, dim3((unsigned)n_lds), dim3(64), 0, stream, h);
+            if (n_mem > 0) K4_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_join, 0));
         } else {
             K4_HIP(ctx, hipMemsetAsync(ctx->d_hc_hash, 0, (size_t)cnt << (k4::HC_HASH_LOG + 2), stream));
             hipLaunchKernelGGL(k4::k4_hc_chain_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
@@ -1159,6 +1174,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     ctx->prof_gtab = getenv("K4LZ4_PROF_GTAB") != nullptr;
     ctx->use_pace = getenv("K4LZ4_NO_PACE") == nullptr;
     if (const char *e = getenv("K4LZ4_PACE_MIN")) ctx->pace_min_per_cu = std::max(0, atoi(e));
+    if (const char *e = getenv("K4LZ4_HC_MEM_PCT")) ctx->hc_mem_pct = std::max(0, std::min(100, atoi(e)));
     ctx->use_segments = getenv("K4LZ4_NO_SEGMENTS") == nullptr;
     if (const char *e = getenv("K4LZ4_SEG_MIN")) ctx->seg_min = (uint32_t)std::max(65536 + 4096, atoi(e));
     if (const char *e = getenv("K4LZ4_SEG_TARGET")) ctx->seg_target = (uint32_t)std::max(8192, atoi(e));

@@ -305,6 +305,7 @@ __device__ __forceinline__ void hop_chain_pairs(unsigned long long &hmx, unsigne
  * round-based encoder needs for it.
  */
 constexpr uint32_t SEG_NONE = 0xffffffffu;
+constexpr uint32_t SEG_ITEM_WORDS = 10u;          /* a segment's record (k4lz4_segments.hpp, SegItem) as the words the encoder kernels read and write */
 constexpr int SEG_SNAP_DWORDS = 4096 + 16;          /* [0] cut + 1 (0: not there yet, SEG_NONE: this run never found one), [16..] the table */
 constexpr uint32_t SEG_SPIN_MAX = 1u << 20;          /* polls (with s_sleep 8 between them: some tenths of a second) before a run stops waiting for the next one's cut */
 struct SegRun {
@@ -1018,7 +1019,7 @@ __device__ __forceinline__ SegFirst seg_first_of(const BatchArgs &a, long long b
     if (!a.seg_first) return f;
     const int32_t it = (int32_t)uni((uint32_t)a.seg_first[b]);
     if (it < 0) return f;
-    const uint32_t *w = (const uint32_t *)a.seg_items + 10u * (uint32_t)it;     /* block, k, nseg, start, next_start, warm_from, cut, stop, state, bytes */
+    const uint32_t *w = (const uint32_t *)a.seg_items + SEG_ITEM_WORDS * (uint32_t)it;     /* block, k, nseg, start, next_start, warm_from, cut, stop, state, bytes */
     f.cut = true;
     f.run.stop_at = uni(w[4]);
     f.cap = f.run.stop_at;                                          /* its piece may not reach into the next segment's */
@@ -1028,7 +1029,7 @@ __device__ __forceinline__ SegFirst seg_first_of(const BatchArgs &a, long long b
 __device__ __forceinline__ void seg_first_done(const BatchArgs &a, long long b, const SegFirst &f, int ret, int lane)
 {
     if (!f.cut || lane != 0) return;
-    uint32_t *w = (uint32_t *)a.seg_items + 10u * (uint32_t)a.seg_first[b];
+    uint32_t *w = (uint32_t *)a.seg_items + SEG_ITEM_WORDS * (uint32_t)a.seg_first[b];
     w[6] = f.run.cut; w[7] = f.run.stop; w[8] = ret > 0 ? f.run.state : 3u; w[9] = (uint32_t)ret;
 }
 

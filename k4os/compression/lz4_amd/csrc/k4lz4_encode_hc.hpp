@@ -71,6 +71,7 @@ struct HcArgs {
     unsigned int maxLen;           /* the longest block the launch was sized for (same case) */
     uint32_t *status;              /* the context's status word (k4lz4_common.hpp), or nullptr */
     uint32_t *pace;                /* the parse kernel's late-blocks-first slots (k4lz4_common.hpp, Pace), zeroed; or nullptr */
+    unsigned int blockBase;        /* chain kernels: workgroup 0 is block blockBase (the two of them share a launch chunk) */
 };
 
 /* a launch sized from a reservation (k4lz4_ctx_reserve_hc) whose batch turned out bigger: nothing is touched, every block
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(64) void k4_hc_chain_kernel(HcArgs a)
 {
     __shared__ uint32_t seen[(1u << HC_HASH_LOG) / 32u];
     const int lane = lane_id();
-    const long long b = (long long)blockIdx.x;
+    const long long b = (long long)blockIdx.x + (long long)a.blockBase;
     const int len = a.srcLen[b];
     if (len < MFLIMIT + 1 || !hc_scratch_ok(a)) return;    /* no search happens (LL64.high.cs:549) */
     for (uint32_t k = (uint32_t)lane; k < (1u << HC_HASH_LOG) / 32u; k += 64u) seen[k] = 0u;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(64) void k4_hc_chain_lds_kernel(HcArgs a)
     __shared__ uint32_t seen[(1u << HC_HASH_LOG) / 32u];
     __shared__ uint16_t tab[1u << HC_HASH_LOG];
     const int lane = lane_id();
-    const long long b = (long long)blockIdx.x;
+    const long long b = (long long)blockIdx.x + (long long)a.blockBase;
     const int len = a.srcLen[b];
     if (len < MFLIMIT + 1 || len > 65536 || !hc_scratch_ok(a)) return;
     for (uint32_t k = (uint32_t)lane; k < (1u << HC_HASH_LOG) / 32u; k += 64u) seen[k] = 0u;

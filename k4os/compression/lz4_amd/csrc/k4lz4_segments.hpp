@@ -35,6 +35,8 @@ struct SegItem {
     int32_t bytes;                           /* what it wrote at slot + start (at the slot's beginning for segment 0) */
 };
 
+static_assert(sizeof(SegItem) == 4u * SEG_ITEM_WORDS, "seg_first_of / seg_first_done address SegItem's fields as words 4 (next_start) and 6..9 (results)");
+
 struct SegHdr {
     uint32_t n_items, n_work, n_blocks, pad;
 };
