@@ -26,6 +26,8 @@ namespace K4os.Compression.LZ4.Engine
 		[DllImport(Lib)] public static extern int k4lz4_ctx_device(IntPtr ctx);
 		[DllImport(Lib)] public static extern int k4lz4_synchronize(IntPtr ctx, IntPtr stream);
 		[DllImport(Lib)] public static extern int k4lz4_ctx_reserve_hc(IntPtr ctx, long totalSrcBytes, int longestBlock);
+		[DllImport(Lib)] public static extern int k4lz4_host_register(IntPtr ptr, UIntPtr bytes);
+		[DllImport(Lib)] public static extern int k4lz4_host_unregister(IntPtr ptr);
 		[DllImport(Lib)] public static extern void k4lz4_set_enforce32(int on);
 		[DllImport(Lib)] public static extern int k4lz4_get_enforce32();
 		[DllImport(Lib)] public static extern int k4lz4_compress_bound(int n);

@@ -38,6 +38,7 @@
 #ifndef K4LZ4_H
 #define K4LZ4_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -100,6 +101,15 @@ K4LZ4_API int k4lz4_synchronize(k4lz4_ctx *ctx, void *stream);
  * at most longestBlock bytes each only enqueue, like every other *_device call; a batch that exceeds the reservation is
  * not encoded (outLen = failure, K4LZ4_E_NOMEM at the next synchronising call).  (0, 0) removes the reservation. */
 K4LZ4_API int k4lz4_ctx_reserve_hc(k4lz4_ctx *ctx, int64_t totalSrcBytes, int32_t longestBlock);
+/* Page-locks [ptr, ptr + bytes) of the caller's memory (hipHostRegister) and remembers the range: host-pointer batch calls
+ * whose source span, or whose destination slots, lie inside a registered range move those bytes straight between the
+ * caller's pages and the GPU instead of through the context's pinned staging buffers (no counterpart in the reference; a
+ * .NET caller registers a pinned array / NativeMemory block it reuses across calls).  Results are the same byte for byte:
+ * exactly outLen[i] bytes are written to slot i either way.  Registering costs about as much as the copy it saves, so it
+ * pays for buffers that are used more than once.  The range must stay registered until every call that uses it has
+ * returned; unregister with the same ptr.  Process-wide, any thread. */
+K4LZ4_API int k4lz4_host_register(void *ptr, size_t bytes);
+K4LZ4_API int k4lz4_host_unregister(void *ptr);
 /* Diagnostic, no counterpart in the reference: the three serial chains of the kernels exist as hand-written scalar ISA and
  * as C (the form the CPU wave emulator of the test suite runs).  Runs both forms on the device over `waves` x `rounds`
  * pseudo-random well-formed inputs; mismatches[0..2] = rounds in which they disagreed (token chain of the decoder, hop

@@ -7,9 +7,9 @@ from .pickler import LZ4Pickler, InvalidDataException
 from .encoders import (LZ4BlockEncoder, LZ4BlockDecoder, EncoderAction, InvalidOperationException, TopupAndEncode,
                        FlushAndEncode, DecodeAndDrain)
 from .frames import LZ4Frame, LZ4EncoderSettings, LZ4Descriptor, parse_frame, xxh32_many
-from ._native import NativeLibraryError, Context, load_library, default_context
+from ._native import NativeLibraryError, Context, load_library, default_context, host_register, host_unregister
 
 __all__ = ["LZ4Codec", "LZ4Level", "LZ4Pickler", "InvalidDataException", "NativeLibraryError", "Context",
-           "load_library", "default_context", "pack_blocks", "make_arena", "LZ4BlockEncoder", "LZ4BlockDecoder",
+           "load_library", "default_context", "host_register", "host_unregister", "pack_blocks", "make_arena", "LZ4BlockEncoder", "LZ4BlockDecoder",
            "EncoderAction", "InvalidOperationException", "TopupAndEncode", "FlushAndEncode", "DecodeAndDrain", "LZ4Frame",
            "LZ4EncoderSettings", "LZ4Descriptor", "parse_frame", "xxh32_many"]

@@ -35,6 +35,8 @@ SYMBOLS = {
     "k4lz4_ctx_device": (C.c_int, [C.c_void_p]),
     "k4lz4_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "k4lz4_ctx_reserve_hc": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
+    "k4lz4_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "k4lz4_host_unregister": (C.c_int, [C.c_void_p]),
     "k4lz4_selftest_chains": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_uint32)]),
     "k4lz4_set_enforce32": (None, [C.c_int]),
     "k4lz4_get_enforce32": (C.c_int, []),
@@ -189,6 +191,29 @@ def default_context() -> Context:
         ctx = Context(dev)
         _tls.ctx = ctx
     return ctx
+
+
+def _check_plain(lib, rc: int):
+    if rc == K4LZ4_OK:
+        return
+    msg = (lib.k4lz4_last_error(None) or b"").decode()
+    if rc == E_ARG:
+        raise ValueError(msg)
+    if rc == E_NOMEM:
+        raise MemoryError(msg)
+    raise NativeLibraryError(f"libk4lz4 error {rc}: {msg}")
+
+
+def host_register(arr) -> None:
+    """k4lz4_host_register: page-lock a (C-contiguous) numpy buffer that is reused across host-pointer batch calls, so that
+    its bytes move between the caller's pages and the GPU without the stop in a staging buffer."""
+    lib = load_library()
+    _check_plain(lib, lib.k4lz4_host_register(C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes)))
+
+
+def host_unregister(arr) -> None:
+    lib = load_library()
+    _check_plain(lib, lib.k4lz4_host_unregister(C.c_void_p(arr.ctypes.data)))
 
 
 def check_last_status(lib):

@@ -96,6 +96,8 @@ struct k4lz4_ctx {
     uint32_t *d_status = nullptr;   /* this context's status word: DEV_STATUS_* bits raised by its kernels (k4lz4_common.hpp) */
     int split_pct = -1;
     bool no_pair = false;
+    int direct_span_pct = 200;            /* K4LZ4_DIRECT_SPAN_PCT: a registered source goes up as it lies while its span is at most this share of its blocks' bytes */
+    bool no_direct = false;               /* K4LZ4_NO_DIRECT: registered host memory is staged like any other */
     int hc_mem_pct = 33;                  /* K4LZ4_HC_MEM_PCT: share of an HC chunk whose chains are built with the table in memory, beside the LDS-table kernel */
     int pace_min_per_cu = 6;              /* K4LZ4_PACE_MIN: batches of more blocks per CU than this use the priorities (measured: 8 per CU +3 % encode, +7 % decode; 4 per CU -1 %, -4 %) */
     bool use_pace = true;                 /* K4LZ4_NO_PACE: without the late-blocks-first priorities */
@@ -778,6 +780,49 @@ int staged_download(k4lz4_ctx *ctx, uint8_t *dst, const uint64_t *dstOff, const 
     return K4LZ4_OK;
 }
 
+/* Host memory the caller has page-locked through k4lz4_host_register: the DMA engine reads and writes it directly, so a
+ * host-pointer call whose source or destination lies inside such a range skips the pinned staging buffers on that side. */
+std::mutex g_reg_mu;
+std::vector<std::pair<uintptr_t, size_t>> g_reg;   /* [start, bytes), guarded by g_reg_mu */
+
+bool registered(const void *p, size_t bytes)
+{
+    if (!p || !bytes) return false;
+    const uintptr_t a = (uintptr_t)p;
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    for (const auto &r : g_reg)
+        if (a >= r.first && a - r.first <= r.second && bytes <= r.second - (a - r.first)) return true;
+    return false;
+}
+
+constexpr size_t DIRECT_RUNS_MAX = 64;
+
+/* device -> registered caller memory without the stop in a pinned buffer: blocks whose stored bytes follow one another both on
+ * the device and in the caller's memory travel as one copy (a decoded batch in adjacent slots: one copy per part).  More than
+ * DIRECT_RUNS_MAX such runs (compressed blocks in worst-case slots: every block its own) are cheaper through the buffers:
+ * returns false and has enqueued nothing.  Exactly stored[i] bytes land in slot i, as on the staged way. */
+bool direct_download(k4lz4_ctx *ctx, uint8_t *dst, const uint64_t *dstOff, const uint8_t *d_from, const uint64_t *from_off,
+                     const int32_t *stored, int64_t n, hipStream_t st, int *rc)
+{
+    struct Run { uint64_t host, dev, len; };
+    std::vector<Run> runs;
+    for (int64_t i = 0; i < n; i++) {
+        if (stored[i] <= 0) continue;
+        if (!runs.empty() && runs.back().host + runs.back().len == dstOff[i] && runs.back().dev + runs.back().len == from_off[i])
+            runs.back().len += (uint64_t)stored[i];
+        else {
+            if (runs.size() == DIRECT_RUNS_MAX) return false;
+            runs.push_back(Run{dstOff[i], from_off[i], (uint64_t)stored[i]});
+        }
+    }
+    *rc = K4LZ4_OK;
+    for (const Run &r : runs) {
+        const hipError_t e = hipMemcpyAsync(dst + r.host, d_from + r.dev, (size_t)r.len, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) { *rc = hip_fail(ctx, e, "hipMemcpyAsync"); break; }
+    }
+    return true;
+}
+
 int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen,
                    uint8_t *dst, const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level,
                    int flags, const DictArgs *hd);
@@ -848,7 +893,9 @@ int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t
     if (lo == UINT64_MAX) { lo = 0; hi = 0; }
     const size_t span = (size_t)(hi - lo);
     /* blocks that fill less than 7/8 of their span (and each fit a staging chunk) travel packed */
-    const bool packed = span >= 2 * STAGE_CHUNK && packed_bytes + (packed_bytes >> 3) < span && longest <= STAGE_CHUNK;
+    /* a registered source goes up as it lies (its span, straight from the caller's pages) unless that is over twice the bytes */
+    const bool src_reg = span > 0 && !ctx->no_direct && registered(src + lo, span) && (uint64_t)span * 100u <= (uint64_t)ctx->direct_span_pct * packed_bytes;
+    const bool packed = !src_reg && span >= 2 * STAGE_CHUNK && packed_bytes + (packed_bytes >> 3) < span && longest <= STAGE_CHUNK;
     {
         uint64_t at = 0;
         for (int64_t i = 0; i < n; i++) {
@@ -874,7 +921,7 @@ int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t
         int k = 1;
         for (int64_t i = 0; i < n && k < want; i++) {
             acc += srcLen[i] > 0 ? (((uint64_t)srcLen[i] + 15u) & ~(uint64_t)15u) : 0u;
-            if (acc >= up_bytes * (uint64_t)k / (uint64_t)want) cuts[k++] = i + 1;
+            if (acc >= packed_bytes * (uint64_t)k / (uint64_t)want) cuts[k++] = i + 1;   /* (the blocks' own bytes: a span has its gaps) */
         }
         bool ok = k == want;
         cuts[want] = n;
@@ -943,6 +990,13 @@ int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t
      * pinned buffers, own helper threads) while this thread stages and launches the later parts: PCIe carries both ways at
      * once, and so do the host's copies.  `launched` says how many parts have had their kernels and their ev_len enqueued. ---- */
     const bool raw_negative = (flags & K4LZ4_FLAG_ALLOW_COPY) && kind == KIND_ENCODE;
+    bool dst_reg = false;                   /* the caller's slots lie in registered memory: whole runs of them come back in one copy each */
+    if (!ctx->no_direct) {
+        uint64_t dlo = UINT64_MAX, dhi = 0;
+        for (int64_t i = 0; i < n; i++)
+            if (h_cap[(size_t)i] > 0) { dlo = std::min(dlo, dstOff[i]); dhi = std::max(dhi, dstOff[i] + (uint64_t)h_cap[(size_t)i]); }
+        dst_reg = dlo != UINT64_MAX && registered(dst + dlo, (size_t)(dhi - dlo));
+    }
     std::vector<uint64_t> h_poff((size_t)n);
     std::vector<int32_t> stored((size_t)n);
     if (nparts > 1 && (rc = grow(ctx, &ctx->d_pack, &ctx->d_pack_cap, (size_t)dtotal + 64, false)) != K4LZ4_OK) return rc;
@@ -980,6 +1034,10 @@ int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t
             from_off = h_poff.data() + b0;
         }
         pack_base += used;
+        if (dst_reg) {
+            int rc3 = K4LZ4_OK;
+            if (direct_download(ctx, dst, dstOff + b0, d_from, from_off, stored.data() + b0, cnt, dq, &rc3)) return rc3;
+        }
         return staged_download(ctx, dst, dstOff + b0, d_from, from_off, stored.data() + b0, cnt, dq, nparts > 1 ? pool_dl_of(ctx) : pool_of(ctx));
     };
     int dl_rc = K4LZ4_OK;
@@ -1027,7 +1085,12 @@ int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t
             for (int64_t i = b0; i < b1; i++)
                 if (srcLen[i] > 0) { a = std::min(a, h_soff[(size_t)i]); e = std::max(e, h_soff[(size_t)i] + (uint64_t)srcLen[i]); }
             if (nparts == 1) { a = 0; e = span; }
-            if (a != UINT64_MAX && e > a && (rc = staged_upload(ctx, ctx->d_src + a, src + lo + a, (size_t)(e - a), cq)) != K4LZ4_OK) return finish(rc);
+            if (a != UINT64_MAX && e > a) {
+                if (src_reg) {
+                    const hipError_t ue = hipMemcpyAsync(ctx->d_src + a, src + lo + a, (size_t)(e - a), hipMemcpyHostToDevice, cq);
+                    if (ue != hipSuccess) return finish(hip_fail(ctx, ue, "hipMemcpyAsync"));
+                } else if ((rc = staged_upload(ctx, ctx->d_src + a, src + lo + a, (size_t)(e - a), cq)) != K4LZ4_OK) return finish(rc);
+            }
         }
         hipError_t he = hipSuccess;
         if (cq != st) {
@@ -1174,6 +1237,8 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     ctx->prof_gtab = getenv("K4LZ4_PROF_GTAB") != nullptr;
     ctx->use_pace = getenv("K4LZ4_NO_PACE") == nullptr;
     if (const char *e = getenv("K4LZ4_PACE_MIN")) ctx->pace_min_per_cu = std::max(0, atoi(e));
+    if (const char *e = getenv("K4LZ4_DIRECT_SPAN_PCT")) ctx->direct_span_pct = std::max(100, atoi(e));
+    if (const char *e = getenv("K4LZ4_NO_DIRECT")) ctx->no_direct = atoi(e) != 0;
     if (const char *e = getenv("K4LZ4_HC_MEM_PCT")) ctx->hc_mem_pct = std::max(0, std::min(100, atoi(e)));
     ctx->use_segments = getenv("K4LZ4_NO_SEGMENTS") == nullptr;
     if (const char *e = getenv("K4LZ4_SEG_MIN")) ctx->seg_min = (uint32_t)std::max(65536 + 4096, atoi(e));
@@ -1243,6 +1308,39 @@ int k4lz4_synchronize(k4lz4_ctx *ctx, void *stream)
     K4_HIP(ctx, hipSetDevice(ctx->device));
     K4_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
     return take_device_status(ctx);
+}
+
+int k4lz4_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) { tl_error = "k4lz4_host_register: empty range"; return K4LZ4_E_ARG; }
+    {
+        const uintptr_t a = (uintptr_t)ptr;
+        std::lock_guard<std::mutex> g(g_reg_mu);
+        for (const auto &r : g_reg)
+            if (a < r.first + r.second && r.first < a + bytes) { tl_error = "k4lz4_host_register: overlaps a registered range"; return K4LZ4_E_ARG; }
+    }
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        tl_error = std::string("hipHostRegister: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? K4LZ4_E_NOMEM : K4LZ4_E_HIP;
+    }
+    std::lock_guard<std::mutex> g(g_reg_mu);
+    g_reg.emplace_back((uintptr_t)ptr, bytes);
+    return K4LZ4_OK;
+}
+
+int k4lz4_host_unregister(void *ptr)
+{
+    {
+        std::lock_guard<std::mutex> g(g_reg_mu);
+        auto it = std::find_if(g_reg.begin(), g_reg.end(), [&](const std::pair<uintptr_t, size_t> &r) { return r.first == (uintptr_t)ptr; });
+        if (it == g_reg.end()) { tl_error = "k4lz4_host_unregister: not a registered range"; return K4LZ4_E_ARG; }
+        g_reg.erase(it);
+    }
+    const hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); tl_error = std::string("hipHostUnregister: ") + hipGetErrorString(e); return K4LZ4_E_HIP; }
+    return K4LZ4_OK;
 }
 
 int k4lz4_ctx_reserve_hc(k4lz4_ctx *ctx, int64_t totalSrcBytes, int32_t longestBlock)

@@ -360,6 +360,58 @@ def test_host_pointer_staging_branches_big_ragged_shuffled(oracle):
     assert np.array_equal(got2, got[perm])
 
 
+def test_registered_host_buffers_give_the_same_bytes_as_pageable_ones():
+    """k4lz4_host_register: with the caller's buffers page-locked the source goes up straight from its pages and a decoded batch in
+    adjacent slots comes back in one copy per part (direct_download); compressed blocks in worst-case slots (every block a
+    run of its own), ragged lengths, a corrupt stream and a destination that is too small keep to the staged way or mix both.
+    Every byte of every destination arena -- slack of the slots included -- must equal what the same calls write without
+    registration; registering twice / unregistering something unknown are refused."""
+    from k4os.compression.lz4_amd import host_register, host_unregister
+    n, bs = 2048, 65536
+    blocks = corpus.silesia_like_blocks(n, bs, seed=21)
+    src = np.ascontiguousarray(blocks.reshape(-1))
+    off = np.arange(n, dtype=np.uint64) * bs
+    lens = np.full(n, bs, np.int32)
+    lens[5::97] -= 13                                   # ragged: these blocks end short of the next one's start
+    caps = np.full(n, LZ4Codec.MaximumOutputSize(bs), np.int32)
+    plain_c, coff = make_arena(caps, fill=0xCD)
+    plain_len = LZ4Codec.EncodeBatchPacked(src, off, lens, plain_c, coff, caps)
+    dcap = lens.copy()
+    i_bad, i_small = 77, 1500
+    dcap[i_small] -= 9
+    plain_c[int(coff[i_bad]) + 9] ^= 0x5A
+    plain_c[int(coff[i_bad]) + 300:int(coff[i_bad]) + 308] = 0
+    plain_b, boff = make_arena(dcap, fill=0xCD)
+    plain_got = LZ4Codec.DecodeBatchPacked(plain_c, coff, plain_len, plain_b, boff, dcap)
+    assert plain_got[i_small] == -1 and (np.delete(plain_got, [i_bad, i_small]) == np.delete(lens, [i_bad, i_small])).all()
+
+    reg_c, _ = make_arena(caps, fill=0xCD)
+    reg_b, _ = make_arena(dcap, fill=0xCD)
+    held = []
+    try:
+        for arr in (src, reg_c, reg_b):
+            host_register(arr); held.append(arr)
+        reg_len = LZ4Codec.EncodeBatchPacked(src, off, lens, reg_c, coff, caps)
+        assert np.array_equal(reg_len, plain_len)
+        reg_c[int(coff[i_bad]) + 9] ^= 0x5A
+        reg_c[int(coff[i_bad]) + 300:int(coff[i_bad]) + 308] = 0
+        assert np.array_equal(reg_c, plain_c)
+        reg_got = LZ4Codec.DecodeBatchPacked(reg_c, coff, reg_len, reg_b, boff, dcap)
+        assert np.array_equal(reg_got, plain_got)
+        assert np.array_equal(reg_b, plain_b)
+        # a batch that lies only partly inside a registered range is staged as a whole
+        part = np.concatenate([src[:bs * 8], src[:bs * 8]])
+        got8 = LZ4Codec.EncodeBatchPacked(part, off[:16], lens[:16] * 0 + bs, reg_c, coff[:16], caps[:16])
+        assert (got8[:8] == got8[8:]).all() and (got8 > 0).all()
+        with pytest.raises(ValueError):
+            host_register(src[100:200])                 # overlaps a registered range
+    finally:
+        for arr in held:
+            host_unregister(arr)
+    with pytest.raises(ValueError):
+        host_unregister(src)                            # no longer registered
+
+
 def test_two_ranks_on_one_gpu_run_the_real_multi_rank_backend():
     """`bench.py --strong --gpus 2` as two processes (torch.distributed.run) that share GPU 0 (K4LZ4_RANK_DEVICE=0): a context
     and a DevicePickleBackend per rank, byte-balanced ranges, the size vector gathered (over gloo: RCCL refuses two ranks
