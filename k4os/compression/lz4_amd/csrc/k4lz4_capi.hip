@@ -98,6 +98,7 @@ struct k4lz4_ctx {
     bool no_pair = false;
     int direct_span_pct = 200;            /* K4LZ4_DIRECT_SPAN_PCT: a registered source goes up as it lies while its span is at most this share of its blocks' bytes */
     bool no_direct = false;               /* K4LZ4_NO_DIRECT: registered host memory is staged like any other */
+    int hop2_max_per_cu = 12;             /* K4LZ4_HOP2_MAX: pair decoders follow the token chain two links per hop in launches of up to this many blocks per CU */
     int hc_mem_pct = 33;                  /* K4LZ4_HC_MEM_PCT: share of an HC chunk whose chains are built with the table in memory, beside the LDS-table kernel */
     int pace_min_per_cu = 6;              /* K4LZ4_PACE_MIN: batches of more blocks per CU than this use the priorities (measured: 8 per CU +3 % encode, +7 % decode; 4 per CU -1 %, -4 %) */
     bool use_pace = true;                 /* K4LZ4_NO_PACE: without the late-blocks-first priorities */
@@ -431,6 +432,8 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
         a.dst = dst; a.dstOff = dstOff + first; a.dstCap = dstCap + first;
         a.outLen = outLen + first; a.n = cnt; a.level = level; a.accel = ctx->accel;
         a.flags = flags | (g_enforce32.load(std::memory_order_relaxed) ? K4LZ4_FLAG_X32 : 0);
+        /* pair decoders: the token chain two links at a time while the launch leaves wave slots free (k4lz4_decode.hpp, follow_tokens) */
+        const bool hop2 = cnt <= (int64_t)ctx->hop2_max_per_cu * (int64_t)ctx->cu_count;
         a.prof = ctx->prof ? ctx->prof + k4::PROF_STRIDE * first : nullptr;
         a.status = ctx->d_status;
         if ((kind == KIND_ENCODE || (K4_DEC_PACE && (kind == KIND_DECODE || kind == KIND_UNPICKLE))) && ctx->use_pace && ctx->d_pace && cnt > (int64_t)ctx->pace_min_per_cu * (int64_t)ctx->cu_count) {   /* k4lz4_common.hpp, Pace: more than two blocks per SIMD */
@@ -581,7 +584,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             else if (cnt <= 16 * (int64_t)ctx->cu_count && !ctx->no_pair) {
                 /* at most half the chip's wave slots (8 per SIMD at 64 VGPRs) are needed: two waves per block, one
                  * parsing ahead of the one that copies */
-                hipLaunchKernelGGL(k4::k4_decode_pair_kernel, dim3((unsigned)((cnt + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
+                hipLaunchKernelGGL(hop2 ? k4::k4_decode_pair2_kernel : k4::k4_decode_pair_kernel, dim3((unsigned)((cnt + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
                                    dim3(128 * k4::DECODE_PAIRS_PER_WG), 0, stream, a);
             }
             else hipLaunchKernelGGL(k4::k4_decode_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
@@ -591,7 +594,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             break;
         case KIND_UNPICKLE:
             if (cnt <= 64 * (int64_t)ctx->cu_count && !ctx->no_pair) {
-                hipLaunchKernelGGL(k4::k4_unpickle_pair_kernel, dim3((unsigned)((cnt + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
+                hipLaunchKernelGGL(hop2 ? k4::k4_unpickle_pair2_kernel : k4::k4_unpickle_pair_kernel, dim3((unsigned)((cnt + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
                                    dim3(128 * k4::DECODE_PAIRS_PER_WG), 0, stream, a);
             }
             else hipLaunchKernelGGL(k4::k4_unpickle_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
@@ -1239,6 +1242,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (const char *e = getenv("K4LZ4_PACE_MIN")) ctx->pace_min_per_cu = std::max(0, atoi(e));
     if (const char *e = getenv("K4LZ4_DIRECT_SPAN_PCT")) ctx->direct_span_pct = std::max(100, atoi(e));
     if (const char *e = getenv("K4LZ4_NO_DIRECT")) ctx->no_direct = atoi(e) != 0;
+    if (const char *e = getenv("K4LZ4_HOP2_MAX")) ctx->hop2_max_per_cu = std::max(0, atoi(e));
     if (const char *e = getenv("K4LZ4_HC_MEM_PCT")) ctx->hc_mem_pct = std::max(0, std::min(100, atoi(e)));
     ctx->use_segments = getenv("K4LZ4_NO_SEGMENTS") == nullptr;
     if (const char *e = getenv("K4LZ4_SEG_MIN")) ctx->seg_min = (uint32_t)std::max(65536 + 4096, atoi(e));

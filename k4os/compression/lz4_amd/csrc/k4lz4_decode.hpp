@@ -95,10 +95,59 @@ __device__ __forceinline__ void follow_tokens_ref(uint32_t word, unsigned long l
         idx = pk >> 9;
     }
 }
-__device__ __forceinline__ void follow_tokens(uint32_t word, unsigned long long &T, uint32_t &idx)
+__device__ __forceinline__ void follow_tokens1(uint32_t word, unsigned long long &T, uint32_t &idx);
+__device__ __forceinline__ void follow_tokens(uint32_t word, unsigned long long &T, uint32_t &idx, bool two = true)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t pk = 0;                                        /* a word's low six bits are the next lane: it selects the lane itself */
+    if (!two) { follow_tokens1(word, T, idx); return; }
+    /* Two sequences per hop: every lane first learns where its successor points (one ds_bpermute), and the chain follows those
+     * double links -- the word a hop reads carries the lane after next in its low six bits (the next v_readlane's lane select, as
+     * before) and the lane in between in bits 24-29, which a shift hands to a second s_bitset1.  Lanes where the chain ends point
+     * at themselves, so both links of such a lane are the lane itself and hopping on stays harmless; the word read last is the
+     * end lane's own either way.  The three scalar instructions between two v_readlane are three of the four wait states the
+     * lane select needs.  scripts/ubench/hop_chain.hip, 24 sequences at 1 / 4 / 8 waves per SIMD: 1016 / 1045 / 1375 cycles
+     * one link at a time, 592 / 711 / 1054 this way, the bpermute included.  In the pair decoder (A/B on one box, bench batch cut
+     * to 512 / 1024 / 2048 / 3072 / 4096 blocks): +10 / +9.7 / +7 / +1.6 / -3 % -- with every wave slot of the chip taken, the LDS
+     * round trip costs more than the shorter chain saves -- so the host side launches the kernels built with it (k4_decode_pair2_kernel, k4_unpickle_pair2_kernel) up to 12 blocks per CU,
+     * and follow_tokens1 below is the form for a full chip. */
+    const uint32_t n1 = word & 63u;
+    const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(n1 << 2), (int)word);
+    const uint32_t word2 = (word & ~63u) | (w1 & 63u) | (n1 << 24);
+    uint32_t pk = 0, mid = 0;
+    T = 0;
+#define K4_HOP "s_bitset1_b64 %[T], %[pk]\n\ts_lshr_b32 %[mid], %[pk], 24\n\ts_bitset1_b64 %[T], %[mid]\n\ts_nop 0\n\tv_readlane_b32 %[pk], %[word], %[pk]\n\t"
+#define K4_HOP4 K4_HOP K4_HOP K4_HOP K4_HOP
+    asm volatile(
+        K4_HOP4
+        "s_bitcmp1_b32 %[pk], 7\n\t"
+        "s_cbranch_scc1 .Ltok_end%=\n\t"
+        K4_HOP4
+        "s_bitcmp1_b32 %[pk], 7\n\t"
+        "s_cbranch_scc1 .Ltok_end%=\n\t"
+        K4_HOP4
+        ".Ltok_end%=:"
+        : [T] "+s"(T), [pk] "+s"(pk), [mid] "+s"(mid)
+        : [word] "v"(word2)
+        : "scc");
+#undef K4_HOP4
+#undef K4_HOP
+    const uint32_t last = 63u - (uint32_t)__builtin_clzll(T);
+    if (pk & 0x100u) {
+        idx = (pk >> 9) & 0x7fffu;                          /* (bits 24-29: the link in between) */
+    } else {
+        T &= ~(1ull << last);
+        idx = last;
+    }
+#else
+    (void)two;
+    follow_tokens_ref(word, T, idx);
+#endif
+}
+/* one link per hop: s_bitset1 and v_readlane both take the lane from the low six bits of the word just read */
+__device__ __forceinline__ void follow_tokens1(uint32_t word, unsigned long long &T, uint32_t &idx)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t pk = 0;
     T = 0;
 #define K4_HOP "s_bitset1_b64 %[T], %[pk]\n\ts_nop 2\n\tv_readlane_b32 %[pk], %[word], %[pk]\n\t"
 #define K4_HOP8 K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP K4_HOP
@@ -318,7 +367,7 @@ __device__ __forceinline__ bool pipe_wait(const uint32_t *pipe, int which, uint3
  */
 /* ROLE 0: one wave does everything.  ROLE 1: PARSE only, batches go into the pair's queue (`pipe`).  ROLE 2: takes
  * batches from the queue and does LITERALS / MATCHES; returns the block's result. */
-template <bool PROF = false, int ROLE = 0>
+template <bool PROF = false, int ROLE = 0, bool HOP2 = false>
 __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uint8_t *out, int out_size, int lane,
                                             uint32_t *lds, unsigned long long *pc = nullptr, bool partial = false,
                                             DecodeDict dict = DecodeDict{nullptr, 0u, 0}, uint32_t *pipe = nullptr,
@@ -439,7 +488,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 unsigned long long T = 0;
                 uint32_t idx = 0;
                 const unsigned long long tp1 = prof_now<PROF>();
-                follow_tokens(packed, T, idx);
+                follow_tokens(packed, T, idx, HOP2);
                 const unsigned long long tp2 = prof_now<PROF>();
                 /* output position of every chosen sequence: prefix sum of the chosen lengths */
                 bool in_t = ((T >> lane) & 1ull) != 0;
@@ -882,9 +931,10 @@ __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_decode_kernel(Bat
 #define K4_DEC_PAIRS 2
 #endif
 constexpr int DECODE_PAIRS_PER_WG = K4_DEC_PAIRS;     /* measured: 4 pairs per workgroup 233 GiB/s on the bench batch, 2 pairs 242, 1 pair 223; with the late-blocks-first priorities 260 / 290 / 265 */
-__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k4_decode_pair_kernel(BatchArgs a)
+/* HOP2: the parsing wave follows the token chain two links at a time (follow_tokens) -- the kernel for launches that leave wave slots free */
+template <bool HOP2>
+__device__ __forceinline__ void decode_pair_kernel_body(const BatchArgs &a, uint32_t (*lds)[DECODE_PAIR_LDS_DWORDS])
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
     const int lane = lane_id();
     const uint32_t wave = uni(threadIdx.x >> 6);
     /* odd workgroups swap the roles, so that a SIMD hosts parsing and copying waves alike */
@@ -905,13 +955,23 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
     if (role == 0) {
         if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 8, lane);
         if (K4_DEC_PACE) Pace::begin(a.pace, pipe + 2, lane);
-        if (run) decode_block<false, 1>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, nullptr, partial, dict, pipe, nullptr, a.pace);
+        if (run) decode_block<false, 1, HOP2>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, nullptr, partial, dict, pipe, nullptr, a.pace);
     } else {
         int ret = 0;
         if (run) ret = decode_block<false, 2>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, nullptr, partial, dict, pipe, nullptr, a.pace);
         if (lane == 0) a.outLen[b] = codec_decode_result(src_len, ret, a.flags);
         if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 9, lane);
     }
+}
+__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k4_decode_pair_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
+    decode_pair_kernel_body<false>(a, lds);
+}
+__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k4_decode_pair2_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
+    decode_pair_kernel_body<true>(a, lds);
 }
 
 /* diagnostic twin of the pair kernel: 32 counters per block, the parsing wave's in [0, 16), the copying wave's in [16, 32) */

@@ -88,7 +88,7 @@ __device__ __forceinline__ PickleHeader unpickle_header(const uint8_t *src, int 
 
 /* Unpickle(source, output): returns the unpickled size (== cap), 0 for an empty pickle,
  * -1 where the reference throws (unpickle.cs:115-128,:134,:143-144) */
-template <int ROLE = 0>
+template <int ROLE = 0, bool HOP2 = false>
 __device__ __forceinline__ int unpickle_block(const uint8_t *src, int len, uint8_t *dst, int cap, int lane, uint32_t *lds,
                                               uint32_t *pipe = nullptr, uint32_t *pace = nullptr)
 {
@@ -103,8 +103,8 @@ __device__ __forceinline__ int unpickle_block(const uint8_t *src, int len, uint8
     }
     int decoded = 0;                                        /* LZ4Codec.Decode: empty -> 0 */
     if (data_len > 0) {
-        decoded = decode_block<false, ROLE>(src + h.data_offset, data_len, dst, cap, lane, lds, nullptr, false,
-                                            DecodeDict{nullptr, 0u, 0}, pipe, nullptr, pace);
+        decoded = decode_block<false, ROLE, HOP2>(src + h.data_offset, data_len, dst, cap, lane, lds, nullptr, false,
+                                                  DecodeDict{nullptr, 0u, 0}, pipe, nullptr, pace);
         if (decoded <= 0) decoded = -1;
     }
     return decoded == h.result_len ? decoded : -1;
@@ -134,9 +134,9 @@ __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_unpickle_kernel(B
 
 /* Pickles are ragged (1 KiB .. 4 MiB in BASELINE configs[3]) and, started longest first, the call lasts as long as
  * its biggest message: the two waves per message of k4_decode_pair_kernel shorten exactly that. */
-__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_waves_per_eu(4, 8))) void k4_unpickle_pair_kernel(BatchArgs a)
+template <bool HOP2>
+__device__ __forceinline__ void unpickle_pair_kernel_body(const BatchArgs &a, uint32_t (*lds)[DECODE_PAIR_LDS_DWORDS])
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
     const int lane = lane_id();
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t pair = wave >> 1, role = (wave ^ blockIdx.x) & 1u;   /* as in k4_decode_pair_kernel */
@@ -152,11 +152,22 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
     const int cap = a.dstCap[b];
     if (role == 0) {
         if (K4_DEC_PACE) Pace::begin(a.pace, pipe + 2, lane);
-        unpickle_block<1>(src, len, dst, cap, lane, ring, pipe, a.pace);
+        unpickle_block<1, HOP2>(src, len, dst, cap, lane, ring, pipe, a.pace);
     } else {
         const int r = unpickle_block<2>(src, len, dst, cap, lane, ring, pipe, a.pace);
         if (lane == 0) a.outLen[b] = r;
     }
+}
+__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_waves_per_eu(4, 8))) void k4_unpickle_pair_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
+    unpickle_pair_kernel_body<false>(a, lds);
+}
+/* the token chain two links per hop (k4lz4_decode.hpp, follow_tokens): launches that leave wave slots free */
+__global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_waves_per_eu(4, 8))) void k4_unpickle_pair2_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[DECODE_PAIRS_PER_WG][DECODE_PAIR_LDS_DWORDS];
+    unpickle_pair_kernel_body<true>(a, lds);
 }
 
 /* HC levels: the block encoder runs as its own kernels between these two.

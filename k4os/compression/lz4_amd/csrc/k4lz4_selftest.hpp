@@ -46,9 +46,12 @@ __global__ __launch_bounds__(64) void k4_chain_selftest_kernel(uint32_t seed, in
             const uint32_t word = token_word(fast, next, lane);
             unsigned long long Ta, Tb;
             uint32_t ia, ib;
-            follow_tokens(word, Ta, ia);
+            unsigned long long Tc;
+            uint32_t ic;
+            follow_tokens(word, Ta, ia, true);                  /* two links per hop */
+            follow_tokens1(word, Tc, ic);                       /* one */
             follow_tokens_ref(word, Tb, ib);
-            if (Ta != Tb || ia != ib) bad_tok++;
+            if (Ta != Tb || ia != ib || Tc != Tb || ic != ib) bad_tok++;
         }
         const uint32_t ru = uni(st_rand(su));
         const uint32_t nvalid = 64u - (ru % 3u == 0u ? (ru >> 4) % 20u : 0u);          /* lanes past the last probe position */
