@@ -36,6 +36,8 @@
 #include "k4lz4_xxh32.hpp"
 #include "k4lz4_selftest.hpp"
 
+constexpr int MAX_PARTS = 8;      /* a big host-pointer call is staged, run and brought back in up to this many parts */
+
 struct k4lz4_ctx {
     int device = -1;
     std::string error;
@@ -85,7 +87,7 @@ struct k4lz4_ctx {
      * run, the first half's results come down while the second half's kernels run; results' sizes via a pinned array */
     hipStream_t copyq = nullptr;
     hipStream_t dlq = nullptr;          /* ... and the way back has a queue (and a thread, and helper threads) of its own: up and down at once */
-    hipEvent_t ev_up[4] = {nullptr, nullptr, nullptr, nullptr}, ev_len[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_up[MAX_PARTS] = {}, ev_len[MAX_PARTS] = {};
     uint8_t *h_len = nullptr; size_t h_len_cap = 0;
     struct Pool *pool = nullptr, *pool_dl = nullptr;   /* helper threads of the upload side, of the download side */
     bool pool_failed = false, pool_dl_failed = false;
@@ -98,6 +100,7 @@ struct k4lz4_ctx {
     bool no_pair = false;
     int direct_span_pct = 200;            /* K4LZ4_DIRECT_SPAN_PCT: a registered source goes up as it lies while its span is at most this share of its blocks' bytes */
     bool no_direct = false;               /* K4LZ4_NO_DIRECT: registered host memory is staged like any other */
+    int dec_parts = 4, dec_parts_direct = 8;   /* K4LZ4_DEC_PARTS, K4LZ4_DEC_PARTS_DIRECT: parts of a big decode-like host-pointer call (2..MAX_PARTS); with a registered destination */
     int hop2_max_per_cu = 12;             /* K4LZ4_HOP2_MAX: pair decoders follow the token chain two links per hop in launches of up to this many blocks per CU */
     int hc_mem_pct = 33;                  /* K4LZ4_HC_MEM_PCT: share of an HC chunk whose chains are built with the table in memory, beside the LDS-table kernel */
     int pace_min_per_cu = 6;              /* K4LZ4_PACE_MIN: batches of more blocks per CU than this use the priorities (measured: 8 per CU +3 % encode, +7 % decode; 4 per CU -1 %, -4 %) */
@@ -914,12 +917,23 @@ int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t
     /* Encoders: two parts (a part's kernels last as long as their slowest block whatever their number, and the parts' kernels
      * run one after the other).  Decoders, whose kernels are short: four, so that more of the way up and of the way down
      * overlap. */
+    bool dst_reg = false;                   /* the caller's slots lie in registered memory: whole runs of them come back in one copy each */
+    if (!ctx->no_direct) {
+        uint64_t dlo = UINT64_MAX, dhi = 0;
+        for (int64_t i = 0; i < n; i++)
+            if (h_cap[(size_t)i] > 0) { dlo = std::min(dlo, dstOff[i]); dhi = std::max(dhi, dstOff[i] + (uint64_t)h_cap[(size_t)i]); }
+        dst_reg = dlo != UINT64_MAX && registered(dst + dlo, (size_t)(dhi - dlo));
+    }
     int nparts = 1;
-    int64_t part_lo[4] = {0, n, n, n}, part_hi[4] = {n, n, n, n};
+    int64_t part_lo[MAX_PARTS], part_hi[MAX_PARTS];
+    for (int q = 0; q < MAX_PARTS; q++) { part_lo[q] = q ? n : 0; part_hi[q] = n; }
     if (n >= 1024 && up_bytes >= 4 * STAGE_CHUNK && (packed || ascending) && !hc && !(hd && hd->dict)) {
         const bool decode_like = kind == KIND_DECODE || kind == KIND_UNPICKLE;
-        const int want = decode_like && n >= 2048 && up_bytes >= 8 * STAGE_CHUNK ? 4 : 2;
-        int64_t cuts[5] = {0, n, n, n, n};
+        /* (a registered destination: no scatter thread to keep fed, so the shorter the first and the last part the better -- eight
+         * parts 36.9 GiB/s, six 35.9, four 34.4 on the bench batch; through the buffers eight parts are slower than four, 27 against 29) */
+        const int want = decode_like && n >= 2048 && up_bytes >= 8 * STAGE_CHUNK ? (dst_reg && n >= 4096 ? ctx->dec_parts_direct : ctx->dec_parts) : 2;
+        int64_t cuts[MAX_PARTS + 1];
+        for (int q = 0; q <= MAX_PARTS; q++) cuts[q] = q ? n : 0;
         uint64_t acc = 0;
         int k = 1;
         for (int64_t i = 0; i < n && k < want; i++) {
@@ -993,13 +1007,6 @@ int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t
      * pinned buffers, own helper threads) while this thread stages and launches the later parts: PCIe carries both ways at
      * once, and so do the host's copies.  `launched` says how many parts have had their kernels and their ev_len enqueued. ---- */
     const bool raw_negative = (flags & K4LZ4_FLAG_ALLOW_COPY) && kind == KIND_ENCODE;
-    bool dst_reg = false;                   /* the caller's slots lie in registered memory: whole runs of them come back in one copy each */
-    if (!ctx->no_direct) {
-        uint64_t dlo = UINT64_MAX, dhi = 0;
-        for (int64_t i = 0; i < n; i++)
-            if (h_cap[(size_t)i] > 0) { dlo = std::min(dlo, dstOff[i]); dhi = std::max(dhi, dstOff[i] + (uint64_t)h_cap[(size_t)i]); }
-        dst_reg = dlo != UINT64_MAX && registered(dst + dlo, (size_t)(dhi - dlo));
-    }
     std::vector<uint64_t> h_poff((size_t)n);
     std::vector<int32_t> stored((size_t)n);
     if (nparts > 1 && (rc = grow(ctx, &ctx->d_pack, &ctx->d_pack_cap, (size_t)dtotal + 64, false)) != K4LZ4_OK) return rc;
@@ -1230,7 +1237,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
         e = hipEventCreateWithFlags(&ctx->ev_in[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_out[b], hipEventDisableTiming);
     }
-    for (int b = 0; b < 4 && e == hipSuccess; b++) {
+    for (int b = 0; b < MAX_PARTS && e == hipSuccess; b++) {
         e = hipEventCreateWithFlags(&ctx->ev_up[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_len[b], hipEventDisableTiming);
     }
@@ -1242,6 +1249,8 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (const char *e = getenv("K4LZ4_PACE_MIN")) ctx->pace_min_per_cu = std::max(0, atoi(e));
     if (const char *e = getenv("K4LZ4_DIRECT_SPAN_PCT")) ctx->direct_span_pct = std::max(100, atoi(e));
     if (const char *e = getenv("K4LZ4_NO_DIRECT")) ctx->no_direct = atoi(e) != 0;
+    if (const char *e = getenv("K4LZ4_DEC_PARTS")) ctx->dec_parts = std::max(2, std::min(MAX_PARTS, atoi(e)));
+    if (const char *e = getenv("K4LZ4_DEC_PARTS_DIRECT")) ctx->dec_parts_direct = std::max(2, std::min(MAX_PARTS, atoi(e)));
     if (const char *e = getenv("K4LZ4_HOP2_MAX")) ctx->hop2_max_per_cu = std::max(0, atoi(e));
     if (const char *e = getenv("K4LZ4_HC_MEM_PCT")) ctx->hc_mem_pct = std::max(0, std::min(100, atoi(e)));
     ctx->use_segments = getenv("K4LZ4_NO_SEGMENTS") == nullptr;
@@ -1278,7 +1287,7 @@ void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
     }
     if (ctx->d_pack) (void)hipFree(ctx->d_pack);
     if (ctx->h_len) (void)hipHostFree(ctx->h_len);
-    for (int b = 0; b < 4; b++) {
+    for (int b = 0; b < MAX_PARTS; b++) {
         if (ctx->ev_up[b]) (void)hipEventDestroy(ctx->ev_up[b]);
         if (ctx->ev_len[b]) (void)hipEventDestroy(ctx->ev_len[b]);
     }

@@ -367,7 +367,7 @@ def test_registered_host_buffers_give_the_same_bytes_as_pageable_ones():
     Every byte of every destination arena -- slack of the slots included -- must equal what the same calls write without
     registration; registering twice / unregistering something unknown are refused."""
     from k4os.compression.lz4_amd import host_register, host_unregister
-    n, bs = 2048, 65536
+    n, bs = 4096, 65536                                 # (4096 blocks: a registered destination comes back in eight parts)
     blocks = corpus.silesia_like_blocks(n, bs, seed=21)
     src = np.ascontiguousarray(blocks.reshape(-1))
     off = np.arange(n, dtype=np.uint64) * bs
@@ -377,7 +377,7 @@ def test_registered_host_buffers_give_the_same_bytes_as_pageable_ones():
     plain_c, coff = make_arena(caps, fill=0xCD)
     plain_len = LZ4Codec.EncodeBatchPacked(src, off, lens, plain_c, coff, caps)
     dcap = lens.copy()
-    i_bad, i_small = 77, 1500
+    i_bad, i_small = 77, 3500
     dcap[i_small] -= 9
     plain_c[int(coff[i_bad]) + 9] ^= 0x5A
     plain_c[int(coff[i_bad]) + 300:int(coff[i_bad]) + 308] = 0
