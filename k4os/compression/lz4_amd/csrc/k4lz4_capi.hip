@@ -61,8 +61,9 @@ struct k4lz4_ctx {
     uint8_t *d_seg = nullptr; size_t d_seg_cap = 0;           /* segment records, work list, snapshots, tables */
     uint8_t *d_seg_first = nullptr; size_t d_seg_first_cap = 0;   /* per block: its first segment's record or -1 */
     bool use_segments = true;                                 /* K4LZ4_NO_SEGMENTS */
-    uint32_t seg_min = 1536u << 10, seg_target = 768u << 10, seg_warm = 384u << 10;   /* K4LZ4_SEG_MIN / _TARGET / _WARM (bytes) */
-    uint32_t seg_div = 2500;                                  /* K4LZ4_SEG_DIV: blocks shorter than the batch's bytes / this stay whole */
+    uint32_t seg_min = 1024u << 10, seg_target = 640u << 10, seg_warm = 384u << 10;   /* K4LZ4_SEG_MIN / _TARGET / _WARM (bytes) */
+    uint32_t seg_target_max = 1152u << 10;                    /* K4LZ4_SEG_TARGET_MAX; K4LZ4_SEG_TARGET alone fixes the size */
+    uint32_t seg_div = 3500;                                  /* K4LZ4_SEG_DIV: blocks shorter than the batch's bytes / this stay whole */
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint8_t *d_hc_hash = nullptr; size_t d_hc_hash_cap = 0;   /* HC: per-block hash tables of one launch chunk */
     uint8_t *d_hc_work = nullptr; size_t d_hc_work_cap = 0;   /* HC: prev[] / cand[] of one launch chunk */
@@ -100,6 +101,8 @@ struct k4lz4_ctx {
     bool no_pair = false;
     int direct_span_pct = 200;            /* K4LZ4_DIRECT_SPAN_PCT: a registered source goes up as it lies while its span is at most this share of its blocks' bytes */
     bool no_direct = false;               /* K4LZ4_NO_DIRECT: registered host memory is staged like any other */
+    int lds_floor_per_cu = 8;             /* K4LZ4_LDS_FLOOR: blocks per CU the LDS-table kernel gets at least */
+    int cost_pct = 48;                    /* K4LZ4_COST_PCT: the LDS-table kernel's share of a batch's estimated cost (k4_order_kernel) */
     int dec_parts = 4, dec_parts_direct = 8;   /* K4LZ4_DEC_PARTS, K4LZ4_DEC_PARTS_DIRECT: parts of a big decode-like host-pointer call (2..MAX_PARTS); with a registered destination */
     int hop2_max_per_cu = 12;             /* K4LZ4_HOP2_MAX: pair decoders follow the token chain two links per hop in launches of up to this many blocks per CU */
     int hc_mem_pct = 33;                  /* K4LZ4_HC_MEM_PCT: share of an HC chunk whose chains are built with the table in memory, beside the LDS-table kernel */
@@ -461,7 +464,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             sg.hdr = (k4::SegHdr *)ctx->d_seg; sg.items = (k4::SegItem *)(ctx->d_seg + o_items); sg.work = (uint32_t *)(ctx->d_seg + o_work);
             sg.blocks = (uint32_t *)(ctx->d_seg + o_blocks); sg.snaps = (uint32_t *)(ctx->d_seg + o_snaps); sg.tables = (uint32_t *)(ctx->d_seg + o_tables);
             sg.first = (int32_t *)ctx->d_seg_first;
-            sg.seg_min = ctx->seg_min; sg.seg_target = ctx->seg_target; sg.seg_warm = ctx->seg_warm; sg.seg_div = ctx->seg_div;
+            sg.seg_min = ctx->seg_min; sg.seg_target = ctx->seg_target; sg.seg_warm = ctx->seg_warm; sg.seg_div = ctx->seg_div; sg.seg_target_max = ctx->seg_target_max;
             hipLaunchKernelGGL(k4::k4_seg_plan_kernel, dim3(1), dim3(256), 0, stream, a, sg);
             a.seg_first = sg.first; a.seg_items = sg.items; a.seg_snaps = sg.snaps;
             seg = true;
@@ -494,8 +497,8 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             const bool two_kernels = kind == KIND_ENCODE && !a.prof && cnt > 512 && !(flags & K4LZ4_FLAG_NO_SPLIT) &&
                                      cnt > 8 * (int64_t)ctx->cu_count && ctx->split_pct <= 0;
             k4::BatchArgs ao = a;
-            ao.first = two_kernels ? 48u : 0u;
-            ao.total = (uint32_t)(8 * (int64_t)ctx->cu_count);
+            ao.first = two_kernels ? (uint32_t)ctx->cost_pct : 0u;
+            ao.total = (uint32_t)((int64_t)ctx->lds_floor_per_cu * (int64_t)ctx->cu_count);
             hipLaunchKernelGGL(k4::k4_order_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, ao);
             a.order = d_order;
             if (two_kernels) a.split = d_hist + 2 * k4::COST_BUCKETS;
@@ -1249,13 +1252,16 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (const char *e = getenv("K4LZ4_PACE_MIN")) ctx->pace_min_per_cu = std::max(0, atoi(e));
     if (const char *e = getenv("K4LZ4_DIRECT_SPAN_PCT")) ctx->direct_span_pct = std::max(100, atoi(e));
     if (const char *e = getenv("K4LZ4_NO_DIRECT")) ctx->no_direct = atoi(e) != 0;
+    if (const char *e = getenv("K4LZ4_LDS_FLOOR")) ctx->lds_floor_per_cu = std::max(0, std::min(8, atoi(e)));
+    if (const char *e = getenv("K4LZ4_COST_PCT")) ctx->cost_pct = std::max(1, std::min(99, atoi(e)));
     if (const char *e = getenv("K4LZ4_DEC_PARTS")) ctx->dec_parts = std::max(2, std::min(MAX_PARTS, atoi(e)));
     if (const char *e = getenv("K4LZ4_DEC_PARTS_DIRECT")) ctx->dec_parts_direct = std::max(2, std::min(MAX_PARTS, atoi(e)));
     if (const char *e = getenv("K4LZ4_HOP2_MAX")) ctx->hop2_max_per_cu = std::max(0, atoi(e));
     if (const char *e = getenv("K4LZ4_HC_MEM_PCT")) ctx->hc_mem_pct = std::max(0, std::min(100, atoi(e)));
     ctx->use_segments = getenv("K4LZ4_NO_SEGMENTS") == nullptr;
     if (const char *e = getenv("K4LZ4_SEG_MIN")) ctx->seg_min = (uint32_t)std::max(65536 + 4096, atoi(e));
-    if (const char *e = getenv("K4LZ4_SEG_TARGET")) ctx->seg_target = (uint32_t)std::max(8192, atoi(e));
+    if (const char *e = getenv("K4LZ4_SEG_TARGET")) ctx->seg_target = ctx->seg_target_max = (uint32_t)std::max(8192, atoi(e));
+    if (const char *e = getenv("K4LZ4_SEG_TARGET_MAX")) ctx->seg_target_max = (uint32_t)std::max(8192, atoi(e));
     if (const char *e = getenv("K4LZ4_SEG_WARM")) ctx->seg_warm = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("K4LZ4_SEG_DIV")) ctx->seg_div = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("K4LZ4_PICKLE_SPLIT_MIN")) ctx->pickle_split_min = std::max(0, atoi(e));

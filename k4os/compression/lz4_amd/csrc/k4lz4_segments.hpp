@@ -50,6 +50,7 @@ struct SegArgs {
     uint32_t *snaps;             /* SEG_MAX_ITEMS x SEG_SNAP_DWORDS */
     uint32_t *tables;            /* SEG_MAX_ITEMS x 4096: the hash tables of k4_encode_seg_kernel's waves */
     uint32_t seg_min, seg_target, seg_warm;
+    uint32_t seg_target_max;     /* the segment size grows with the batch up to this (0 or <= seg_target: fixed size), see k4_seg_plan_kernel */
     uint32_t seg_div;            /* a block is cut only if it is longer than the batch's bytes / seg_div: a wave encodes ~25 MB/s, the whole chip
                                   * ~2 500 times that, so shorter blocks are over before the batch is and cutting them only adds their warm-ups */
 };
@@ -72,10 +73,20 @@ __global__ __launch_bounds__(256) void k4_seg_plan_kernel(BatchArgs a, SegArgs g
     for (int k = 0; k < 256; k++) all += bytes_of[k];
     const unsigned long long by_share = g.seg_div ? all / (unsigned long long)g.seg_div : 0ull;
     const uint32_t min_len = by_share > (unsigned long long)g.seg_min ? (by_share > 0x7fffffffull ? 0x7fffffffu : (uint32_t)by_share) : g.seg_min;
+    /* The segment size goes by the same budget: what a wave encodes while the chip does the whole batch, less the warm-up a
+     * later segment's wave runs first -- a small batch is as long as its longest serial run, so short segments (seg_target);
+     * a batch that fills the chip is as long as its work, and every segment costs a warm-up's worth of that, so long ones
+     * (up to seg_target_max).  Rank 0's share of configs[3], 6.3 GB: 125 ms with 768 KiB segments, 111 with 1.1 - 1.25 MiB,
+     * 120 with 1.5 MiB; half of it (3.1 GB): 74 / 81 / 93 ms with 768 KiB / 1 MiB / 1.25 MiB. */
+    uint32_t target = g.seg_target;
+    if (g.seg_target_max > g.seg_target && by_share > (unsigned long long)g.seg_warm + (unsigned long long)g.seg_target) {
+        const unsigned long long t = by_share - (unsigned long long)g.seg_warm;
+        target = t < (unsigned long long)g.seg_target_max ? (uint32_t)t : g.seg_target_max;
+    }
     auto segments_of = [&](long long b) -> uint32_t {
         const int U = a.srcLen[b], cap = a.dstCap[b];
         if (U < (int)min_len || U < LIMIT_64K || cap < U - 1) return 0u;
-        const uint32_t nseg = ((uint32_t)U + g.seg_target - 1u) / g.seg_target;
+        const uint32_t nseg = ((uint32_t)U + target - 1u) / target;
         return nseg >= 2u ? nseg : 0u;
     };
     uint32_t ni = 0, nb = 0;
