@@ -101,15 +101,19 @@ __global__ __launch_bounds__(256) void k4_seg_plan_kernel(BatchArgs a, SegArgs g
         int32_t at = -1;
         if (nseg && base + nseg <= (uint32_t)SEG_MAX_ITEMS && bi < (uint32_t)SEG_MAX_BLOCKS) {
             const uint32_t U = (uint32_t)a.srcLen[b];
-            const uint32_t span = ((U + nseg - 1u) / nseg + 63u) & ~63u;
+            /* the first segment is the longer one: its wave has no warm-up to run first, so the runs of a block -- warm-up and
+             * segment -- come out about equally long (the warm-up counted for at most half a segment) */
+            const uint32_t w = g.seg_warm < U / (2u * nseg) ? g.seg_warm : U / (2u * nseg);
+            const uint32_t later = ((U - w + nseg - 1u) / nseg + 63u) & ~63u;
+            const uint32_t first = U - (nseg - 1u) * later;
             const uint32_t w0 = base - bi;                  /* every cut block before this one took one item more than places in the work list */
             at = (int32_t)base;
             g.blocks[bi] = (uint32_t)b;
             for (uint32_t k = 0; k < nseg; k++) {
                 SegItem it;
                 it.block = (uint32_t)b; it.k = k; it.nseg = nseg;
-                it.start = k * span;
-                it.next_start = k + 1u < nseg ? (k + 1u) * span : SEG_NONE;
+                it.start = k ? first + (k - 1u) * later : 0u;
+                it.next_start = k + 1u < nseg ? first + k * later : SEG_NONE;
                 it.warm_from = it.start > g.seg_warm ? it.start - g.seg_warm : 0u;
                 it.cut = 0u; it.stop = 0u; it.state = 3u; it.bytes = 0;
                 g.items[base + k] = it;
