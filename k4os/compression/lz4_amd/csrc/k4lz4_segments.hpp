@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k4_seg_plan_kernel(BatchArgs a, SegArgs g
             /* the first segment is the longer one: its wave has no warm-up to run first, so the runs of a block -- warm-up and
              * segment -- come out about equally long (the warm-up counted for at most half a segment) */
             const uint32_t w = g.seg_warm < U / (2u * nseg) ? g.seg_warm : U / (2u * nseg);
-            const uint32_t later = ((U - w + nseg - 1u) / nseg + 63u) & ~63u;
+            const uint32_t later = ((U - w) / nseg) & ~63u;     /* (rounded down: the first segment takes the remainder, whatever nseg is) */
             const uint32_t first = U - (nseg - 1u) * later;
             const uint32_t w0 = base - bi;                  /* every cut block before this one took one item more than places in the work list */
             at = (int32_t)base;
