@@ -20,20 +20,19 @@
  *   - LZ4Pickler envelope V0 (Pickle / Unpickle)
  *         reference: LZ4Pickler.pickle.cs:51-228, LZ4Pickler.unpickle.cs:39-158
  *
- * Parity pin: the reference is C# and cannot be built in this image (no dotnet/mono);
- * this oracle is pinned instead by tests/test_oracle_pins.py against (a) the in-repo
- * known-answer fixture assets/issue64 (copied as tests/golden/issue64_*.bin), (b) the
- * probe values recorded in SURVEY.md 8c, and (c) byte-equality with the system
- * liblz4.so.1 (v1.9.3; the reference's goldens were produced by native lz4 1.9.2,
- * playground/SharedSources/app.cpp:79-141) on every fixture.  Output bytes are exact;
- * unlike the reference's wildcopy helpers this restatement never stores beyond the
- * returned length (the overshoot is unobservable: SURVEY.md 8a row a10).
- *
- * State of the pin, plainly: DECODE is pinned to a reference-held golden (issue64).  ENCODE (fast and
- * HC) is pinned to liblz4 1.9.3 and the survey's probe values only -- the reference's own encode
- * goldens (ChecksumBlockTests.cs:14-50,125-172: whole Silesia files) need the corpus, which this image
- * does not have (tests/tools/fetch_silesia.md).  Until a run with K4LZ4_CORPUS_DIR happens the
- * encoders are PARITY UNPINNED with respect to the reference itself, and the Enforce32 arm to anything.
+ * Parity pin (round 4): PINNED TO THE REFERENCE ITSELF.  oracle/make_ref.py respells the reference's own
+ * engine files (Engine/x64/LL64.*.cs, Engine/x32/LL32.*.cs, Engine/LL.*.cs, Internal/Mem*.cs) as C++ and g++
+ * compiles them into oracle/_ref/libk4ref.so; tests/test_ref_pins.py compares every entry point of this file
+ * with it byte for byte -- all 4096 bench blocks at L00, 384 at L03, 216 at L09/L10/L12, 200 configs[3]
+ * messages through both engines, 1 500 mutated streams (return value incl. error position), partial and
+ * dictionary arms, the Enforce32 arm against LL32.  Older pins stay in tests/test_oracle_pins.py: the in-repo
+ * known-answer fixture assets/issue64 (tests/golden/issue64_*.bin), the probe values of SURVEY.md 8c, and byte
+ * equality with the system liblz4.so.1 (1.9.3).  The LZ4Codec / LZ4Pickler mappings below follow managed-array
+ * code the translator does not take; they are pinned by reading and by the reference's reproducible tests.
+ * Output bytes are exact; unlike the reference's wildcopy helpers this restatement never stores beyond the
+ * returned length (the overshoot is unobservable: SURVEY.md 8a row a10).  Not run here: the reference's recorded
+ * encode outputs (ChecksumBlockTests.cs:14-50,125-172: whole Silesia files; no corpus in this image,
+ * tests/tools/fetch_silesia.md).
  */
 #include <stdint.h>
 #include <stddef.h>
@@ -258,7 +257,7 @@ K4O_API int k4o_compress_fast(const uint8_t *src, uint8_t *dst, int src_len, int
 
 /* LL32.LZ4_compress_fast as LZ4Codec.Enforce32 = true runs it in a 64-bit process (x32/LL32.fast.cs:517-576): the table
  * type for >= 64 KiB inputs is still byU32 (`sizeof(void*) < 8` is false, :543-545), only the hash differs.
- * PARITY UNPINNED: no 32-bit lz4 build is available here to compare with. */
+ * Pinned to LL32 compiled here (oracle/_ref, k4ref_compress_fast_x32): tests/test_ref_pins.py. */
 K4O_API int k4o_compress_fast_x32(const uint8_t *src, uint8_t *dst, int src_len, int dst_cap, int accel)
 {
     fast_table_t tbl;

@@ -74,7 +74,7 @@ class Oracle:
         return ret, dst[:cap]
 
     def compress_fast_x32(self, src: np.ndarray, cap: int | None = None, accel: int = 1):
-        """LL32.LZ4_compress_fast as LZ4Codec.Enforce32 runs it in a 64-bit process (parity unpinned, see the C source)"""
+        """LL32.LZ4_compress_fast as LZ4Codec.Enforce32 runs it in a 64-bit process (pinned to oracle/_ref's LL32)"""
         src = np.ascontiguousarray(src, dtype=np.uint8)
         if cap is None:
             cap = self.compress_bound(src.size)
@@ -286,3 +286,85 @@ class FrameOracle:
         used = C.c_int64(0)
         n = self.lib.k4o_frame_decode(_ptr(f), f.size, _ptr(dst), cap, C.byref(used))
         return int(n), dst[:max(n, 0)].tobytes(), int(used.value)
+
+
+# ---- oracle/_ref: the reference itself, compiled here (oracle/make_ref.py) --------------------------------------------
+REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+REFERENCE_PRESENT = os.path.isdir("/root/reference/src/K4os.Compression.LZ4")
+
+
+def build_ref() -> str | None:
+    """(re)builds oracle/_ref where /root/reference is present; elsewhere (the GPU box) returns the prebuilt library that
+    travelled with the snapshot, or None when there is none"""
+    so = os.path.join(REF_DIR, "libk4ref.so")
+    if REFERENCE_PRESENT:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "ref"])
+    return so if os.path.exists(so) else None
+
+
+class RefEngine:
+    """LL64 / LL32 of the reference, respelled by oracle/make_ref.py and compiled by g++ (oracle/_ref/libk4ref*.so).
+    Same call shapes as `Oracle`'s raw entry points.  variant: "" (NET5_0_OR_GREATER), "_net462", "_debug" (Assert()s on)."""
+
+    def __init__(self, variant: str = ""):
+        so = build_ref()
+        if so is None:
+            raise FileNotFoundError("oracle/_ref/libk4ref.so (needs /root/reference at build time)")
+        so = so.replace("libk4ref.so", f"libk4ref{variant}.so")
+        if variant == "_debug" and REFERENCE_PRESENT:
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "_ref/libk4ref_debug.so"])
+        self.lib = L = C.CDLL(so)
+        enc = [_u8p, _u8p, C.c_int, C.c_int, C.c_int]
+        for f in ("k4ref_compress_fast", "k4ref_compress_fast_x32", "k4ref_compress_hc", "k4ref_compress_hc_x32"):
+            getattr(L, f).argtypes = enc
+        dec = [_u8p, _u8p, C.c_int, C.c_int]
+        L.k4ref_decompress_safe.argtypes = dec
+        L.k4ref_decompress_safe_x32.argtypes = dec
+        L.k4ref_decompress_safe_partial.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int]
+        L.k4ref_decompress_safe_using_dict.argtypes = [_u8p, _u8p, C.c_int, C.c_int, _u8p, C.c_int]
+        L.k4ref_compress_bound.argtypes = [C.c_int]
+        L.k4ref_inputs_sha256.restype = C.c_char_p
+        self.inputs_sha256 = L.k4ref_inputs_sha256().decode()
+
+    def compress_bound(self, n):
+        return self.lib.k4ref_compress_bound(n)
+
+    def _enc(self, fn, src, cap, arg):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        if cap is None:
+            cap = self.compress_bound(src.size)
+        dst = np.full(max(cap, 1), 0xCD, dtype=np.uint8)
+        ret = fn(_ptr(src if src.size else np.zeros(1, np.uint8)), _ptr(dst), src.size, cap, arg)
+        return ret, dst[:cap]
+
+    def compress_fast(self, src, cap=None, accel=1):
+        return self._enc(self.lib.k4ref_compress_fast, src, cap, accel)
+
+    def compress_fast_x32(self, src, cap=None, accel=1):
+        return self._enc(self.lib.k4ref_compress_fast_x32, src, cap, accel)
+
+    def compress_hc(self, src, level, cap=None):
+        return self._enc(self.lib.k4ref_compress_hc, src, cap, level)
+
+    def compress_hc_x32(self, src, level, cap=None):
+        return self._enc(self.lib.k4ref_compress_hc_x32, src, cap, level)
+
+    def decompress_safe(self, src, cap, fill=0xCD, x32=False):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dst = np.full(max(cap, 1), fill, dtype=np.uint8)
+        fn = self.lib.k4ref_decompress_safe_x32 if x32 else self.lib.k4ref_decompress_safe
+        ret = fn(_ptr(src if src.size else np.zeros(1, np.uint8)), _ptr(dst), src.size, cap)
+        return ret, dst[:cap]
+
+    def decompress_partial(self, src, target, cap):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dst = np.full(max(cap, 1), 0xCD, dtype=np.uint8)
+        ret = self.lib.k4ref_decompress_safe_partial(_ptr(src), _ptr(dst), src.size, target, cap)
+        return ret, dst[:cap]
+
+    def decompress_using_dict(self, src, cap, dictionary):
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dictionary = np.ascontiguousarray(dictionary, dtype=np.uint8)
+        dst = np.full(max(cap, 1), 0xCD, dtype=np.uint8)
+        ret = self.lib.k4ref_decompress_safe_using_dict(_ptr(src), _ptr(dst), src.size, cap, _ptr(dictionary), dictionary.size)
+        return ret, dst[:cap]

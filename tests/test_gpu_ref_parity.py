@@ -1,0 +1,131 @@
+"""The HIP path against THE REFERENCE ITSELF, compiled here (oracle/_ref/libk4ref.so = the reference's own LL64 / LL32
+engine files respelled as C++ by oracle/make_ref.py; the prebuilt library travels to the GPU box with the snapshot).
+The other GPU tests compare with the oracle restatement, which tests/test_ref_pins.py pins to this library byte for byte;
+these compare the kernels with it directly, through the C ABI, on the graded data."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from k4os.compression.lz4_amd import LZ4Codec, LZ4Level, LZ4Pickler, corpus, pack_blocks, make_arena
+from k4os.compression.lz4_amd._native import FLAG_RAW_RETURN, load_library
+from oracle_lib import RefEngine, REFERENCE_PRESENT
+from test_oracle_pins import _pool_map
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ref():
+    try:
+        return RefEngine()
+    except FileNotFoundError as e:
+        assert not REFERENCE_PRESENT
+        pytest.skip(str(e))
+
+
+def _enc(ref, b, level=0):
+    r, d = ref.compress_fast(b) if level == 0 else ref.compress_hc(b, level)
+    return d[:r].tobytes()
+
+
+def test_bench_batch_l00_every_block_vs_compiled_reference(ref):
+    """configs[1]: all 4096 blocks of bench.py's batch, encoded on the GPU, bytes equal to LL64.LZ4_compress_fast's"""
+    blocks = corpus.silesia_like_blocks(4096, 65536, seed=2)
+    n = blocks.shape[0]
+    off = np.arange(n, dtype=np.uint64) * 65536
+    lens = np.full(n, 65536, np.int32)
+    caps = np.full(n, LZ4Codec.MaximumOutputSize(65536), np.int32)
+    dst, doff = make_arena(caps, fill=0xCD)
+    out = LZ4Codec.EncodeBatchPacked(blocks.reshape(-1), off, lens, dst, doff, caps)
+    want = _pool_map(lambda i: _enc(ref, blocks[i]), range(n))
+    bad = [i for i in range(n) if out[i] != len(want[i]) or dst[int(doff[i]):int(doff[i]) + int(out[i])].tobytes() != want[i]]
+    assert not bad, bad[:10]
+    # and the decoder on the reference's own streams: return values and bytes
+    src, soff, slen = pack_blocks([np.frombuffer(w, np.uint8) for w in want])
+    back, boff = make_arena(lens, fill=0xCD)
+    dl = LZ4Codec.DecodeBatchPacked(src, soff, slen, back, boff, lens, flags=FLAG_RAW_RETURN)
+    assert (dl == 65536).all() and np.array_equal(back[:n * 65536].reshape(n, 65536), blocks)
+
+
+@pytest.mark.parametrize("level,count", [(3, 384), (9, 96), (10, 48), (12, 24)])
+def test_bench_blocks_hc_levels_vs_compiled_reference(ref, level, count):
+    """configs[4] and the other levels ChecksumBlockTests.cs:125-172 holds goldens for"""
+    blocks = corpus.silesia_like_blocks(4096, 65536, seed=2)[:count]
+    enc = LZ4Codec.EncodeBatch(list(blocks), level=LZ4Level(level))
+    want = _pool_map(lambda i: _enc(ref, blocks[i], level), range(count))
+    bad = [i for i in range(count) if enc[i] != want[i]]
+    assert not bad, bad[:10]
+
+
+def test_ragged_messages_both_engines_vs_compiled_reference(ref):
+    """byU16 / byU32 switch at 65 547 and messages up to 4 MiB (configs[3] shapes); with Enforce32 the 32-bit engine's bytes
+    (x32/LL32.tools.cs:141-148) -- this arm was compared with an unpinned oracle arm until round 4"""
+    sizes = [1, 12, 13, 100, 65535, 65536, 65546, 65547, 70000, 300000, 1 << 20, (4 << 20) - 3]
+    blocks = [corpus.class_bytes(corpus.SILESIA_NAMES[i % 12], s, 40 + i) for i, s in enumerate(sizes)]
+    enc = LZ4Codec.EncodeBatch(blocks)
+    for b, e in zip(blocks, enc):
+        assert e == _enc(ref, b), b.size
+    try:
+        LZ4Codec.Enforce32 = True
+        enc32 = LZ4Codec.EncodeBatch(blocks)
+        pick = LZ4Pickler.Pickle(blocks[8])
+    finally:
+        LZ4Codec.Enforce32 = False
+    differ = 0
+    for b, e, e64 in zip(blocks, enc32, enc):
+        r, d = ref.compress_fast_x32(b)
+        assert e == d[:r].tobytes(), b.size
+        differ += e != e64
+    assert differ >= 4
+    # the pickle of a >= 64 KiB message under Enforce32 carries the LL32 block (the flag was dropped)
+    r, d = ref.compress_fast_x32(blocks[8])
+    assert pick.endswith(d[:r].tobytes())
+
+
+def test_acceleration_through_the_llxx_seam(ref):
+    """LLxx.LZ4_compress_fast passes `acceleration` through (LLxx.cs:65-75): k4lz4_compress_fast with 1, 2, 8 and an out of
+    range value (< 1 -> ACCELERATION_DEFAULT, LL64.fast.cs:522)"""
+    lib = load_library()
+    u8p = C.POINTER(C.c_uint8)
+    lib.k4lz4_compress_fast.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int]
+    for i, size in enumerate((3000, 65536, 65600, 200000)):
+        for cls in ("dickens", "xml", "mr", "sao"):
+            data = corpus.class_bytes(cls, size, i)
+            cap = LZ4Codec.MaximumOutputSize(size)
+            for acc in (1, 2, 8, 0, 70):
+                dst = np.full(cap, 0xCD, np.uint8)
+                r = lib.k4lz4_compress_fast(data.ctypes.data_as(u8p), dst.ctypes.data_as(u8p), size, cap, acc)
+                want_r, want = ref.compress_fast(data, accel=acc)
+                assert r == want_r and dst.tobytes() == want.tobytes(), (cls, size, acc)
+
+
+def test_mutated_streams_vs_compiled_reference(ref):
+    """LZ4_decompress_safe's return value (negative error position included) and bytes on 1 200 mutants"""
+    rng = np.random.default_rng(32)
+    comps, caps = [], []
+    for name, n in (("dickens", 3000), ("xml", 6000), ("mr", 66000)):
+        data = corpus.class_bytes(name, n, 4)
+        r, d = ref.compress_fast(data)
+        good = d[:r].copy()
+        for t in range(400):
+            bad = good.copy()
+            k = t % 4
+            if k == 0:
+                bad = bad[:rng.integers(1, good.size)]
+            elif k == 1:
+                for _ in range(int(rng.integers(1, 4))):
+                    bad[rng.integers(0, good.size)] = rng.integers(0, 256)
+            elif k == 2:
+                bad = np.concatenate([bad, rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8)])
+            comps.append(bad)
+            caps.append(n + int(rng.integers(-20, 21)) if k != 3 else int(rng.integers(0, n)))
+    src, soff, slen = pack_blocks(comps)
+    caps = np.array(caps, np.int32)
+    dst, doff = make_arena(caps + 32, fill=0xCD)
+    out = LZ4Codec.DecodeBatchPacked(src, soff, slen, dst, doff, caps, flags=FLAG_RAW_RETURN)
+    for i, (c, cap) in enumerate(zip(comps, caps)):
+        n, want = ref.decompress_safe(c, int(cap))
+        assert out[i] == n, i
+        if n > 0:
+            assert dst[int(doff[i]):int(doff[i]) + n].tobytes() == want[:n].tobytes()
