@@ -169,9 +169,10 @@ namespace {
 thread_local std::string tl_error;
 thread_local int tl_status = K4LZ4_OK;
 
+std::mutex g_err_mu;   /* a host-pointer call's download thread and its staging thread may both fail at the same moment */
 int fail(k4lz4_ctx *ctx, int code, const std::string &msg)
 {
-    if (ctx) ctx->error = msg;
+    if (ctx) { std::lock_guard<std::mutex> g(g_err_mu); ctx->error = msg; }
     tl_error = msg;
     return code;
 }
@@ -339,6 +340,17 @@ struct DictArgs {
     const signed char *mode;
 };
 
+/* how many slots the LDS-table encoder kernel is launched with for a batch of cnt blocks: a fixed share of the number
+ * (K4LZ4_SPLIT_PCT), or the most the device-side split by cost (k4_order_kernel, cost_pct hundredths of the cost, at least one
+ * residency) can ask for -- that kernel clamps its count to this value, so a block is never left to neither kernel */
+static int64_t lds_share(const k4lz4_ctx *ctx, int64_t cnt)
+{
+    const int64_t lds_slots = 8 * (int64_t)ctx->cu_count;
+    if (ctx->split_pct > 0) return std::min<int64_t>(cnt, std::max<int64_t>(1, cnt * ctx->split_pct / 100));
+    const int64_t pct = std::max<int64_t>(48, std::min<int64_t>(ctx->cost_pct, 100));
+    return std::min<int64_t>(cnt, std::max<int64_t>(lds_slots, (cnt * pct + 99) / 100));
+}
+
 /* enqueue the kernels for n blocks; all pointers are device pointers */
 int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
                  const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, int64_t n, int level, int flags,
@@ -387,7 +399,15 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
         K4_HIP(ctx, hipGetLastError());
         return K4LZ4_OK;
     }
-    if (kind == KIND_PICKLE && (n > (int64_t)ctx->pickle_split_min || ctx->use_segments) && !ctx->prof) {
+    /* (a small batch without a message big enough to be cut into segments keeps the one-kernel pickle path: the segment
+     * machinery costs a plan kernel, a 4096-workgroup launch on a second queue, a join, and -- on a context's first such
+     * call -- 269 MB of scratch; lengths the host does not know count as "may be big") */
+    bool may_cut = ctx->use_segments;
+    if (may_cut && hostLen && n <= (int64_t)ctx->pickle_split_min) {
+        may_cut = false;
+        for (int64_t i = 0; i < n && !may_cut; i++) may_cut = (uint32_t)hostLen[i] >= ctx->seg_min;
+    }
+    if (kind == KIND_PICKLE && (n > (int64_t)ctx->pickle_split_min || may_cut) && !ctx->prof) {
         /* Fast-level pickles of a batch go the encoders' way: slots prepared (block = envelope + 5, cap U - 1, exactly what
          * k4_pickle_kernel hands its encoder), the batch encoded by the two encoder kernels side by side -- the expensive
          * messages with their tables in LDS, the others with tables in memory, which puts a ragged batch on all the
@@ -407,7 +427,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             a.flags = flags | (g_enforce32.load(std::memory_order_relaxed) ? K4LZ4_FLAG_X32 : 0);
             hipLaunchKernelGGL(k4::k4_pickle_prep_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, a, d_encoff, d_enccap);
             rc = launch_inner(ctx, KIND_ENCODE, src, srcOff + first, srcLen + first, dst, d_encoff, d_enccap, d_enclen, cnt, level,
-                              (flags & K4LZ4_FLAG_NO_REORDER) | K4LZ4_FLAG_RAW_RETURN | FLAG_SEGMENTS_OK, stream, nullptr, hostLen ? hostLen + first : nullptr);
+                              (flags & (K4LZ4_FLAG_NO_REORDER | K4LZ4_FLAG_X32)) | K4LZ4_FLAG_RAW_RETURN | FLAG_SEGMENTS_OK, stream, nullptr, hostLen ? hostLen + first : nullptr);
             if (rc != K4LZ4_OK) return rc;
             hipLaunchKernelGGL(k4::k4_pickle_finish_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a, d_enclen);
             K4_HIP(ctx, hipGetLastError());
@@ -499,7 +519,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             k4::BatchArgs ao = a;
             ao.first = two_kernels ? (uint32_t)ctx->cost_pct : 0u;
             ao.total = (uint32_t)((int64_t)ctx->lds_floor_per_cu * (int64_t)ctx->cu_count);
-            hipLaunchKernelGGL(k4::k4_order_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, ao);
+            hipLaunchKernelGGL(k4::k4_order_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, ao, (uint32_t)lds_share(ctx, cnt));
             a.order = d_order;
             if (two_kernels) a.split = d_hist + 2 * k4::COST_BUCKETS;
         }
@@ -525,11 +545,10 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
                  * residency of the chip (8 blocks per CU) or about 48 % of a larger batch; one block more
                  * than a residency starts a second pass and costs 20 % */
                 const int64_t lds_slots = 8 * (int64_t)ctx->cu_count;
-                const int64_t n_lds = ctx->split_pct > 0 ? std::min<int64_t>(cnt, std::max<int64_t>(1, cnt * ctx->split_pct / 100))
-                                                         : std::min<int64_t>(cnt, std::max<int64_t>(lds_slots, cnt * 48 / 100));
+                const int64_t n_lds = lds_share(ctx, cnt);
                 /* (with the split decided on the device, a.split: n_lds is the most the LDS-table kernel can get -- the share of
                  * the cost is never a larger share of the number -- and the other kernel is sized for the least) */
-                const int64_t n_g = cnt - (a.split ? std::min<int64_t>(cnt, lds_slots) : n_lds);
+                const int64_t n_g = cnt - (a.split ? std::min<int64_t>(cnt, (int64_t)ctx->lds_floor_per_cu * (int64_t)ctx->cu_count) : n_lds);
                 const int64_t gchunk = 8192;
                 if (n_g > 0 && (size_t)std::min(n_g, gchunk) * 16384 > ctx->d_gtab_cap) {
                     K4_HIP(ctx, hipStreamSynchronize(ctx->aux));
@@ -1055,18 +1074,21 @@ int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t
     };
     int dl_rc = K4LZ4_OK;
     auto download_all = [&]() {
-        (void)hipSetDevice(ctx->device);
-        uint64_t pack_base = 0;
-        for (int p = 0; p < nparts; p++) {
-            {
-                std::unique_lock<std::mutex> lk(dm);
-                dcv.wait(lk, [&] { return launched > p || abandon; });
-                if (launched <= p) return;
+        try {      /* it may run as a thread: nothing may escape (std::terminate), and its message is its own (tl_error) */
+            (void)hipSetDevice(ctx->device);
+            uint64_t pack_base = 0;
+            for (int p = 0; p < nparts; p++) {
+                {
+                    std::unique_lock<std::mutex> lk(dm);
+                    dcv.wait(lk, [&] { return launched > p || abandon; });
+                    if (launched <= p) return;
+                }
+                const int r = download_part(p, pack_base);
+                if (r != K4LZ4_OK) { dl_rc = r; dl_error = tl_error; return; }
             }
-            const int r = download_part(p, pack_base);
-            if (r != K4LZ4_OK) { dl_rc = r; dl_error = ctx->error; return; }
-        }
-        if (hipStreamSynchronize(dq) != hipSuccess) { (void)hipGetLastError(); dl_rc = K4LZ4_E_HIP; dl_error = "download queue failed"; }
+            if (hipStreamSynchronize(dq) != hipSuccess) { (void)hipGetLastError(); dl_rc = K4LZ4_E_HIP; dl_error = "download queue failed"; }
+        } catch (const std::bad_alloc &) { dl_rc = K4LZ4_E_NOMEM; dl_error = "download: out of host memory";
+        } catch (...) { dl_rc = K4LZ4_E_HIP; dl_error = "download: unexpected exception"; }
     };
     std::thread dl_thread;
     bool threaded = false;
@@ -1332,20 +1354,26 @@ int k4lz4_synchronize(k4lz4_ctx *ctx, void *stream)
 int k4lz4_host_register(void *ptr, size_t bytes)
 {
     if (!ptr || !bytes) { tl_error = "k4lz4_host_register: empty range"; return K4LZ4_E_ARG; }
-    {
-        const uintptr_t a = (uintptr_t)ptr;
+    /* one lock scope for check + insert: the range is entered before the (slow) pinning so that a second thread registering an
+     * overlapping range is refused; if pinning fails the entry is taken out again */
+    const uintptr_t a = (uintptr_t)ptr;
+    try {
         std::lock_guard<std::mutex> g(g_reg_mu);
         for (const auto &r : g_reg)
             if (a < r.first + r.second && r.first < a + bytes) { tl_error = "k4lz4_host_register: overlaps a registered range"; return K4LZ4_E_ARG; }
-    }
+        g_reg.emplace_back(a, bytes);
+    } catch (const std::bad_alloc &) { tl_error = "k4lz4_host_register: out of host memory"; return K4LZ4_E_NOMEM; }
     const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
     if (e != hipSuccess) {
         (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> g(g_reg_mu);
+            auto it = std::find_if(g_reg.begin(), g_reg.end(), [&](const std::pair<uintptr_t, size_t> &r) { return r.first == a && r.second == bytes; });
+            if (it != g_reg.end()) g_reg.erase(it);
+        }
         tl_error = std::string("hipHostRegister: ") + hipGetErrorString(e);
         return e == hipErrorOutOfMemory ? K4LZ4_E_NOMEM : K4LZ4_E_HIP;
     }
-    std::lock_guard<std::mutex> g(g_reg_mu);
-    g_reg.emplace_back((uintptr_t)ptr, bytes);
     return K4LZ4_OK;
 }
 

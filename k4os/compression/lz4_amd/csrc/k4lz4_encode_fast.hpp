@@ -980,8 +980,10 @@ __device__ __forceinline__ unsigned long long bucket_cost(uint32_t bkt)
 /* order[] = block indices, most expensive bucket first.  Its first thread also says where the second encoder kernel's part of
  * that order begins (hist[2 * COST_BUCKETS]): the most expensive blocks that hold `first` hundredths of the batch's COST go
  * to the LDS-table kernel -- for blocks of one size that is the same share of their number, for a ragged batch a few big
- * ones --, but never fewer than `total` of them (one residency of that kernel), when the batch has that many. */
-__global__ __launch_bounds__(256) void k4_order_kernel(BatchArgs a)
+ * ones --, but never fewer than `total` of them (one residency of that kernel), when the batch has that many.
+ * `lds_max`: the number of slots the host launched the LDS-table kernel with -- the count decided here never exceeds it
+ * (the rounding-up of a bucket's part could otherwise give one more, and that block would be encoded by neither kernel). */
+__global__ __launch_bounds__(256) void k4_order_kernel(BatchArgs a, uint32_t lds_max = 0xffffffffu)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.first != 0u) {
         unsigned long long all = 0;
@@ -996,6 +998,7 @@ __global__ __launch_bounds__(256) void k4_order_kernel(BatchArgs a)
         const unsigned long long floor_n = (unsigned long long)a.total < (unsigned long long)a.n ? (unsigned long long)a.total : (unsigned long long)a.n;
         if (cnt < floor_n) cnt = floor_n;
         if (cnt > (unsigned long long)a.n) cnt = (unsigned long long)a.n;
+        if (cnt > (unsigned long long)lds_max) cnt = (unsigned long long)lds_max;
         a.hist[2 * COST_BUCKETS] = (uint32_t)cnt;
     }
     const long long b = (long long)blockIdx.x * 256 + threadIdx.x;

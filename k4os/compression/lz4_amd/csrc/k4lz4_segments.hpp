@@ -157,8 +157,13 @@ __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_wav
     const long long b = (long long)s.block;
     const int U = a.srcLen[b];
     SegRun r = seg_run_of(g, it, s);
-    const uint32_t end = s.next_start != SEG_NONE ? s.next_start : (uint32_t)U;
-    const int ret = compress_fast_block<false, false, false>(a.src + a.srcOff[b], U, a.dst + a.dstOff[b] + s.start, (int)(end - s.start), a.accel, stages[wave], lane,
+    /* its piece lies at `start` of the block's slot and may reach neither the next segment's place nor the end of the slot
+     * (the plan accepts cap == U - 1: the last piece must not store to dst[cap]) */
+    const uint32_t slot_cap = a.dstCap[b] < 0 ? 0u : (uint32_t)a.dstCap[b];
+    uint32_t end = s.next_start != SEG_NONE ? s.next_start : (uint32_t)U;
+    if (end > slot_cap) end = slot_cap;
+    const int ret = end <= s.start ? 0 :
+                    compress_fast_block<false, false, false>(a.src + a.srcOff[b], U, a.dst + a.dstOff[b] + s.start, (int)(end - s.start), a.accel, stages[wave], lane,
                                                              g.tables + 4096ull * (unsigned long long)w, (a.flags & FLAG_X32) != 0, a.pace, &r);
     if (lane == 0) {
         g.items[it].cut = r.cut; g.items[it].stop = r.stop; g.items[it].state = ret > 0 ? r.state : 3u; g.items[it].bytes = ret;

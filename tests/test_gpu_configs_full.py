@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import pytest
 
-from k4os.compression.lz4_amd import LZ4Codec, LZ4Level, corpus, make_arena
+from k4os.compression.lz4_amd import LZ4Codec, LZ4Level, LZ4Pickler, corpus, make_arena
 from k4os.compression.lz4_amd._native import FLAG_RAW_RETURN, FLAG_SEGMENTS, FLAG_X32
 from k4os.compression.lz4_amd.sharding import byte_balanced_ranges
 
@@ -428,3 +428,38 @@ def test_two_ranks_on_one_gpu_run_the_real_multi_rank_backend():
     assert r["n_gpus"] == 2 and r["roundtrip_ok_all_ranks"] and r["size_vector_sample_equals_oracle"]
     assert r["size_vector_equals_single_rank_run"] is True
     assert len(r["rank_busy_ms"]) == 2 and r["critical_path_ms"] > 0
+
+
+@pytest.mark.parametrize("n", [5001, 8192])
+def test_uniform_cost_pickle_batch_leaves_no_block_to_neither_encoder_kernel(oracle, n):
+    """a batch that lands in ONE cost bucket made k4_order_kernel round the device-side split up to
+    n_lds + 1 while the host launched the LDS-table kernel with n_lds slots -- order[n_lds] was encoded by neither kernel.
+    n uniform messages (same class, same length) through the unchunked pickle path: every envelope vs the oracle."""
+    msgs = [corpus.class_bytes("dickens", 3000, 900 + (i % 64)) for i in range(n)]
+    got = LZ4Pickler.PickleBatch(msgs)
+    want = {}
+    for i in range(n):
+        k = i % 64
+        if k not in want:
+            want[k] = oracle.pickle(msgs[i])
+        assert got[i] == want[k], i
+
+
+def test_pickle_batch_honours_the_per_call_x32_flag(oracle):
+    """K4LZ4_FLAG_X32 on a pickle call was dropped by the segment-capable pickle path; a >= 64 KiB
+    message must carry the 32-bit engine's block (oracle arm pinned to LL32 compiled here, tests/test_ref_pins.py)"""
+    from k4os.compression.lz4_amd import _native
+    from k4os.compression.lz4_amd.codec import _batch_args, pack_blocks, make_arena
+    ctx = _native.default_context()
+    msgs = [corpus.class_bytes("dickens", 70000, 1), corpus.lorem(150000), corpus.class_bytes("xml", 3000, 2)]
+    src, soff, slen = pack_blocks(msgs)
+    caps = np.array([ctx.lib.k4lz4_pickle_bound(m.size) for m in msgs], dtype=np.int32)
+    dst, doff = make_arena(caps)
+    out = np.empty(len(msgs), dtype=np.int32)
+    ctx.check(ctx.lib.k4lz4_pickle_batch(ctx.handle, *_batch_args(src, soff, slen, dst, doff, caps, out), 0, _native.FLAG_X32))
+    for i, m in enumerate(msgs):
+        env = dst[int(doff[i]):int(doff[i]) + int(out[i])].tobytes()
+        r, w = oracle.compress_fast_x32(m)
+        assert env.endswith(w[:r].tobytes()), i
+        if m.size >= 65547:
+            assert env != oracle.pickle(m)
