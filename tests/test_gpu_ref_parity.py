@@ -69,7 +69,8 @@ def test_ragged_messages_both_engines_vs_compiled_reference(ref):
     try:
         LZ4Codec.Enforce32 = True
         enc32 = LZ4Codec.EncodeBatch(blocks)
-        pick = LZ4Pickler.Pickle(blocks[8])
+        text = corpus.class_bytes("dickens", 70000, 3)           # compressible, so the envelope carries a block and not the raw bytes
+        pick = LZ4Pickler.Pickle(text)
     finally:
         LZ4Codec.Enforce32 = False
     differ = 0
@@ -79,8 +80,8 @@ def test_ragged_messages_both_engines_vs_compiled_reference(ref):
         differ += e != e64
     assert differ >= 4
     # the pickle of a >= 64 KiB message under Enforce32 carries the LL32 block (the flag was dropped)
-    r, d = ref.compress_fast_x32(blocks[8])
-    assert pick.endswith(d[:r].tobytes())
+    r, d = ref.compress_fast_x32(text)
+    assert pick[0] != 0 and pick.endswith(d[:r].tobytes())
 
 
 def test_acceleration_through_the_llxx_seam(ref):
