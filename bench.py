@@ -137,14 +137,30 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
+    # K4LZ4_RANK_DEVICE=0 puts every rank on GPU 0 (the headline path with world > 1 on a one-GPU box, tests/test_gpu_configs_full.py):
+    # RCCL refuses two ranks on one device, so the barrier / max / size vector then travel over gloo
+    shared = os.environ.get("K4LZ4_RANK_DEVICE")
+    device = int(shared) if shared is not None else local_rank
+    torch.cuda.set_device(device)
+    on = torch.device("cuda", device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if shared is None:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=on)
+        else:
+            os.environ.setdefault("MASTER_PORT", "29534")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            on = torch.device("cpu")
 
     n, bs = args.blocks, args.block_size
-    blocks = corpus.silesia_like_blocks(n, bs, seed=2 + rank)
-    dc = DeviceCodec(local_rank)
+    corpus_dir = os.environ.get("K4LZ4_CORPUS_DIR")
+    blocks = corpus.silesia_blocks(n, bs, corpus_dir) if corpus_dir and os.path.isdir(corpus_dir) else None
+    data_kind = "silesia" if blocks is not None else "synthetic"
+    if blocks is None:
+        blocks = corpus.silesia_like_blocks(n, bs, seed=2 + rank)
+    elif rank:
+        blocks = np.roll(blocks, -rank * 97, axis=0)       # every rank its own order of the same corpus
+    dc = DeviceCodec(device)
     lens = np.full(n, bs, np.int32)
     off = np.arange(n, dtype=np.uint64) * bs
     bound = LZ4Codec.MaximumOutputSize(bs)
@@ -181,7 +197,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dc.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=on)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -231,29 +247,59 @@ def main():
             bit_exact = bit_exact and ok_roundtrip
             if not args.no_cpu_baseline:
                 out_h, out_off = make_arena(lens)
-                t_dec = []
-                for _ in range(2):
-                    t = time.perf_counter()
-                    oracle.decode_batch(ref_dst, ref_off, ref_len, out_h, out_off, lens, threads=threads)
-                    t_dec.append(time.perf_counter() - t)
-                # single-thread sample for orientation
-                k1 = min(n, 256)
-                t = time.perf_counter()
-                oracle.encode_batch(src_h, off[:k1], lens[:k1], ref_dst, ref_off[:k1], caps[:k1], threads=1)
-                t1e = time.perf_counter() - t
-                t = time.perf_counter()
-                oracle.decode_batch(ref_dst, ref_off[:k1], ref_len[:k1], out_h, out_off[:k1], lens[:k1], threads=1)
-                t1d = time.perf_counter() - t
                 gib = sum_u / 2 ** 30
+                k1 = min(n, 256)
+
+                def timed(engine, label):
+                    """encode + decode of the whole batch on all host threads (best of 2) and of 256 blocks on one thread"""
+                    te, td = [], []
+                    for _ in range(2):
+                        t = time.perf_counter(); el = engine.encode_batch(src_h, off, lens, ref_dst, ref_off, caps, threads=threads); te.append(time.perf_counter() - t)
+                    for _ in range(2):
+                        t = time.perf_counter(); engine.decode_batch(ref_dst, ref_off, el, out_h, out_off, lens, threads=threads); td.append(time.perf_counter() - t)
+                    t = time.perf_counter(); engine.encode_batch(src_h, off[:k1], lens[:k1], ref_dst, ref_off[:k1], caps[:k1], threads=1); t1e = time.perf_counter() - t
+                    t = time.perf_counter(); engine.decode_batch(ref_dst, ref_off[:k1], el[:k1], out_h, out_off[:k1], lens[:k1], threads=1); t1d = time.perf_counter() - t
+                    return {"value": round(gib / (min(te) + min(td)), 3), "encode_GiBs": round(gib / min(te), 3), "decode_GiBs": round(gib / min(td), 3),
+                            "one_thread_encode_GiBs": round(k1 * bs / 2 ** 30 / t1e, 3), "one_thread_decode_GiBs": round(k1 * bs / 2 ** 30 / t1d, 3),
+                            "what": label}
+
+                port = timed(oracle, "oracle/k4lz4_oracle.c: C restatement of the reference's LL64 engine, gcc -O2")
+                ref_cpu = None
+                try:
+                    from oracle_lib import RefEngine
+                    ref_engine = RefEngine()
+                    ref_cpu = timed(ref_engine, "oracle/_ref/libk4ref.so: the reference's own LL64 engine files (Engine/x64/LL64.fast.cs, LL64.dec.cs) "
+                                                "respelled as C++ by oracle/make_ref.py, g++ -O2 -fwrapv")
+                    # and its bytes against the GPU's, block by block (the restatement's were compared above)
+                    ref2_dst, _ = make_arena(caps)
+                    ref2_len = ref_engine.encode_batch(src_h, off, lens, ref2_dst, ref_off, caps, threads=threads)
+                    ref_cpu["equals_gpu_bytes"] = bool(np.array_equal(ref2_len, clen_h.astype(np.int32))) and all(
+                        np.array_equal(comp_h[coff_h[i]:coff_h[i] + clen_h[i]], ref2_dst[int(ref_off[i]):int(ref_off[i]) + int(ref2_len[i])]) for i in range(n))
+                except FileNotFoundError:
+                    pass
+                # SURVEY.md 8(d): "as sanity, liblz4.so.1" -- one thread (ctypes calls hold no batch entry point), 256 blocks
+                lz = None
+                try:
+                    from oracle_lib import SystemLZ4
+                    sl = SystemLZ4()
+                    if sl.available:
+                        t = time.perf_counter(); encs = [sl.compress_fast(blocks[i], bound) for i in range(k1)]; t1e = time.perf_counter() - t
+                        t = time.perf_counter(); [sl.decompress_safe(d[:r], bs) for r, d in encs]; t1d = time.perf_counter() - t
+                        lz = {"version": sl.version, "one_thread_encode_GiBs": round(k1 * bs / 2 ** 30 / t1e, 3), "one_thread_decode_GiBs": round(k1 * bs / 2 ** 30 / t1d, 3),
+                              "what": "liblz4.so.1 through ctypes, per-block calls, 256 blocks (sanity column, not the reference)"}
+                except Exception:
+                    lz = None
+                head = ref_cpu or port
                 cpu = {
-                    "value": round(gib / (min(t_enc) + min(t_dec)), 3), "unit": "GiB/s", "cores": threads,
-                    "kind": "port",
-                    "sample": f"all {n} blocks x {bs} B of this workload, encode+decode, best of 2, {threads} threads "
-                              f"(oracle = C restatement of the reference's LL64 engine, gcc -O2)",
-                    "encode_GiBs": round(gib / min(t_enc), 3), "decode_GiBs": round(gib / min(t_dec), 3),
-                    "one_thread_encode_GiBs": round(k1 * bs / 2 ** 30 / t1e, 3),
-                    "one_thread_decode_GiBs": round(k1 * bs / 2 ** 30 / t1d, 3),
+                    "value": head["value"], "unit": "GiB/s", "cores": threads,
+                    "kind": "reference" if ref_cpu else "port",
+                    "sample": f"all {n} blocks x {bs} B of this workload, encode+decode, best of 2, {threads} threads; {head['what']}",
+                    "encode_GiBs": head["encode_GiBs"], "decode_GiBs": head["decode_GiBs"],
+                    "one_thread_encode_GiBs": head["one_thread_encode_GiBs"], "one_thread_decode_GiBs": head["one_thread_decode_GiBs"],
+                    "port": port, "liblz4": lz,
                 }
+                if ref_cpu:
+                    cpu["equals_gpu_bytes"] = ref_cpu["equals_gpu_bytes"]
         # the same batch through the host-pointer entry points (pageable host memory -> GPU -> host memory): PCIe and staging
         # inclusive, reported beside the metric, never as `value`
         host_to_host = None
@@ -292,13 +338,14 @@ def main():
                     host_unregister(arr)
         ms_per_step = elapsed / args.steps * 1e3
         alg_bytes = sum_u + sum_c + 12 * n          # U read + C written (+12 B metadata) per block
-        enc_avg, dec_avg = float(enc_ms.mean()), float(dec_ms.mean())
+        # median of the timed launches (the mean is kept beside it)
+        enc_avg, dec_avg = float(np.median(enc_ms)), float(np.median(dec_ms))
 
         # HBM traffic per launch: rocprofv3 PMC passes (scripts/pmc_round.sh: the L2's DRAM read and write requests in 32-byte units,
         # separate passes; the same two counters reproduce the known byte counts of scripts/ubench/pmc_calib.hip exactly, which
         # FETCH_SIZE / WRITE_SIZE do not).  The file names the kernel sources it was measured on; figures from other
         # sources (or for another workload) are not reported: traffic = null.
-        traffic = {}
+        traffic, issue_doc = {}, {}
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path) and n == 4096 and bs == 65536:
             try:
@@ -312,17 +359,43 @@ def main():
                         h.update(name.encode()); h.update(open(os.path.join(csrc, name), "rb").read())
                 if doc.get("source_sha") == h.hexdigest()[:16]:
                     traffic = doc.get("traffic_bytes_per_launch", {})
+                    issue_doc = doc.get("issue", {})
             except Exception:
                 traffic = {}
 
-        def roof(avg_ms, kernels, timed):
-            ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+        def issue(kernels, units, per, med_ms):
+            """the limit that binds these kernels: how busy the vector and scalar issue ports are over the timed call
+            and how many wave instructions a unit of work costs -- from the same hashed PMC file as `traffic`
+            (scripts/pmc_summary.py: SQ_ACTIVE_INST_VALU / _SCA in quad-cycles, SQ_INSTS_*), else null"""
+            rows = [issue_doc.get(k) for k in kernels]
+            if not rows or any(r is None for r in rows) or not rows[0].get("kernel_ns_alone"):
+                return None
+            insts = sum(r["insts_total"] for r in rows)
+            clock_ghz = rows[0]["kernel_cycles_alone"] / rows[0]["kernel_ns_alone"]
+            call_cycles = med_ms * 1e6 * clock_ghz                     # kernels that run side by side share the call's cycles
+            return {"valu_busy": round(4.0 * sum(r["active_valu_quadcycles"] for r in rows) / 1024 / call_cycles, 3),
+                    "salu_busy": round(4.0 * sum(r["active_scalar_quadcycles"] for r in rows) / 1024 / call_cycles, 3),
+                    "wave_insts_per_launch": int(insts), per: round(insts / units, 2) if units else None,
+                    "note": "busy = SQ_ACTIVE_INST_{VALU,SCA} x 4 cycles / (1024 SIMDs x the timed call's cycles); the issue ports, "
+                            "not HBM, are the binding limit (DESIGN.md 5)"}
+
+        def roof(med_ms, mean_ms, kernels, timed, iss):
+            ach = alg_bytes / (med_ms * 1e-3) / 1e9
             tr = [traffic.get(k) for k in kernels]
             return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": sum(tr) if tr and all(t is not None for t in tr) else None,
-                    "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                    "avg_launch_ms": round(med_ms, 4), "avg_is": "median of the timed launches", "mean_launch_ms": round(mean_ms, 4),
+                    "algorithmic_bytes_per_launch": alg_bytes, "issue": iss,
                     "kernel": " || ".join(kernels), "timed": timed}
 
+        n_seq = None
+        if not args.no_verify or not args.no_cpu_baseline:
+            try:
+                n_seq = sum(oracle.count_sequences(ref_dst[int(ref_off[i]):int(ref_off[i]) + int(ref_len[i])]) for i in range(n))
+            except Exception:
+                n_seq = None
+
+        dec_kernel = "k4_decode_pair_kernel" if n <= 16 * 256 and not os.environ.get("K4LZ4_NO_PAIR") else "k4_decode_kernel"
         result = {
             "metric": "GiB/s encode+decode on batched 64 KiB blocks; bit-exact vs C# ref",
             "value": round(world * sum_u / 2 ** 30 / (elapsed / args.steps), 3),
@@ -330,9 +403,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: {n} independent {bs} B blocks per GPU, Silesia-like 12-class "
-                                   f"mix (seed 2+rank), L00_FAST encode + decode, HBM-resident",
+            "dtype": "u8", "data": data_kind,
+            "config": {"workload": f"BASELINE.json configs[1]: {n} independent {bs} B blocks per GPU, " +
+                                   ("real Silesia corpus cut into consecutive blocks (K4LZ4_CORPUS_DIR)" if data_kind == "silesia" else
+                                    "Silesia-like 12-class mix (seed 2+rank)") + ", L00_FAST encode + decode, HBM-resident",
                        "blocks_per_gpu": n, "block_bytes": bs, "level": "L00_FAST",
                        "ratio": round(sum_c / sum_u, 4), "total_compressed_bytes_all_gpus": total_c,
                        "encode_GiBs_per_gpu": round(sum_u / 2 ** 30 / (enc_avg * 1e-3), 3),
@@ -341,11 +415,14 @@ def main():
             "bit_exact": bit_exact,
             # what the events bracket: the whole library call on its launch stream.  Encode = k4_cost_kernel + k4_order_kernel
             # (0.14 ms together), then the two encoder kernels side by side on two queues; the longer of the two is the call.
-            "roofline": roof(enc_avg, ["k4_encode_fast_gtab_kernel", "k4_encode_fast_kernel"],
-                             "k4lz4_encode_batch_device call, HIP events on the launch stream (cost + order kernels, then both encoder kernels concurrently)"),
+            "roofline": roof(enc_avg, float(enc_ms.mean()), ["k4_encode_fast_gtab_kernel", "k4_encode_fast_kernel"],
+                             "k4lz4_encode_batch_device call, HIP events on the launch stream (cost + order kernels, then both encoder kernels concurrently)",
+                             issue(["k4_encode_fast_gtab_kernel", "k4_encode_fast_kernel"], n * bs / 64.0, "wave_insts_per_64_positions", enc_avg)),
             # batches of up to 16 blocks per CU are decoded by the two-waves-per-block kernel (k4lz4_capi.hip launch())
-            "roofline_decode": roof(dec_avg, ["k4_decode_pair_kernel" if n <= 16 * 256 and not os.environ.get("K4LZ4_NO_PAIR") else "k4_decode_kernel"],
-                                    "k4lz4_decode_batch_device call, HIP events on the launch stream (one kernel)"),
+            "roofline_decode": roof(dec_avg, float(dec_ms.mean()), [dec_kernel],
+                                    "k4lz4_decode_batch_device call, HIP events on the launch stream (one kernel)",
+                                    issue([dec_kernel], n_seq, "wave_insts_per_sequence", dec_avg)),
+            "sequences_per_launch": n_seq,
             "cpu_baseline": cpu,
             "host_to_host": host_to_host,
         }

@@ -252,6 +252,25 @@ def silesia_like_blocks(n_blocks: int, block_size: int, seed: int = 2,
     return out
 
 
+def silesia_blocks(n_blocks: int, block_size: int, corpus_dir: str) -> np.ndarray | None:
+    """[n_blocks, block_size] of the REAL corpus ("if K4LZ4_CORPUS_DIR is set, use real Silesia cut into
+    consecutive 64 KiB blocks"): the twelve files in name order, whole blocks only, tiled when the corpus is shorter than the
+    batch.  None when a file is missing."""
+    parts = []
+    for name in SILESIA_NAMES:
+        path = os.path.join(corpus_dir, name)
+        if not os.path.exists(path):
+            return None
+        data = np.fromfile(path, dtype=np.uint8)
+        k = data.size // block_size
+        if k:
+            parts.append(data[:k * block_size].reshape(k, block_size))
+    if not parts:
+        return None
+    allb = np.concatenate(parts)
+    return allb[np.arange(n_blocks) % allb.shape[0]].copy()
+
+
 def variable_messages(n_msgs: int, seed: int = 4, lo: int = 1024, hi: int = 4 << 20,
                       budget_bytes: int | None = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """BASELINE.json configs[3]: message lengths log-uniform in [lo, hi], content alternating

@@ -595,6 +595,27 @@ K4O_API int k4o_decode_batch(const uint8_t *src, const uint64_t *src_off, const 
     return run_batch(1, src, src_off, src_len, dst, dst_off, dst_cap, out_len, n, 0, threads);
 }
 
+/* Number of sequences (tokens) in a VALID block: what bench.py divides the decoder's instruction counters by.
+ * Walks the token chain of LL64.dec.cs:175-336 without copying; -1 on anything that does not parse to the end. */
+K4O_API int64_t k4o_count_sequences(const uint8_t *src, int src_len)
+{
+    const uint8_t *ip = src, *iend = src + src_len;
+    int64_t n = 0;
+    while (ip < iend) {
+        unsigned token = *ip++;
+        size_t len = token >> 4;
+        n++;
+        if (len == 15) { unsigned s; do { if (ip >= iend) return -1; s = *ip++; len += s; } while (s == 255); }
+        if ((size_t)(iend - ip) < len) return -1;
+        ip += len;
+        if (ip == iend) return n;            /* last sequence: literals only */
+        if (iend - ip < 2) return -1;
+        ip += 2;
+        if ((token & 15) == 15) { unsigned s; do { if (ip >= iend) return -1; s = *ip++; } while (s == 255); }
+    }
+    return -1;
+}
+
 /* Adler32 exactly as the reference's test helper computes it (src/TestHelpers/Tools.cs:29-44):
  * used to compare against the golden (length, adler32) rows of ChecksumBlockTests.cs. */
 K4O_API uint32_t k4o_adler32(const uint8_t *data, int64_t len)

@@ -25,3 +25,38 @@ K4REF_API int k4ref_decompress_safe_partial(const uint8_t* s, uint8_t* d, int n,
 K4REF_API int k4ref_decompress_safe_using_dict(const uint8_t* s, uint8_t* d, int n, int cap, const uint8_t* dict, int dictLen) {
 	return LL64::LZ4_decompress_safe_usingDict((byte*) s, d, n, cap, (byte*) dict, dictLen); }
 K4REF_API const char* k4ref_inputs_sha256() { return K4REF_INPUTS_SHA256; }
+
+// ---- threaded batch drivers: bench.py's cpu_baseline (kind "reference") times the reference's own engine on the host cores.
+// The per-block mapping is LZ4Codec's (LZ4Codec.cs:40-52,104-115: empty -> 0, <= 0 -> -1); static partition over T threads.
+#include <pthread.h>
+namespace {
+struct Job { int op; const uint8_t* src; const uint64_t* so; const int32_t* sl; uint8_t* dst; const uint64_t* dof; const int32_t* dc; int32_t* out; int64_t lo, hi; int level; };
+void* worker(void* p) {
+	Job* j = (Job*) p;
+	for (int64_t i = j->lo; i < j->hi; i++) {
+		byte* s = (byte*) j->src + j->so[i]; byte* d = j->dst + j->dof[i];
+		int r;
+		if (j->sl[i] <= 0) r = 0;
+		else if (j->op == 0) r = j->level < 3 ? LL64::LZ4_compress_fast(s, d, j->sl[i], j->dc[i], 1) : LL64::LZ4_compress_HC(s, d, j->sl[i], j->dc[i], j->level);
+		else r = LL64::LZ4_decompress_safe(s, d, j->sl[i], j->dc[i]);
+		j->out[i] = j->sl[i] <= 0 ? 0 : (r <= 0 ? -1 : r);
+	}
+	return nullptr;
+}
+int run(int op, const uint8_t* src, const uint64_t* so, const int32_t* sl, uint8_t* dst, const uint64_t* dof, const int32_t* dc, int32_t* out, int64_t n, int level, int threads) {
+	if (threads < 1) threads = 1;
+	if (threads > 256) threads = 256;
+	pthread_t tid[256]; Job jobs[256];
+	for (int t = 0; t < threads; t++) {
+		jobs[t] = Job{op, src, so, sl, dst, dof, dc, out, n * t / threads, n * (t + 1) / threads, level};
+		if (threads == 1) worker(&jobs[t]);
+		else if (pthread_create(&tid[t], nullptr, worker, &jobs[t]) != 0) return -1;
+	}
+	if (threads > 1) for (int t = 0; t < threads; t++) pthread_join(tid[t], nullptr);
+	return 0;
+}
+}
+K4REF_API int k4ref_encode_batch(const uint8_t* src, const uint64_t* so, const int32_t* sl, uint8_t* dst, const uint64_t* dof, const int32_t* dc, int32_t* out, int64_t n, int level, int threads) {
+	return run(0, src, so, sl, dst, dof, dc, out, n, level, threads); }
+K4REF_API int k4ref_decode_batch(const uint8_t* src, const uint64_t* so, const int32_t* sl, uint8_t* dst, const uint64_t* dof, const int32_t* dc, int32_t* out, int64_t n, int threads) {
+	return run(1, src, so, sl, dst, dof, dc, out, n, 0, threads); }

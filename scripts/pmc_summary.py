@@ -73,11 +73,51 @@ print("for comparison, FETCH_SIZE / WRITE_SIZE on the same kernels (reported byt
 rd = per_kernel_raw("dramrd", "TCC_EA0_RDREQ_DRAM_32B_sum", "k4::")
 wr = per_kernel_raw("dramwr", "TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", "k4::")
 out = {k: int(32.0 * (rd.get(k, 0.0) + wr.get(k, 0.0))) for k in set(rd) | set(wr)}
+# ---- the issue ports (bench.py's roofline.issue): per kernel, mean per dispatch, from the sq1 / sq2 / grbm passes --------------
+def counters_of(kind, names):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    paths = glob.glob(os.path.join(root, kind, "**", "*counter_collection.csv"), recursive=True) + \
+        glob.glob(os.path.join(root, kind + "_counter_collection.csv"))
+    for path in paths:
+        seen = set()
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                k = row.get("Kernel_Name", "")
+                if not k.startswith("k4::") or row["Counter_Name"] not in names:
+                    continue
+                k = k.split("(")[0].replace("k4::", "")
+                acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                if row["Dispatch_Id"] not in seen:
+                    seen.add(row["Dispatch_Id"])
+                    dur[k].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    return ({k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}, {k: sum(v) / len(v) for k, v in dur.items()})
+
+
+SIMDS = 1024          # 256 CUs x 4
+c1, _ = counters_of("sq1", {"SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"})
+c2, _ = counters_of("sq2", {"SQ_INSTS_SMEM", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA"})
+cg, dg = counters_of("grbm", {"GRBM_GUI_ACTIVE"})
+issue = {}
+for k in c1:
+    if k not in c2 or k not in cg:
+        continue
+    cycles = cg[k]["GRBM_GUI_ACTIVE"] / 8.0                # summed over the 8 XCDs; the kernel alone (rocprofv3 serialises dispatches while it counts)
+    insts = sum(c1[k].get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")) + c2[k].get("SQ_INSTS_SMEM", 0.0)
+    issue[k] = {"insts_total": insts, "insts_valu": c1[k].get("SQ_INSTS_VALU", 0.0), "insts_salu": c1[k].get("SQ_INSTS_SALU", 0.0),
+                "insts_lds": c1[k].get("SQ_INSTS_LDS", 0.0), "insts_vmem": c1[k].get("SQ_INSTS_VMEM_RD", 0.0) + c1[k].get("SQ_INSTS_VMEM_WR", 0.0),
+                "active_valu_quadcycles": c2[k].get("SQ_ACTIVE_INST_VALU", 0.0), "active_scalar_quadcycles": c2[k].get("SQ_ACTIVE_INST_SCA", 0.0),
+                "kernel_cycles_alone": cycles, "kernel_ns_alone": dg.get(k, 0.0),
+                "valu_busy": 4.0 * c2[k].get("SQ_ACTIVE_INST_VALU", 0.0) / SIMDS / cycles if cycles else None,
+                "salu_busy": 4.0 * c2[k].get("SQ_ACTIVE_INST_SCA", 0.0) / SIMDS / cycles if cycles else None}
+if issue:
+    print("issue ports (x4 quad-cycles / 1024 SIMDs / the kernel's own cycles):",
+          {k: (round(v["valu_busy"], 3), round(v["salu_busy"], 3), int(v["insts_total"])) for k, v in issue.items()})
 if out:
     doc = {"source_sha": source_hash(), "counters": "32 B x (TCC_EA0_RDREQ_DRAM_32B_sum + TCC_EA0_WRREQ_WRITE_DRAM_32B_sum), separate passes",
            "calibration_vs_known_bytes": check,
            "read_bytes_per_launch": {k: int(32.0 * v) for k, v in rd.items()}, "write_bytes_per_launch": {k: int(32.0 * v) for k, v in wr.items()},
-           "traffic_bytes_per_launch": out}
+           "traffic_bytes_per_launch": out, "issue": issue}
     print("traffic bytes per launch:", out)
     if len(sys.argv) > 2:
         json.dump(doc, open(sys.argv[2], "w"), indent=1)

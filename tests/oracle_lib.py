@@ -154,6 +154,12 @@ class Oracle:
         n = self.lib.k4o_unpickle(_ptr(a), a.size, _ptr(dst), rl)
         return None if n < 0 else dst[:rl].tobytes()
 
+    def count_sequences(self, src: np.ndarray) -> int:
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        self.lib.k4o_count_sequences.restype = C.c_int64
+        self.lib.k4o_count_sequences.argtypes = [_u8p, C.c_int]
+        return int(self.lib.k4o_count_sequences(_ptr(src if src.size else np.zeros(1, np.uint8)), src.size))
+
     def adler32(self, data) -> int:
         a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data)
         return int(self.lib.k4o_adler32(_ptr(a if a.size else np.zeros(1, np.uint8)), a.size))
@@ -361,6 +367,22 @@ class RefEngine:
         dst = np.full(max(cap, 1), 0xCD, dtype=np.uint8)
         ret = self.lib.k4ref_decompress_safe_partial(_ptr(src), _ptr(dst), src.size, target, cap)
         return ret, dst[:cap]
+
+    def encode_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, level=0, threads=1):
+        out = np.empty(len(src_len), dtype=np.int32)
+        self.lib.k4ref_encode_batch.argtypes = [_u8p, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]
+        rc = self.lib.k4ref_encode_batch(_ptr(src), src_off.ctypes.data, src_len.ctypes.data, _ptr(dst), dst_off.ctypes.data,
+                                         dst_cap.ctypes.data, out.ctypes.data, len(src_len), level, threads)
+        assert rc == 0
+        return out
+
+    def decode_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, threads=1):
+        out = np.empty(len(src_len), dtype=np.int32)
+        self.lib.k4ref_decode_batch.argtypes = [_u8p, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+        rc = self.lib.k4ref_decode_batch(_ptr(src), src_off.ctypes.data, src_len.ctypes.data, _ptr(dst), dst_off.ctypes.data,
+                                         dst_cap.ctypes.data, out.ctypes.data, len(src_len), threads)
+        assert rc == 0
+        return out
 
     def decompress_using_dict(self, src, cap, dictionary):
         src = np.ascontiguousarray(src, dtype=np.uint8)

@@ -463,3 +463,32 @@ def test_pickle_batch_honours_the_per_call_x32_flag(oracle):
         assert env.endswith(w[:r].tobytes()), i
         if m.size >= 65547:
             assert env != oracle.pickle(m)
+
+
+def test_headline_bench_with_two_ranks_is_the_command_the_scaling_run_launches(oracle):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` -- the weak-scaling (headline) path with
+    world > 1: rank r encodes + decodes its own batch (seed 2 + r), barrier + max-over-ranks timing, the size vector
+    all-gathered.  Two processes share GPU 0 (K4LZ4_RANK_DEVICE=0, gloo for the three small exchanges: RCCL refuses two ranks
+    on one device).  n_gpus, bit_exact and the gathered total of compressed bytes = what the oracle gives for seeds 2 and 3."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, K4LZ4_RANK_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    nb = 1024
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29579", os.path.join(root, "bench.py"), "--gpus", "2", "--blocks", str(nb), "--steps", "3", "--warmup", "1",
+           "--no-host-path", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and lines, p.stderr[-2000:]
+    r = json.loads(lines[-1])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["bit_exact"] is True
+    want = 0
+    for seed in (2, 3):
+        blocks = corpus.silesia_like_blocks(nb, 65536, seed=seed)
+        off = np.arange(nb, dtype=np.uint64) * 65536
+        lens = np.full(nb, 65536, np.int32)
+        caps = np.full(nb, LZ4Codec.MaximumOutputSize(65536), np.int32)
+        dst, doff = make_arena(caps)
+        want += int(oracle.encode_batch(blocks.reshape(-1), off, lens, dst, doff, caps, threads=THREADS).astype(np.int64).sum())
+    assert r["config"]["total_compressed_bytes_all_gpus"] == want
+    assert r["value"] > 0 and abs(r["value"] - 2 * nb * 65536 / 2 ** 30 / (r["ms_per_step"] * 1e-3)) < 0.01 * r["value"]
