@@ -20,6 +20,7 @@ namespace K4os.Compression.LZ4.Engine
 
 		[DllImport(Lib)] public static extern int k4lz4_version();
 		[DllImport(Lib)] public static extern int k4lz4_device_count();
+		[DllImport(Lib)] public static extern long k4lz4_recommended_min_batch(int kind, int blockBytes, double hostGiBs);
 		[DllImport(Lib)] public static extern int k4lz4_ctx_create(out IntPtr ctx, int device);
 		[DllImport(Lib)] public static extern void k4lz4_ctx_destroy(IntPtr ctx);
 		[DllImport(Lib)] public static extern IntPtr k4lz4_last_error(IntPtr ctx);

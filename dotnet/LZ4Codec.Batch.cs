@@ -8,6 +8,10 @@ namespace K4os.Compression.LZ4
 {
 	public static partial class LZ4Codec
 	{
+		/// <summary>What this host's threads sustain together on block work (GiB/s), for the batch-size crossover; 0 = the
+		/// library's own figures for the box it was measured on.</summary>
+		public static double HostGiBs { get; set; } = 0;
+
 		/// <summary>Compresses n independent blocks. Block i is source[sourceOffsets[i] .. +sourceLengths[i]) and goes to
 		/// target[targetOffsets[i] .. +targetLengths[i]); encodedLengths[i] is what Encode(...) would return for it.</summary>
 		public static unsafe void EncodeBatch(
@@ -49,6 +53,18 @@ namespace K4os.Compression.LZ4
 			if (blocks is null) throw new ArgumentNullException(nameof(blocks));
 			var n = blocks.Length;
 			var result = new byte[n][];
+			// A device call has a floor (one block's time on its wavefront, about 3 ms for 64 KiB at the fast level): below the
+			// batch size the library recommends for this host, the managed engine is the faster one (INTEGRATION.md, "Crossover").
+			if (n > 0 && n < LLNative.k4lz4_recommended_min_batch(level < LZ4Level.L03_HC ? 0 : 2, Math.Max(1, blocks[0]?.Length ?? 1), HostGiBs))
+			{
+				for (var i = 0; i < n; i++)
+				{
+					var buf = new byte[MaximumOutputSize(blocks[i].Length)];
+					var k = Encode(blocks[i], 0, blocks[i].Length, buf, 0, buf.Length, level);
+					result[i] = k < 0 ? null : buf.AsSpan(0, k).ToArray();
+				}
+				return result;
+			}
 			for (var first = 0; first < n;)
 			{
 				long st = 0, dt = 0;

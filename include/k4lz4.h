@@ -86,6 +86,18 @@ enum k4lz4_flags {
 K4LZ4_API int k4lz4_version(void);
 K4LZ4_API int k4lz4_device_count(void);
 
+/* Below which batch size a caller should stay on the managed engine (LZ4Codec.cs:40-52 -> LLxx -> LL64 on the host).
+ * One wavefront encodes a 64 KiB block in about 3 ms and decodes it in 0.6 ms however small the batch is (the chip is fast
+ * because it runs thousands of blocks side by side, not because a block is fast), so a device call has a floor; a host that
+ * sustains `hostGiBs` on this work beats it below
+ *     floor(kind, blockBytes) * hostGiBs / blockBytes   blocks.
+ * kind: 0 fast-level encode, 1 decode, 2 HC encode (level 3); blockBytes: uncompressed bytes per block;
+ * hostGiBs: what the caller's host threads sustain together on such blocks (the reference's engine, measured on the 256-thread
+ * host of the MI355X box: 0.8 GiB/s encode / 4 GiB/s decode per thread, 32 / 35 GiB/s with all threads); <= 0: those box figures.
+ * For data that starts and ends in host memory use the host-pointer rate (about 22 GiB/s encode, 28-37 decode) as the device's
+ * ceiling as well: a host faster than that never gains.  Returns the number of blocks (>= 1), or a negative error. */
+K4LZ4_API int64_t k4lz4_recommended_min_batch(int kind, int32_t blockBytes, double hostGiBs);
+
 /* device < 0: the calling thread's current HIP device */
 K4LZ4_API int k4lz4_ctx_create(k4lz4_ctx **out, int device);
 K4LZ4_API void k4lz4_ctx_destroy(k4lz4_ctx *ctx);

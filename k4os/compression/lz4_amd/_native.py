@@ -29,6 +29,7 @@ _BATCH = [C.c_void_p, _u8p, C.c_void_p, C.c_void_p, _u8p, C.c_void_p, C.c_void_p
 SYMBOLS = {
     "k4lz4_version": (C.c_int, []),
     "k4lz4_device_count": (C.c_int, []),
+    "k4lz4_recommended_min_batch": (C.c_int64, [C.c_int, C.c_int32, C.c_double]),
     "k4lz4_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "k4lz4_ctx_destroy": (None, [C.c_void_p]),
     "k4lz4_last_error": (C.c_char_p, [C.c_void_p]),

@@ -100,6 +100,15 @@ class LZ4Codec(metaclass=_LZ4CodecMeta):
     Version = 192  # block format of lz4 1.9.2 (LZ4Codec.cs:13)
 
     @staticmethod
+    def RecommendedMinBatch(kind: int = 0, block_bytes: int = 65536, host_GiBs: float = 0.0) -> int:
+        """k4lz4_recommended_min_batch: the batch size below which the managed engine on the host is the faster choice
+        (kind 0 fast encode, 1 decode, 2 HC encode; INTEGRATION.md "Crossover")"""
+        n = _native.load_library().k4lz4_recommended_min_batch(kind, block_bytes, float(host_GiBs))
+        if n < 0:
+            raise ValueError("kind must be 0, 1 or 2 and block_bytes positive")
+        return int(n)
+
+    @staticmethod
     def MaximumOutputSize(length: int) -> int:
         return _native.load_library().k4lz4_compress_bound(int(length))
 

@@ -1055,7 +1055,9 @@ __device__ __forceinline__ void encode_fast_kernel_body(const BatchArgs &a, uint
         SegFirst f = seg_first_of(a, b);
         const int c = cap < 0 ? 0 : (f.cut && (uint32_t)cap > f.cap ? (int)f.cap : cap);
         if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
-            ret = compress_fast_block<true, MORE>(src, src_len, dst, c, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0, a.pace, f.cut ? &f.run : nullptr);
+            /* (always the address of f.run -- neutral fields when the block is not cut -- never a select between it and nullptr:
+             * a pointer that may be null keeps the struct in scratch memory, one that cannot lets it live in registers) */
+            ret = compress_fast_block<true, MORE>(src, src_len, dst, c, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0, a.pace, &f.run);
         seg_first_done(a, b, f, ret, lane);
     } else
     if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
@@ -1108,7 +1110,7 @@ __device__ __forceinline__ void encode_fast_gtab_kernel_body(const BatchArgs &a,
         const int c = cap < 0 ? 0 : (f.cut && (uint32_t)cap > f.cap ? (int)f.cap : cap);
         if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
             ret = compress_fast_block<false, false, false>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], c, a.accel, stage, lane,
-                                             a.gtab + 4096ull * (unsigned long long)slot, (a.flags & FLAG_X32) != 0, a.pace, f.cut ? &f.run : nullptr);
+                                             a.gtab + 4096ull * (unsigned long long)slot, (a.flags & FLAG_X32) != 0, a.pace, &f.run);
         seg_first_done(a, b, f, ret, lane);
     } else
     if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
@@ -1124,7 +1126,7 @@ __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_wav
 }
 /* the two kernels once more for launches in which big blocks are cut into segments (k4lz4_segments.hpp): a cut block's first
  * segment comes their way like any block, with the rule where to stop; kernels of their own so that the others carry none of it */
-__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void k4_encode_fast_gtab_seg_kernel(BatchArgs a)
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(5, 6))) void k4_encode_fast_gtab_seg_kernel(BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t stages[ENCODE_WAVES_PER_WG][ENCODE_STAGE_DWORDS];
     encode_fast_gtab_kernel_body<true>(a, stages);
