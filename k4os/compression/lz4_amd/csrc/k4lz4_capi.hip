@@ -63,6 +63,7 @@ struct k4lz4_ctx {
     bool use_segments = true;                                 /* K4LZ4_NO_SEGMENTS */
     uint32_t seg_min = 1024u << 10, seg_target = 640u << 10, seg_warm = 384u << 10;   /* K4LZ4_SEG_MIN / _TARGET / _WARM (bytes) */
     uint32_t seg_target_max = 1152u << 10;                    /* K4LZ4_SEG_TARGET_MAX; K4LZ4_SEG_TARGET alone fixes the size */
+    uint32_t seg_spin_max = 0;                                /* K4LZ4_SEG_SPIN_MAX: polls a run waits for its successor's cut (0: SEG_SPIN_MAX); tests force the exit with 1 */
     uint32_t seg_div = 3500;                                  /* K4LZ4_SEG_DIV: blocks shorter than the batch's bytes / this stay whole */
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint8_t *d_hc_hash = nullptr; size_t d_hc_hash_cap = 0;   /* HC: per-block hash tables of one launch chunk */
@@ -471,6 +472,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
         k4::SegArgs sg{};
         bool seg = false;
         if (kind == KIND_ENCODE && (flags & (FLAG_SEGMENTS_OK | K4LZ4_FLAG_SEGMENTS)) && ctx->use_segments && !a.prof && !(flags & K4LZ4_FLAG_ALLOW_COPY)) {
+            static_assert(k4::SEG_HDR_DWORDS * 4 == 256, "seg_first_of finds the header in front of the items");
             const size_t o_items = 256, o_work = o_items + (size_t)k4::SEG_MAX_ITEMS * sizeof(k4::SegItem);
             const size_t o_blocks = o_work + (size_t)k4::SEG_MAX_ITEMS * 4, o_snaps = (o_blocks + (size_t)k4::SEG_MAX_BLOCKS * 4 + 255) & ~(size_t)255;
             const size_t o_tables = o_snaps + (size_t)k4::SEG_MAX_ITEMS * k4::SEG_SNAP_DWORDS * 4, total = o_tables + (size_t)k4::SEG_MAX_ITEMS * 16384;
@@ -484,7 +486,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             sg.hdr = (k4::SegHdr *)ctx->d_seg; sg.items = (k4::SegItem *)(ctx->d_seg + o_items); sg.work = (uint32_t *)(ctx->d_seg + o_work);
             sg.blocks = (uint32_t *)(ctx->d_seg + o_blocks); sg.snaps = (uint32_t *)(ctx->d_seg + o_snaps); sg.tables = (uint32_t *)(ctx->d_seg + o_tables);
             sg.first = (int32_t *)ctx->d_seg_first;
-            sg.seg_min = ctx->seg_min; sg.seg_target = ctx->seg_target; sg.seg_warm = ctx->seg_warm; sg.seg_div = ctx->seg_div; sg.seg_target_max = ctx->seg_target_max;
+            sg.seg_min = ctx->seg_min; sg.seg_target = ctx->seg_target; sg.seg_warm = ctx->seg_warm; sg.seg_div = ctx->seg_div; sg.seg_target_max = ctx->seg_target_max; sg.spin_max = ctx->seg_spin_max;
             hipLaunchKernelGGL(k4::k4_seg_plan_kernel, dim3(1), dim3(256), 0, stream, a, sg);
             a.seg_first = sg.first; a.seg_items = sg.items; a.seg_snaps = sg.snaps;
             seg = true;
@@ -1285,6 +1287,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (const char *e = getenv("K4LZ4_SEG_TARGET")) ctx->seg_target = ctx->seg_target_max = (uint32_t)std::max(8192, atoi(e));
     if (const char *e = getenv("K4LZ4_SEG_TARGET_MAX")) ctx->seg_target_max = (uint32_t)std::max(8192, atoi(e));
     if (const char *e = getenv("K4LZ4_SEG_WARM")) ctx->seg_warm = (uint32_t)std::max(0, atoi(e));
+    if (const char *e = getenv("K4LZ4_SEG_SPIN_MAX")) ctx->seg_spin_max = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("K4LZ4_SEG_DIV")) ctx->seg_div = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("K4LZ4_PICKLE_SPLIT_MIN")) ctx->pickle_split_min = std::max(0, atoi(e));
     if (const char *e = getenv("K4LZ4_STAGE_THREADS")) ctx->stage_threads = std::max(0, std::min(63, atoi(e) - 1));

@@ -307,6 +307,7 @@ __device__ __forceinline__ void hop_chain_pairs(unsigned long long &hmx, unsigne
 constexpr uint32_t SEG_NONE = 0xffffffffu;
 constexpr uint32_t SEG_ITEM_WORDS = 10u;          /* a segment's record (k4lz4_segments.hpp, SegItem) as the words the encoder kernels read and write */
 constexpr int SEG_SNAP_DWORDS = 4096 + 16;          /* [0] cut + 1 (0: not there yet, SEG_NONE: this run never found one), [16..] the table */
+constexpr uint32_t SEG_HDR_DWORDS = 64u;            /* k4lz4_capi.hip lays a launch's segment scratch out as header (256 bytes), then the items */
 constexpr uint32_t SEG_SPIN_MAX = 1u << 20;          /* polls (with s_sleep 8 between them: some tenths of a second) before a run stops waiting for the next one's cut */
 struct SegRun {
     uint32_t begin;             /* where the run starts probing: 0, or the start of the warm-up */
@@ -316,6 +317,8 @@ struct SegRun {
     const uint32_t *snap_chk;   /* ... if it is the cut published here, with an equal table; or nullptr */
     const uint32_t *resume;     /* nullptr, or the table published at position `begin`, a verified cut: the run goes on from there as the
                                  * true run would (cursor right behind a match), writing from its first sequence */
+    uint32_t spin_max;          /* polls before a run stops waiting for the next one's cut (0: SEG_SPIN_MAX; K4LZ4_SEG_SPIN_MAX, the tests' way
+                                 * to force that exit) */
     uint32_t cut, stop, state;  /* results: first position of the output (the cut; 0), one past its last (verified cut, or U),
                                  * 1 stopped at a verified cut, 2 ran to the end of the block, 3 no use (not in step, no cut, no room) */
 };
@@ -846,7 +849,8 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 } else {
                     /* the true run has reached a match end behind the next segment's boundary: is that segment's run in step here? */
                     uint32_t theirs = 0u;
-                    for (uint32_t spin = 0; spin < SEG_SPIN_MAX; spin++) {
+                    const uint32_t spin_max = uni(sr->spin_max) ? uni(sr->spin_max) : SEG_SPIN_MAX;
+                    for (uint32_t spin = 0; spin < spin_max; spin++) {
                         theirs = uni(agent_peek(sr->snap_chk));
                         if (theirs != 0u) break;
                         __builtin_amdgcn_s_sleep(8);
@@ -1018,12 +1022,13 @@ __device__ __forceinline__ SegFirst seg_first_of(const BatchArgs &a, long long b
     SegFirst f;
     f.cut = false; f.cap = 0u;
     f.run.begin = 0u; f.run.emit_from = 0u; f.run.stop_at = SEG_NONE; f.run.snap_pub = nullptr; f.run.snap_chk = nullptr; f.run.resume = nullptr;
-    f.run.cut = 0u; f.run.stop = 0u; f.run.state = 3u;
+    f.run.cut = 0u; f.run.stop = 0u; f.run.state = 3u; f.run.spin_max = 0u;
     if (!a.seg_first) return f;
     const int32_t it = (int32_t)uni((uint32_t)a.seg_first[b]);
     if (it < 0) return f;
     const uint32_t *w = (const uint32_t *)a.seg_items + SEG_ITEM_WORDS * (uint32_t)it;     /* block, k, nseg, start, next_start, warm_from, cut, stop, state, bytes */
     f.cut = true;
+    f.run.spin_max = uni(((const uint32_t *)a.seg_items)[-(int)SEG_HDR_DWORDS + 3]);      /* SegHdr::spin_max: the header sits SEG_HDR_DWORDS in front of the items */
     f.run.stop_at = uni(w[4]);
     f.cap = f.run.stop_at;                                          /* its piece may not reach into the next segment's */
     f.run.snap_chk = a.seg_snaps + (size_t)(it + 1) * SEG_SNAP_DWORDS;

@@ -38,7 +38,7 @@ struct SegItem {
 static_assert(sizeof(SegItem) == 4u * SEG_ITEM_WORDS, "seg_first_of / seg_first_done address SegItem's fields as words 4 (next_start) and 6..9 (results)");
 
 struct SegHdr {
-    uint32_t n_items, n_work, n_blocks, pad;
+    uint32_t n_items, n_work, n_blocks, spin_max;    /* spin_max: SegRun::spin_max for every run of the launch (word 3: seg_first_of reads it as such) */
 };
 
 struct SegArgs {
@@ -51,6 +51,7 @@ struct SegArgs {
     uint32_t *tables;            /* SEG_MAX_ITEMS x 4096: the hash tables of k4_encode_seg_kernel's waves */
     uint32_t seg_min, seg_target, seg_warm;
     uint32_t seg_target_max;     /* the segment size grows with the batch up to this (0 or <= seg_target: fixed size), see k4_seg_plan_kernel */
+    uint32_t spin_max;           /* SegRun::spin_max (0: the default) */
     uint32_t seg_div;            /* a block is cut only if it is longer than the batch's bytes / seg_div: a wave encodes ~25 MB/s, the whole chip
                                   * ~2 500 times that, so shorter blocks are over before the batch is and cutting them only adds their warm-ups */
 };
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void k4_seg_plan_kernel(BatchArgs a, SegArgs g
     uint32_t ni = 0, nb = 0;
     for (long long b = lo; b < hi; b++) { const uint32_t k = segments_of(b); ni += k; nb += k ? 1u : 0u; }
     items_of[t] = ni; blocks_of[t] = nb;
-    if (t == 0) { g.hdr->n_items = 0u; g.hdr->n_work = 0u; g.hdr->n_blocks = 0u; }
+    if (t == 0) { g.hdr->n_items = 0u; g.hdr->n_work = 0u; g.hdr->n_blocks = 0u; g.hdr->spin_max = g.spin_max; }
     __syncthreads();
     uint32_t base = 0, bi = 0;
     for (int k = 0; k < t; k++) { base += items_of[k]; bi += blocks_of[k]; }
@@ -139,6 +140,7 @@ __device__ __forceinline__ SegRun seg_run_of(const SegArgs &g, uint32_t it, cons
     r.snap_pub = s.k ? g.snaps + (size_t)it * SEG_SNAP_DWORDS : nullptr;
     r.snap_chk = s.next_start != SEG_NONE ? g.snaps + (size_t)(it + 1u) * SEG_SNAP_DWORDS : nullptr;
     r.resume = nullptr;
+    r.spin_max = g.spin_max;
     r.cut = 0u; r.stop = 0u; r.state = 3u;
     return r;
 }
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(64) void k4_seg_join_kernel(BatchArgs a, SegArgs g)
         SegRun r;
         r.begin = at; r.emit_from = 0u; r.stop_at = SEG_NONE; r.snap_pub = nullptr; r.snap_chk = nullptr;
         r.resume = g.snaps + (size_t)((uint32_t)base + good) * SEG_SNAP_DWORDS + 16u;
+        r.spin_max = g.spin_max;
         r.cut = 0u; r.stop = 0u; r.state = 3u;
         const int more = compress_fast_block<true, false>(src, U, dst + out, cap - (int)out, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0, nullptr, &r);
         ret = more > 0 ? (int)out + more : 0;

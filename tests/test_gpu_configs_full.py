@@ -95,8 +95,12 @@ def test_big_messages_in_segments_every_envelope_vs_oracle(oracle, monkeypatch):
     data = np.concatenate(msgs)
     want = [oracle.pickle(m) for m in msgs]
     for env_vars in ({}, {"K4LZ4_SEG_MIN": "70000", "K4LZ4_SEG_TARGET": "49152", "K4LZ4_SEG_WARM": "24576", "K4LZ4_SEG_DIV": "0"},
-                     {"K4LZ4_SEG_MIN": "300000", "K4LZ4_SEG_TARGET": "200000", "K4LZ4_SEG_WARM": "400000", "K4LZ4_SEG_DIV": "0"}):
-        for k in ("K4LZ4_SEG_MIN", "K4LZ4_SEG_TARGET", "K4LZ4_SEG_WARM", "K4LZ4_SEG_DIV"):
+                     {"K4LZ4_SEG_MIN": "300000", "K4LZ4_SEG_TARGET": "200000", "K4LZ4_SEG_WARM": "400000", "K4LZ4_SEG_DIV": "0"},
+                     # a run that waits for its successor's cut gives up after ONE poll (SEG_SPIN_MAX is 2^20): nearly every
+                     # boundary then fails to verify in time and the join kernel encodes those blocks again -- the timeout exit
+                     {"K4LZ4_SEG_SPIN_MAX": "1"},
+                     {"K4LZ4_SEG_SPIN_MAX": "1", "K4LZ4_SEG_MIN": "70000", "K4LZ4_SEG_TARGET": "49152", "K4LZ4_SEG_WARM": "24576", "K4LZ4_SEG_DIV": "0"}):
+        for k in ("K4LZ4_SEG_MIN", "K4LZ4_SEG_TARGET", "K4LZ4_SEG_WARM", "K4LZ4_SEG_DIV", "K4LZ4_SEG_SPIN_MAX"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env_vars.items():
             monkeypatch.setenv(k, v)
