@@ -24,6 +24,11 @@
 
 namespace k4 {
 
+/* The *_seg twins of the global-table kernels (and k4_encode_seg_kernel) may take the registers of five waves per SIMD instead of
+ * six: at 80 VGPRs they spilled to scratch memory inside the block loop (12-80 bytes per lane), at 85 / 82 they do not. */
+#ifndef K4_SEG_WAVES_MIN
+#define K4_SEG_WAVES_MIN 5
+#endif
 #ifndef K4_GTAB_DUTY
 #define K4_GTAB_DUTY 3
 #endif
@@ -1131,7 +1136,7 @@ __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_wav
 }
 /* the two kernels once more for launches in which big blocks are cut into segments (k4lz4_segments.hpp): a cut block's first
  * segment comes their way like any block, with the rule where to stop; kernels of their own so that the others carry none of it */
-__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(5, 6))) void k4_encode_fast_gtab_seg_kernel(BatchArgs a)
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(K4_SEG_WAVES_MIN, 6))) void k4_encode_fast_gtab_seg_kernel(BatchArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t stages[ENCODE_WAVES_PER_WG][ENCODE_STAGE_DWORDS];
     encode_fast_gtab_kernel_body<true>(a, stages);

@@ -146,7 +146,7 @@ __device__ __forceinline__ SegRun seg_run_of(const SegArgs &g, uint32_t it, cons
 }
 
 /* the segments behind the first: a wave each, table in memory */
-__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(5, 6))) void k4_encode_seg_kernel(BatchArgs a, SegArgs g)
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_waves_per_eu(K4_SEG_WAVES_MIN, 6))) void k4_encode_seg_kernel(BatchArgs a, SegArgs g)
 {
     __shared__ __attribute__((aligned(16))) uint32_t stages[ENCODE_WAVES_PER_WG][ENCODE_STAGE_DWORDS];
     const int lane = lane_id();
