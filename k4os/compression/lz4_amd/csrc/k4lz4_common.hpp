@@ -90,6 +90,14 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+/* scripts/isa_phase_table.py builds with -DK4_PHASE_MARKS and counts the instructions between these comments in the ISA listing
+ * (a marker is an empty volatile asm that clobbers memory: it pins the phases' order in THAT build only; normal builds have none) */
+#ifdef K4_PHASE_MARKS
+#define K4_PHASE(name) asm volatile("; k4phase " name ::: "memory")
+#else
+#define K4_PHASE(name) ((void)0)
+#endif
+
 constexpr int PROF_STRIDE = 16;
 
 /* Call-level trouble that is not a property of any block's data: bit 0 = a wave of a decoder pair gave up waiting for

@@ -312,6 +312,7 @@ __device__ __forceinline__ void hop_chain_pairs(unsigned long long &hmx, unsigne
 constexpr uint32_t SEG_NONE = 0xffffffffu;
 constexpr uint32_t SEG_ITEM_WORDS = 10u;          /* a segment's record (k4lz4_segments.hpp, SegItem) as the words the encoder kernels read and write */
 constexpr int SEG_SNAP_DWORDS = 4096 + 16;          /* [0] cut + 1 (0: not there yet, SEG_NONE: this run never found one), [16..] the table */
+constexpr uint32_t SEG_ITEMS_MAX = 8192u;           /* = SEG_MAX_ITEMS (k4lz4_segments.hpp): segments of all cut blocks of a launch */
 constexpr uint32_t SEG_HDR_DWORDS = 64u;            /* k4lz4_capi.hip lays a launch's segment scratch out as header (256 bytes), then the items */
 constexpr uint32_t SEG_SPIN_MAX = 1u << 20;          /* polls (with s_sleep 8 between them: some tenths of a second) before a run stops waiting for the next one's cut */
 struct SegRun {
@@ -322,10 +323,14 @@ struct SegRun {
     const uint32_t *snap_chk;   /* ... if it is the cut published here, with an equal table; or nullptr */
     const uint32_t *resume;     /* nullptr, or the table published at position `begin`, a verified cut: the run goes on from there as the
                                  * true run would (cursor right behind a match), writing from its first sequence */
+    uint32_t *fix;              /* where a run that stops at a cut the next run is NOT in step with (state 4) leaves its table, for a run that goes
+                                 * on from there: the item's slot of SegArgs::tables (for a later segment's wave that IS its table: nothing to copy) */
     uint32_t spin_max;          /* polls before a run stops waiting for the next one's cut (0: SEG_SPIN_MAX; K4LZ4_SEG_SPIN_MAX, the tests' way
                                  * to force that exit) */
     uint32_t cut, stop, state;  /* results: first position of the output (the cut; 0), one past its last (verified cut, or U),
-                                 * 1 stopped at a verified cut, 2 ran to the end of the block, 3 no use (not in step, no cut, no room) */
+                                 * 1 stopped at a verified cut, 2 ran to the end of the block, 3 no use (no cut, no room, gave up waiting),
+                                 * 4 stopped at a cut the next run is NOT in step with: the output stands if this run began in step, and its
+                                 * table now lies in the next run's snapshot for a run that goes on from `stop` */
 };
 
 /*
@@ -545,6 +550,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
 
         for (;;) {
             /* ---------------- load: positions, hashes, candidates ---------------- */
+            K4_PHASE("load");
             const unsigned long long t0 = prof_now<PROF>();
             const bool fresh = jbase == 0u;
             if (fresh) sbase = test ? ip + 1u : ip;
@@ -601,6 +607,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             }
 
             /* ---------------- groups: lanes of the window with equal hashes ---------------- */
+            K4_PHASE("groups");
             unsigned long long G = me;
             {
                 unsigned long long fl = ballot(flagged);
@@ -617,6 +624,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             const unsigned long long dirty = ballot(G != me);
 
             /* ---------------- resolve: every sequence that starts in the window ---------------- */
+            K4_PHASE("resolve");
             const unsigned long long t1 = prof_now<PROF>();
             const unsigned long long inv_m = ballot(!valid), preok_m = ballot(pa.pre_ok);
             /* the common group is a pair: the later lane's candidate is the earlier lane while that one counts
@@ -698,6 +706,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             const uint32_t hop_tab = many ? 0x1040u : (dirty ? hop_word(info & EXT_FWD_MASK, info & 0x100u) : hopv);
             const unsigned long long hmB = dirty ? (ballot(hit_tab || many) | inv_m) : hmx;
             const uint32_t j1c = 63u - (uint32_t)(j1 >= 0 ? j1 : lane);
+            K4_PHASE("hops");
             const unsigned long long ta = prof_now<PROF>();
             if (PROF) c_s1 += ta - t1;
             unsigned long long t_rec = 0;
@@ -774,6 +783,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 q = e_end - ip0;
                 lose((~1ull << f) & ((1ull << q) - 1ull) & ~(1ull << (q - 2u)));
             }
+            K4_PHASE("derive");
             if (PAIRS && !general && (long long)(lost_cands << j1c) < 0) {   /* the lanes the chain switched to their table candidates, for what follows */
                 chit = hit_tab;
                 cpos = cand;
@@ -790,6 +800,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
             if (PROF) n_seq += k;
 
             /* ---------------- where the next round starts; its source loads go out now ---------------- */
+            K4_PHASE("next");
             if (outcome == 1 || outcome == 3) {
                 ip = anchor;
                 test = true;
@@ -811,6 +822,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 Pace::update(pace_words, pace_mine, ip - sr_begin, (sr_stop_at != SEG_NONE && sr_stop_at < U ? sr_stop_at : U) - sr_begin, lane);
 
             /* the k sequences of this round join the pending ones */
+            K4_PHASE("records");
             const bool mine = ((hits >> lane) & 1ull) != 0ull;
             if (k && !dry) {
                 if (mine) {
@@ -822,6 +834,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 rec_count += k;
             }
             /* ---------------- commit the visited positions, one writer per hash ---------------- */
+            K4_PHASE("commit");
             const unsigned long long t2 = prof_now<PROF>();
             if (PROF) c_s4 += t2 - tb;
             if (outcome != 2) {
@@ -831,7 +844,9 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                                                  * LDS accesses execute in program order; this keeps the compiler to it) */
 
             /* ---------------- write sequences out once a wave-full of them is pending (:244-382) ---------------- */
+            K4_PHASE("flush");
             if (rec_count >= REC_FLUSH_AT && !flush()) return 0;
+            K4_PHASE("round-end");
             if (PROF) { const unsigned long long t3 = prof_now<PROF>(); c_probe += t1 - t0; c_ext += t2 - t1; c_emit += t3 - t2; }
 
             if (outcome == 3) {
@@ -870,7 +885,21 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                         }
                         same = ballot(differ) == 0ull;
                     }
-                    if (!same) return 0;            /* state stays 3: the block is encoded again the plain way */
+                    if (!same) {
+                        /* The next segment's run is not in step here.  If THIS run began in step (the join finds that out), what it
+                         * has written up to `cut` is the block's encoding up to there and its table is the block's table there:
+                         * it keeps its output and leaves the table in its item's slot (`fix`; the other run's snapshot stays as it
+                         * is -- it says what THAT run began with, which whoever arrives at this cut later must still be able to
+                         * check) for a run that goes on from this cut (k4_seg_join_kernel).  A run that gave up waiting has
+                         * nothing to offer: the block is then encoded again the plain way. */
+                        if (theirs == 0u || !sr->fix) return 0;
+                        while (rec_count) if (!flush()) return 0;
+                        if (sr->fix != tabmem) { for (int k = lane; k < 4096; k += 64) sr->fix[k] = tabmem[k]; }
+                        wave_sync();
+                        sr->stop = cut;
+                        sr->state = 4u;
+                        return (int)op;
+                    }
                     while (rec_count) if (!flush()) return 0;
                     sr->stop = cut;
                     sr->state = 1u;
@@ -1027,7 +1056,7 @@ __device__ __forceinline__ SegFirst seg_first_of(const BatchArgs &a, long long b
     SegFirst f;
     f.cut = false; f.cap = 0u;
     f.run.begin = 0u; f.run.emit_from = 0u; f.run.stop_at = SEG_NONE; f.run.snap_pub = nullptr; f.run.snap_chk = nullptr; f.run.resume = nullptr;
-    f.run.cut = 0u; f.run.stop = 0u; f.run.state = 3u; f.run.spin_max = 0u;
+    f.run.cut = 0u; f.run.stop = 0u; f.run.state = 3u; f.run.spin_max = 0u; f.run.fix = nullptr;
     if (!a.seg_first) return f;
     const int32_t it = (int32_t)uni((uint32_t)a.seg_first[b]);
     if (it < 0) return f;
@@ -1037,6 +1066,7 @@ __device__ __forceinline__ SegFirst seg_first_of(const BatchArgs &a, long long b
     f.run.stop_at = uni(w[4]);
     f.cap = f.run.stop_at;                                          /* its piece may not reach into the next segment's */
     f.run.snap_chk = a.seg_snaps + (size_t)(it + 1) * SEG_SNAP_DWORDS;
+    f.run.fix = a.seg_snaps + (size_t)SEG_ITEMS_MAX * SEG_SNAP_DWORDS + 4096ull * (unsigned long long)it;    /* SegArgs::tables lies right behind the snapshots */
     return f;
 }
 __device__ __forceinline__ void seg_first_done(const BatchArgs &a, long long b, const SegFirst &f, int ret, int lane)

@@ -24,7 +24,7 @@
 
 namespace k4 {
 
-constexpr int SEG_MAX_ITEMS = 8192;          /* segments of all cut blocks of a launch */
+constexpr int SEG_MAX_ITEMS = (int)SEG_ITEMS_MAX;   /* segments of all cut blocks of a launch */
 constexpr int SEG_MAX_BLOCKS = 4096;         /* cut blocks of a launch */
 
 struct SegItem {
@@ -39,6 +39,7 @@ static_assert(sizeof(SegItem) == 4u * SEG_ITEM_WORDS, "seg_first_of / seg_first_
 
 struct SegHdr {
     uint32_t n_items, n_work, n_blocks, spin_max;    /* spin_max: SegRun::spin_max for every run of the launch (word 3: seg_first_of reads it as such) */
+    uint32_t n_resumed, n_resume_stops, n_plain;     /* k4_seg_join_kernel's runs: begun from a cut; of those, stopped at a verified boundary; whole blocks again */
 };
 
 struct SegArgs {
@@ -48,7 +49,9 @@ struct SegArgs {
     uint32_t *blocks;            /* SEG_MAX_BLOCKS: the cut blocks */
     int32_t *first;              /* per block of the batch: its segment 0's item, or -1 */
     uint32_t *snaps;             /* SEG_MAX_ITEMS x SEG_SNAP_DWORDS */
-    uint32_t *tables;            /* SEG_MAX_ITEMS x 4096: the hash tables of k4_encode_seg_kernel's waves */
+    uint32_t *tables;            /* SEG_MAX_ITEMS x 4096, one slot per ITEM, right behind `snaps` (seg_first_of counts on that): the hash table of the
+                                  * wave that runs a later segment -- what it holds when the run ends is the table at the run's stop --, and for
+                                  * a first segment the place where its run leaves its table when the next segment is not in step (SegRun::fix) */
     uint32_t seg_min, seg_target, seg_warm;
     uint32_t seg_target_max;     /* the segment size grows with the batch up to this (0 or <= seg_target: fixed size), see k4_seg_plan_kernel */
     uint32_t spin_max;           /* SegRun::spin_max (0: the default) */
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void k4_seg_plan_kernel(BatchArgs a, SegArgs g
     uint32_t ni = 0, nb = 0;
     for (long long b = lo; b < hi; b++) { const uint32_t k = segments_of(b); ni += k; nb += k ? 1u : 0u; }
     items_of[t] = ni; blocks_of[t] = nb;
-    if (t == 0) { g.hdr->n_items = 0u; g.hdr->n_work = 0u; g.hdr->n_blocks = 0u; g.hdr->spin_max = g.spin_max; }
+    if (t == 0) { g.hdr->n_items = 0u; g.hdr->n_work = 0u; g.hdr->n_blocks = 0u; g.hdr->spin_max = g.spin_max; g.hdr->n_resumed = 0u; g.hdr->n_resume_stops = 0u; g.hdr->n_plain = 0u; }
     __syncthreads();
     uint32_t base = 0, bi = 0;
     for (int k = 0; k < t; k++) { base += items_of[k]; bi += blocks_of[k]; }
@@ -140,6 +143,7 @@ __device__ __forceinline__ SegRun seg_run_of(const SegArgs &g, uint32_t it, cons
     r.snap_pub = s.k ? g.snaps + (size_t)it * SEG_SNAP_DWORDS : nullptr;
     r.snap_chk = s.next_start != SEG_NONE ? g.snaps + (size_t)(it + 1u) * SEG_SNAP_DWORDS : nullptr;
     r.resume = nullptr;
+    r.fix = g.tables + 4096ull * (unsigned long long)it;
     r.spin_max = g.spin_max;
     r.cut = 0u; r.stop = 0u; r.state = 3u;
     return r;
@@ -164,9 +168,12 @@ __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_wav
     const uint32_t slot_cap = a.dstCap[b] < 0 ? 0u : (uint32_t)a.dstCap[b];
     uint32_t end = s.next_start != SEG_NONE ? s.next_start : (uint32_t)U;
     if (end > slot_cap) end = slot_cap;
-    const int ret = end <= s.start ? 0 :
-                    compress_fast_block<false, false, false>(a.src + a.srcOff[b], U, a.dst + a.dstOff[b] + s.start, (int)(end - s.start), a.accel, stages[wave], lane,
-                                                             g.tables + 4096ull * (unsigned long long)w, (a.flags & FLAG_X32) != 0, a.pace, &r);
+    if (end <= s.start) {            /* no room for this piece: say so to the run before it, which waits for this one's cut */
+        if (lane == 0) { agent_publish(r.snap_pub, SEG_NONE); g.items[it].cut = 0u; g.items[it].stop = 0u; g.items[it].state = 3u; g.items[it].bytes = 0; }
+        return;
+    }
+    const int ret = compress_fast_block<false, false, false>(a.src + a.srcOff[b], U, a.dst + a.dstOff[b] + s.start, (int)(end - s.start), a.accel, stages[wave], lane,
+                                                             g.tables + 4096ull * (unsigned long long)it, (a.flags & FLAG_X32) != 0, a.pace, &r);
     if (lane == 0) {
         g.items[it].cut = r.cut; g.items[it].stop = r.stop; g.items[it].state = ret > 0 ? r.state : 3u; g.items[it].bytes = ret;
     }
@@ -187,42 +194,66 @@ __global__ __launch_bounds__(64) void k4_seg_join_kernel(BatchArgs a, SegArgs g)
     const uint8_t *src = a.src + a.srcOff[b];
     uint8_t *dst = a.dst + a.dstOff[b];
     const uint32_t nseg = uni(g.items[base].nseg);
-    /* every segment must begin where the one before it stopped, and the last must have run to the end: `good` pieces do */
-    uint32_t good = 0, at = 0u;
-    long long total = 0;
-    bool whole = false;
-    for (uint32_t k = 0; k < nseg; k++) {
-        const SegItem s = g.items[(uint32_t)base + k];
-        if (!(s.bytes > 0 && s.cut == at && (s.state == 1u || s.state == 2u) && total + s.bytes <= (long long)cap)) break;
-        good = k + 1u; at = s.stop; total += s.bytes;
-        if (s.state == 2u) { whole = true; break; }
+    /* Piece by piece.  A piece stands if it begins where the encoding so far ends (`at`) and stopped at a cut (state 1: the next
+     * piece is in step there; state 4: it is not, and this piece left the table of the cut in the next piece's snapshot) or at the
+     * end of the block (state 2).  Where a piece does not stand, or the boundary behind it did not verify, ONE wave goes on from
+     * the last cut with the table that lies there -- and stops at the next boundary whose piece IS in step (the same check the
+     * pieces' own runs make), so that the pieces behind a bad boundary are not encoded again when they are good. */
+    uint32_t out = 0, at = 0u, k = 0;
+    bool whole = false, failed = false, resume = false;
+    const uint32_t *resume_tab = nullptr;          /* the table at `at` for a run that goes on from there */
+    while (k < nseg && !whole && !failed) {
+        if (!resume) {
+            const SegItem s = g.items[(uint32_t)base + k];
+            const uint32_t st = uni(s.state), nb = uni((uint32_t)(s.bytes > 0 ? s.bytes : 0));
+            const bool stands = nb != 0u && uni(s.cut) == at && (st == 1u || st == 2u || st == 4u) && (long long)out + nb <= (long long)cap &&
+                                (k != 0u || out == 0u);
+            if (stands) {
+                const uint32_t start = uni(s.start);
+                wave_sync();
+                if (k != 0u && out != start) wave_shift_down(dst + out, dst + start, nb, lane);     /* it lies at or behind where it belongs */
+                out += nb;
+                at = uni(s.stop);
+                if (st == 2u) { whole = true; break; }
+                resume = st == 4u;            /* the next piece is not in step: the table at `at` is in this piece's slot */
+                resume_tab = g.tables + 4096ull * (unsigned long long)((uint32_t)base + k);
+                k++;
+                continue;
+            }
+            if (k == 0u) { failed = true; break; }        /* nothing stands: the plain way */
+            resume = true;                                /* the run before verified piece k's published table at `at`: go on from it */
+            resume_tab = g.snaps + (size_t)((uint32_t)base + k) * SEG_SNAP_DWORDS + 16u;
+        }
+        /* one wave from `at` through piece k's range, behind the pieces that stand */
+        wave_sync();
+        const bool has_next = k + 1u < nseg;
+        const uint32_t room_end = has_next ? uni(g.items[(uint32_t)base + k + 1u].start) : (uint32_t)(cap < 0 ? 0 : cap);   /* not into the next piece's place */
+        SegRun r;
+        r.begin = at; r.emit_from = 0u; r.snap_pub = nullptr;
+        r.stop_at = has_next ? uni(g.items[(uint32_t)base + k].next_start) : SEG_NONE;
+        r.snap_chk = has_next ? g.snaps + (size_t)((uint32_t)base + k + 1u) * SEG_SNAP_DWORDS : nullptr;
+        r.resume = resume_tab;
+        r.fix = g.tables + 4096ull * (unsigned long long)((uint32_t)base + k);      /* piece k does not stand: its slot is free */
+        r.spin_max = 1u;                 /* every piece's run is over by now: what it published is there, what is not never comes */
+        r.cut = 0u; r.stop = 0u; r.state = 3u;
+        int more = 0;
+        if (room_end > out && (long long)room_end <= (long long)cap)
+            more = compress_fast_block<true, false>(src, U, dst + out, (int)(room_end - out), a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0, nullptr, &r);
+        if (lane == 0) { atomicAdd(&g.hdr->n_resumed, 1u); if (more > 0 && r.state == 1u) atomicAdd(&g.hdr->n_resume_stops, 1u); }
+        if (more <= 0 || r.state == 3u) { failed = true; break; }
+        out += (uint32_t)more;
+        at = r.stop;
+        if (r.state == 2u) { whole = true; break; }
+        resume = r.state == 4u;
+        resume_tab = r.fix;
+        k++;
     }
     int ret;
-    uint32_t out = 0;
-    if (good) {
-        out = (uint32_t)uni((uint32_t)g.items[base].bytes);
-        for (uint32_t k = 1; k < good; k++) {                /* a piece lies at or behind where it belongs: forward copies */
-            const uint32_t start = uni(g.items[(uint32_t)base + k].start), nb = uni((uint32_t)g.items[(uint32_t)base + k].bytes);
-            wave_sync();
-            if (out != start) wave_shift_down(dst + out, dst + start, nb, lane);
-            out += nb;
-        }
-    }
-    if (whole) {
+    if (whole && !failed) {
         ret = (int)out;
-    } else if (good && good < nseg) {
-        /* a boundary did not verify (or a piece gave up): `at` is the last verified cut and segment `good` published the table there --
-         * one wave goes on from that state to the end of the block, behind the pieces that stand */
-        wave_sync();
-        SegRun r;
-        r.begin = at; r.emit_from = 0u; r.stop_at = SEG_NONE; r.snap_pub = nullptr; r.snap_chk = nullptr;
-        r.resume = g.snaps + (size_t)((uint32_t)base + good) * SEG_SNAP_DWORDS + 16u;
-        r.spin_max = g.spin_max;
-        r.cut = 0u; r.stop = 0u; r.state = 3u;
-        const int more = compress_fast_block<true, false>(src, U, dst + out, cap - (int)out, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0, nullptr, &r);
-        ret = more > 0 ? (int)out + more : 0;
     } else {
         wave_sync();
+        if (lane == 0) atomicAdd(&g.hdr->n_plain, 1u);
         ret = compress_fast_block<true, false>(src, U, dst, cap < 0 ? 0 : cap, a.accel, tab, lane, nullptr, (a.flags & FLAG_X32) != 0);
     }
     if (lane == 0) a.outLen[b] = codec_encode_result(U, ret, a.flags);

@@ -166,37 +166,43 @@ int k4emu_pickle_seg_batch(const uint8_t *src, const uint64_t *srcOff, const int
     k4emu::launch_fn(dim3((unsigned)((n + 255) / 256)), dim3(256), [=] { k4::k4_pickle_prep_kernel(a, eo, ec); }, 1);
     k4::BatchArgs e = a;
     e.dstOff = encOff.data(); e.dstCap = encCap.data(); e.outLen = encLen.data(); e.flags = (flags & k4::FLAG_X32) | k4::FLAG_RAW_RETURN;
-    k4::SegHdr hdr{};
-    std::vector<k4::SegItem> items((size_t)k4::SEG_MAX_ITEMS);
+    /* header and items in one piece of memory, the header SEG_HDR_DWORDS in front of the items, as k4lz4_capi.hip lays them out
+     * (seg_first_of finds SegHdr::spin_max there) */
+    std::vector<uint32_t> segmem((size_t)k4::SEG_HDR_DWORDS + (size_t)k4::SEG_MAX_ITEMS * k4::SEG_ITEM_WORDS, 0u);
+    k4::SegHdr &hdr = *(k4::SegHdr *)segmem.data();
+    k4::SegItem *items = (k4::SegItem *)(segmem.data() + k4::SEG_HDR_DWORDS);
     std::vector<uint32_t> work((size_t)k4::SEG_MAX_ITEMS), blocks((size_t)k4::SEG_MAX_BLOCKS);
     k4::SegArgs g{};
-    g.hdr = &hdr; g.items = items.data(); g.work = work.data(); g.blocks = blocks.data(); g.first = first.data();
+    g.hdr = &hdr; g.items = items; g.work = work.data(); g.blocks = blocks.data(); g.first = first.data();
     g.seg_min = seg_min; g.seg_target = seg_target; g.seg_warm = seg_warm; g.seg_div = 0u;
-    std::vector<uint32_t> snaps(64), tables(64);
-    /* the plan first with room for the flags only, then the real arrays sized by what it planned */
-    snaps.assign((size_t)k4::SEG_MAX_ITEMS * k4::SEG_SNAP_DWORDS, 0u);
+    /* snapshots and, right behind them, one table slot per item (seg_first_of counts on that layout) */
+    std::vector<uint32_t> snaps;
+    snaps.assign((size_t)k4::SEG_MAX_ITEMS * k4::SEG_SNAP_DWORDS + 64, 0u);       /* the plan only touches the flags */
     g.snaps = snaps.data();
     k4emu::launch_fn(dim3(1), dim3(256), [=] { k4::k4_seg_plan_kernel(e, g); }, 1);
-    tables.assign((size_t)(hdr.n_work + 2u) * 4096u, 0u);
-    g.tables = tables.data();
+    snaps.resize((size_t)k4::SEG_MAX_ITEMS * k4::SEG_SNAP_DWORDS + (size_t)(hdr.n_items + 2u) * 4096u, 0u);
+    g.snaps = snaps.data();
+    g.tables = snaps.data() + (size_t)k4::SEG_MAX_ITEMS * k4::SEG_SNAP_DWORDS;
     e.seg_first = g.first; e.seg_items = g.items; e.seg_snaps = g.snaps;
     if (hdr.n_work)
         k4emu::launch_fn(dim3((hdr.n_work + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG), dim3(64 * k4::ENCODE_WAVES_PER_WG), [=] { k4::k4_encode_seg_kernel(e, g); }, 1);
     k4emu::launch_fn(dim3((unsigned)((n + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG), [=] { k4::k4_encode_fast_seg_kernel(e); }, threads);
     if (stats) {
-        stats[0] = hdr.n_blocks; stats[1] = hdr.n_items; stats[2] = 0;
+        stats[0] = hdr.n_blocks; stats[1] = hdr.n_items; stats[2] = 0; stats[3] = 0;
+        for (uint32_t i = 0; i < hdr.n_items; i++) stats[3] += items[i].state == 4u && items[i].bytes > 0 ? 1u : 0u;    /* pieces that kept their output behind a boundary that did not verify */
         for (uint32_t i = 0; i < hdr.n_blocks; i++) {
             const int32_t base = first[blocks[i]];
             bool ok = true; uint32_t at = 0;
             for (uint32_t k = 0; k < items[base].nseg && ok; k++) {
                 const k4::SegItem &s = items[base + k];
-                ok = s.bytes > 0 && s.cut == at && (k + 1 < s.nseg ? s.state == 1u : s.state == 2u);
+                ok = s.bytes > 0 && s.cut == at && (k + 1 < s.nseg ? s.state == 1u : s.state == 2u);      /* (state 4 pieces stand too, but the block is then not "joined as planned") */
                 at = s.stop;
             }
             stats[2] += ok ? 1u : 0u;
         }
     }
     if (hdr.n_blocks) k4emu::launch_fn(dim3(hdr.n_blocks), dim3(64), [=] { k4::k4_seg_join_kernel(e, g); }, threads);
+    if (stats) { stats[4] = hdr.n_resumed; stats[5] = hdr.n_resume_stops; stats[6] = hdr.n_plain; }
     const int32_t *el = encLen.data();
     k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_pickle_finish_kernel(a, el); }, threads);
     return 0;

@@ -115,9 +115,9 @@ class Emu:
         return out
 
     def pickle_seg_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, seg_min, seg_target, seg_warm, flags=0, threads=0):
-        """pickles with big messages cut into segments (k4lz4_segments.hpp): returns (lengths, [cut blocks, segments, blocks joined])"""
+        """pickles with big messages cut into segments (k4lz4_segments.hpp): returns (lengths, [cut blocks, segments, blocks joined as planned, pieces kept behind a bad boundary, runs resumed by the join, of those stopped at a verified boundary, blocks encoded again whole])"""
         out = np.zeros(src_len.size, np.int32)
-        stats = np.zeros(4, np.uint32)
+        stats = np.zeros(8, np.uint32)
         rc = self.lib.k4emu_pickle_seg_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
                                              dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data, src_len.size, flags,
                                              seg_min, seg_target, seg_warm, stats.ctypes.data, threads)

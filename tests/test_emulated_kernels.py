@@ -221,6 +221,30 @@ def test_pickle_in_segments_matches_oracle(emu, oracle):
     assert 0 < joined < cut, (joined, cut)
 
 
+def test_segments_behind_a_bad_boundary_are_kept(emu, oracle):
+    """round 4: a piece whose successor is not in step keeps its output and leaves the cut's table in its item's slot (state 4;
+    the successor's published snapshot stays what it was: overwriting it once made a later check pass against the wrong table),
+    and the join's one wave goes on from there only as far as the next boundary whose piece IS in step.  Messages whose middle
+    part breaks the warm-up's assumption (random bytes between text) at several segment sizes: state-4 pieces and resumed
+    runs must occur, one of the settings has a resumed run stop at a verified boundary, every envelope is the oracle's."""
+    parts = lambda *p: np.concatenate(p)
+    blocks = [parts(corpus.class_bytes("dickens", 100000, 1), corpus.random_bytes(60000, 1), corpus.class_bytes("dickens", 200000, 2)),
+              parts(corpus.class_bytes("xml", 90000, 3), corpus.random_bytes(50000, 2), corpus.class_bytes("webster", 160000, 4),
+                    corpus.random_bytes(30000, 5), corpus.class_bytes("webster", 100000, 8)),
+              parts(corpus.lorem(40000), corpus.class_bytes("nci", 50000, 5), corpus.lorem(70000))]
+    src, soff, slen = pack(blocks)
+    caps = [oracle.lib.k4o_pickle_bound(b.size) for b in blocks]
+    kept = resumed = stops = 0
+    for (seg_target, seg_warm) in ((32768, 65536), (49152, 70000), (16384, 4096), (24576, 66000)):
+        dst, doff, dcap = arena(caps)
+        out, stats = emu.pickle_seg_batch(src, soff, slen, dst, doff, dcap, 70000, seg_target, seg_warm)
+        for i, b in enumerate(blocks):
+            assert dst[int(doff[i]):int(doff[i]) + int(out[i])].tobytes() == oracle.pickle(b, 0, 0), (i, seg_target, seg_warm)
+            assert (dst[int(doff[i]) + max(int(dcap[i]), int(out[i])):int(doff[i]) + int(dcap[i]) + 16] == 0xCD).all()
+        kept += int(stats[3]); resumed += int(stats[4]); stops += int(stats[5])
+    assert kept > 0 and 0 < stops <= resumed, (kept, resumed, stops)
+
+
 def test_unpickle_corruption(emu, oracle):
     """PicklingTests.cs:149-172: corrupted pickles are rejected exactly where the oracle rejects"""
     rng = np.random.default_rng(23)
