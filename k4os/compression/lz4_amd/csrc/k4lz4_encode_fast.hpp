@@ -405,7 +405,10 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
     const unsigned long long me = 1ull << lane, below_me = me - 1ull;
 
     const bool resumed = sr && uni(sr->resume != nullptr ? 1u : 0u) != 0u;
-    if (resumed) { for (int k = lane; k < 4096; k += 64) tabmem[k] = sr->resume[k]; }
+    if (resumed) {
+#pragma unroll 4
+        for (int k = lane; k < 4096; k += 64) tabmem[k] = sr->resume[k];
+    }
     else
     for (int k = lane; k < 1024; k += 64) ((uint4 *)tabmem)[k] = make_uint4(0u, 0u, 0u, 0u);
     for (int k = lane; k < ENCODE_SCRATCH_BYTES / 4; k += 64) seen[k] = 0u;
@@ -858,6 +861,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 wave_sync();
                 if (dry) {
                     /* the warm run has reached its cut: publish it with the table, write from here on */
+#pragma unroll 4
                     for (int k = lane; k < 4096; k += 64) sr->snap_pub[16 + k] = tabmem[k];
                     wave_sync();
                     if (lane == 0) agent_publish(sr->snap_pub, cut + 1u);
@@ -879,6 +883,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                     if (same) {
                         agent_acquire();
                         bool differ = false;
+#pragma unroll 4
                         for (int k = lane; k < 4096; k += 64) {
                             const uint32_t mine = tabmem[k], other = sr->snap_chk[16 + k];
                             differ = differ || (mine != other && !(cut - mine > (uint32_t)DISTANCE_MAX && cut - other > (uint32_t)DISTANCE_MAX));
@@ -894,7 +899,10 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                          * nothing to offer: the block is then encoded again the plain way. */
                         if (theirs == 0u || !sr->fix) return 0;
                         while (rec_count) if (!flush()) return 0;
-                        if (sr->fix != tabmem) { for (int k = lane; k < 4096; k += 64) sr->fix[k] = tabmem[k]; }
+                        if (sr->fix != tabmem) {
+#pragma unroll 4
+                            for (int k = lane; k < 4096; k += 64) sr->fix[k] = tabmem[k];
+                        }
                         wave_sync();
                         sr->stop = cut;
                         sr->state = 4u;
