@@ -406,7 +406,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
 
     const bool resumed = sr && uni(sr->resume != nullptr ? 1u : 0u) != 0u;
     if (resumed) {
-#pragma unroll 4
+#pragma unroll 2
         for (int k = lane; k < 4096; k += 64) tabmem[k] = sr->resume[k];
     }
     else
@@ -861,7 +861,7 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                 wave_sync();
                 if (dry) {
                     /* the warm run has reached its cut: publish it with the table, write from here on */
-#pragma unroll 4
+#pragma unroll 2
                     for (int k = lane; k < 4096; k += 64) sr->snap_pub[16 + k] = tabmem[k];
                     wave_sync();
                     if (lane == 0) agent_publish(sr->snap_pub, cut + 1u);
@@ -883,34 +883,28 @@ __device__ __forceinline__ int encode_fast_block(const uint8_t *src, int src_len
                     if (same) {
                         agent_acquire();
                         bool differ = false;
-#pragma unroll 4
+#pragma unroll 2
                         for (int k = lane; k < 4096; k += 64) {
                             const uint32_t mine = tabmem[k], other = sr->snap_chk[16 + k];
                             differ = differ || (mine != other && !(cut - mine > (uint32_t)DISTANCE_MAX && cut - other > (uint32_t)DISTANCE_MAX));
                         }
                         same = ballot(differ) == 0ull;
                     }
-                    if (!same) {
-                        /* The next segment's run is not in step here.  If THIS run began in step (the join finds that out), what it
-                         * has written up to `cut` is the block's encoding up to there and its table is the block's table there:
-                         * it keeps its output and leaves the table in its item's slot (`fix`; the other run's snapshot stays as it
-                         * is -- it says what THAT run began with, which whoever arrives at this cut later must still be able to
-                         * check) for a run that goes on from this cut (k4_seg_join_kernel).  A run that gave up waiting has
-                         * nothing to offer: the block is then encoded again the plain way. */
-                        if (theirs == 0u || !sr->fix) return 0;
-                        while (rec_count) if (!flush()) return 0;
-                        if (sr->fix != tabmem) {
-#pragma unroll 4
-                            for (int k = lane; k < 4096; k += 64) sr->fix[k] = tabmem[k];
-                        }
-                        wave_sync();
-                        sr->stop = cut;
-                        sr->state = 4u;
-                        return (int)op;
-                    }
+                    /* Not in step?  If THIS run began in step (the join finds that out), what it has written up to `cut` is the
+                     * block's encoding up to there and its table is the block's table there: it keeps its output and leaves the
+                     * table in its item's slot (`fix`; the other run's snapshot stays as it is -- it says what THAT run began with,
+                     * which whoever arrives at this cut later must still be able to check) for a run that goes on from this cut
+                     * (k4_seg_join_kernel).  A run that gave up waiting has nothing to offer: the block is then encoded again the
+                     * plain way. */
+                    if (!same && (theirs == 0u || !sr->fix)) return 0;
                     while (rec_count) if (!flush()) return 0;
+                    if (!same && sr->fix != tabmem) {
+#pragma unroll 2
+                        for (int k = lane; k < 4096; k += 64) sr->fix[k] = tabmem[k];
+                        wave_sync();
+                    }
                     sr->stop = cut;
-                    sr->state = 1u;
+                    sr->state = same ? 1u : 4u;
                     return (int)op;
                 }
             }
