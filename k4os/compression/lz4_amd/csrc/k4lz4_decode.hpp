@@ -444,89 +444,88 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
         }
         /* a batch is closed when it may not take another round's sequences, or when its output nears what the stage holds */
         while (ROLE != 2 && nseq <= 64 - MAX_SEQ_PER_ROUND && op - op_batch <= (int64_t)DECODE_BATCH_SOFT_BYTES && !done) {
-            /* ---- speculative round: 64 hypotheses "a token starts at ip + lane" ---- */
-            const int64_t lim = shortiend - 1 - ip;        /* hypotheses i < lim satisfy ip + i + 1 < shortiend */
-            if (lim > 0 || iend - RUN_MASK - 1 - ip > 0) {
+            /* ---- speculative round: 64 hypotheses "a token starts at ip + lane" ----
+             * All positions of this part are below 2^31 (sizes are `int`), a hypothesis adds at most a few hundred: the conditions
+             * of LL64.dec.cs are written as sums in uint32 (ip + lane + k < iend instead of lane < iend - k - ip), which costs a
+             * third of the instructions their 64-bit forms did, and both extension bytes are taken without a branch (among 64
+             * hypotheses some lane always has them). */
+            const uint32_t ipu = (uint32_t)ip, opu = (uint32_t)op, iendu = (uint32_t)iend, oendu = (uint32_t)oend;
+            if (ipu + (uint32_t)RUN_MASK + 1u < iendu) {   /* some hypothesis can be usable: lim > 0 || iend - RUN_MASK - 1 - ip > 0 */
+                K4_PHASE("spec-hyp");
                 const unsigned long long tp0 = prof_now<PROF>();
-                win.ensure((uint32_t)ip + win.a0, lane);
-                const uint32_t q = (uint32_t)ip + win.a0 + (uint32_t)lane;
+                win.ensure(ipu + win.a0, lane);
+                const uint32_t pl = ipu + (uint32_t)lane;           /* stream position of this lane's hypothetical token */
+                const uint32_t q = pl + win.a0;
                 const uint32_t t4 = win.read4(q);
-                uint32_t L = (t4 >> 4) & 15u;
-                uint32_t M = t4 & 15u;
-                /* class S: the shortcut (:191-225), literal length in the token.
-                 * class G: 15 + one extension byte of literals -> the general literal path (:228-315) */
-                const bool cls_g = L == RUN_MASK;
-                uint32_t hdr = 1u;                          /* token (+ literal-length extension) bytes */
-                bool fast = cls_g ? (int64_t)lane < iend - RUN_MASK - 1 - ip : (int64_t)lane < lim;
-                if (cls_g) {
-                    const uint32_t ext = (t4 >> 8) & 0xffu;
-                    fast = fast && ext != 255u;
-                    L += ext;
-                    hdr = 2u;
-                    /* the run must leave room for offset + a last sequence (:247) */
-                    fast = fast && (int64_t)ip + lane + hdr + L <= iend - (2 + 1 + LASTLITERALS);
-                }
+                const uint32_t L0 = (t4 >> 4) & 15u;
+                const uint32_t M = t4 & 15u;
+                /* class S: the shortcut (:191-225), literal length in the token: ip + lane + 1 < shortiend.
+                 * class G: 15 + one extension byte of literals -> the general literal path (:228-315): lane < iend - RUN_MASK - 1 - ip,
+                 * the extension byte not 255, and the run leaves room for offset + a last sequence (:247) */
+                const bool cls_g = L0 == RUN_MASK;
+                const uint32_t ext_l = (t4 >> 8) & 0xffu;
+                const uint32_t L = cls_g ? L0 + ext_l : L0;
+                const uint32_t hdr = cls_g ? 2u : 1u;             /* token (+ literal-length extension) bytes */
+                bool fast = cls_g ? (pl + (uint32_t)RUN_MASK + 1u < iendu && ext_l != 255u && pl + hdr + L + (2u + 1u + LASTLITERALS) <= iendu)
+                                  : pl + 1u + 14u + 2u < iendu;
                 const uint32_t q2 = q + hdr + L;
                 const uint32_t o4 = win.read4(q2);
                 const uint32_t offset = o4 & 0xffffu;
-                /* where the match-length field ends and the next token starts, relative to ip */
-                uint32_t next = (uint32_t)lane + hdr + L + 2u;
-                uint32_t mlen = M + MINMATCH;
-                fast = fast && offset != 0u;
-                const bool general = cls_g || M == ML_MASK || offset < 8u;   /* not the shortcut's match stage */
-                if (M == ML_MASK) {                        /* one extension byte (:326-334) */
-                    const uint32_t ext = (o4 >> 16) & 0xffu;
-                    mlen += ext;
-                    next += 1u;
-                    /* the byte after the extension must stay below iend - LASTLITERALS + 1 */
-                    fast = fast && ext != 255u && (int64_t)ip + next < iend - LASTLITERALS + 1;
-                }
+                /* where the match-length field ends and the next token starts, relative to ip; one extension byte (:326-334):
+                 * the byte after it must stay below iend - LASTLITERALS + 1 */
+                const bool m_ext = M == ML_MASK;
+                const uint32_t ext_m = (o4 >> 16) & 0xffu;
+                const uint32_t next = (uint32_t)lane + hdr + L + (m_ext ? 3u : 2u);
+                const uint32_t mlen = M + MINMATCH + (m_ext ? ext_m : 0u);
+                fast = fast && offset != 0u && (!m_ext || (ext_m != 255u && ipu + next + (LASTLITERALS - 1u) < iendu));
+                const bool general = cls_g || m_ext || offset < 8u;   /* not the shortcut's match stage */
                 const uint32_t outlen = L + mlen;
                 const uint32_t packed = token_word(fast, next, lane);
 
                 /* follow the true chain from hypothesis 0: one v_readlane per real sequence */
                 unsigned long long T = 0;
                 uint32_t idx = 0;
+                K4_PHASE("spec-chain");
                 const unsigned long long tp1 = prof_now<PROF>();
                 follow_tokens(packed, T, idx, HOP2);
+                K4_PHASE("spec-scan-rules");
                 const unsigned long long tp2 = prof_now<PROF>();
                 /* output position of every chosen sequence: prefix sum of the chosen lengths */
                 bool in_t = ((T >> lane) & 1ull) != 0;
                 const uint32_t incl = wave_inclusive_scan(in_t ? outlen : 0u);
-                const int64_t v_o64 = op + (int64_t)(incl - (in_t ? outlen : 0u));
-                const uint32_t v_o = (uint32_t)v_o64;
+                const uint32_t v_o = opu + (incl - (in_t ? outlen : 0u));
+                const uint32_t total = readlane_u32(incl, 63);
                 /* position-dependent rules on the chosen sequences: the shortcut needs
                  * op <= shortoend (:191), a 15+ literal run cpy <= oend - MFLIMIT (:247); the offset
                  * must stay inside the output (:338); sequences
                  * that left the shortcut also obey the end-of-block rule (:427-433).  The first
                  * sequence that fails, and everything after it, is left to the scalar parser. */
-                const int64_t mdst_l = v_o64 + L;
+                const uint32_t mdst_l = v_o + L;
                 unsigned long long bad;
-                if (op + (int64_t)__builtin_amdgcn_readlane(incl, 63) <= oend - 64) {
+                if (opu + total + 64u <= oendu) {
                     /* every chosen sequence ends at least 64 bytes before the end of the output: the three
                      * end-of-block rules hold for all of them, only the offset can be wrong */
-                    bad = ballot(in_t && offset > v_o + L);
+                    bad = ballot(in_t && offset > mdst_l);
                 } else {
-                    bad = ballot(in_t && ((cls_g ? mdst_l > oend - MFLIMIT : v_o64 > shortoend) || (int64_t)offset > mdst_l ||
-                                            (general && mdst_l + (int64_t)mlen > oend - MATCH_SAFEGUARD)));
+                    bad = ballot(in_t && ((cls_g ? mdst_l + (uint32_t)MFLIMIT > oendu : v_o + 14u + 18u > oendu) || offset > mdst_l ||
+                                            (general && mdst_l + mlen + (uint32_t)MATCH_SAFEGUARD > oendu)));
                 }
-                int64_t cur_op;
+                uint32_t adv_op = total;
                 if (bad) {
                     const int b = ctz64(bad);
                     T &= (1ull << b) - 1ull;
                     idx = (uint32_t)b;
-                    cur_op = op + (int64_t)(__builtin_amdgcn_readlane(incl, b) - __builtin_amdgcn_readlane(outlen, b));
+                    adv_op = readlane_u32(incl, b) - readlane_u32(outlen, b);
                     in_t = ((T >> lane) & 1ull) != 0;
-                } else {
-                    cur_op = op + (int64_t)__builtin_amdgcn_readlane(incl, 63);
                 }
+                K4_PHASE("spec-slots");
                 const unsigned long long tp3 = prof_now<PROF>();
                 if (PROF) { c_hyp += tp1 - tp0; c_chain += tp2 - tp1; c_rules += tp3 - tp2; n_spec++; }
                 if (T) {
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(T >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)T, 0u));
                     if (in_t) {
                         const uint32_t slot = (uint32_t)nseq + below;
-                        d_lpos[slot] = (uint32_t)ip + (uint32_t)lane + hdr;
+                        d_lpos[slot] = pl + hdr;
                         d_llen[slot] = L;
                         d_out[slot] = v_o;
                         d_moff[slot] = offset;
@@ -534,13 +533,14 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                     }
                     nseq += __popcll(T);
                     ip += idx;
-                    op = cur_op;
+                    op += adv_op;
                     if (PROF) c_slots += prof_now<PROF>() - tp3;
                     continue;
                 }
             }
 
             /* ---- scalar parser: one sequence, the reference's order of checks ---- */
+            K4_PHASE("scalar-parser");
             if (PROF) n_slow++;
             uint32_t w = win.fetch((uint32_t)ip, lane);
             const uint32_t token = w & 0xffu;
@@ -655,6 +655,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             op += adv;
             if (last) done = true;
         }
+        K4_PHASE("batch-end");
         if (ROLE == 1) {                                    /* publish the batch (or the failure) and go on parsing */
             if (lane == 0) {
                 meta[0] = err ? 0u : (uint32_t)nseq;
