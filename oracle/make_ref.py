@@ -4,7 +4,8 @@
 Test infrastructure (never imported by the product package).  The reference engine
 (`/root/reference/src/K4os.Compression.LZ4/Engine/**`, `Internal/Mem*.cs`) is `unsafe` C#
 pointer code -- C in all but spelling.  This script reads those files WHERE THEY LIE (nothing
-is copied into the repository: the generated C++ goes to the git-ignored `oracle/_ref/`),
+is copied into the repository: oracle/Makefile has the generated C++ written into a scratch directory that
+lasts as long as the g++ run that reads it; only the compiled libraries and the report stay, under the git-ignored `oracle/_ref/`),
 rewrites the spelling with purely syntactic, table-driven rules, and leaves every statement
 of every engine function exactly as the reference has it.  What the rules cannot express
 (calls into the .NET runtime) is supplied by `oracle/ref_prelude.hpp` -- a fixed list of
@@ -609,7 +610,7 @@ class Translator:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref"))
+    ap.add_argument("--out", required=True, help="directory for k4ref_engine.hpp + make_ref_report.json (oracle/Makefile passes a scratch directory)")
     ap.add_argument("-D", dest="defines", action="append", default=[],
                     help="C# conditional symbols (e.g. NET5_0_OR_GREATER); BIT32 comes from the x32 files themselves")
     args = ap.parse_args()
@@ -626,7 +627,7 @@ def main():
     if missing:
         raise SystemExit(f"EXCLUDED names never met in the inputs: {missing}")
     os.makedirs(args.out, exist_ok=True)
-    hdr = ["// GENERATED by oracle/make_ref.py from /root/reference (read where it lies; this file is git-ignored).",
+    hdr = ["// GENERATED by oracle/make_ref.py from /root/reference (read where it lies); lives in a scratch directory while g++ compiles it.",
            "// Every function body below is the reference's own statement sequence; only the spelling rules",
            "// R1..R20 documented in oracle/make_ref.py were applied.  Do not edit.",
            f"// inputs sha256: {digest.hexdigest()}",

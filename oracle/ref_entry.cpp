@@ -1,5 +1,5 @@
 // oracle/ref_entry.cpp -- C entry points of oracle/_ref/libk4ref.so (test infrastructure).
-// The bodies of the engine are NOT here: k4ref_engine.hpp is generated from /root/reference by
+// The bodies of the engine are NOT here: k4ref_engine.hpp is generated from /root/reference (into a scratch directory) by
 // oracle/make_ref.py at build time.  These wrappers are the `Algorithm.X64` / `Algorithm.X32` arms of
 // Engine/LLxx.cs:17-103 (which is managed `switch`-expression code the translator does not take) with
 // the engine chosen by the caller instead of by LL.Enforce32.
