@@ -130,3 +130,42 @@ def test_mutated_streams_vs_compiled_reference(ref):
         assert out[i] == n, i
         if n > 0:
             assert dst[int(doff[i]):int(doff[i]) + n].tobytes() == want[:n].tobytes()
+
+
+@pytest.mark.parametrize("level", [4, 5, 6, 7, 8, 11])
+def test_remaining_hc_levels_vs_compiled_reference(ref, level):
+    """the rest of LZ4Level (clTable, LL64.high.cs:1124-1138): 24 bench blocks (two of every class) per level"""
+    blocks = corpus.silesia_like_blocks(4096, 65536, seed=2)[:24]
+    enc = LZ4Codec.EncodeBatch(list(blocks), level=LZ4Level(level))
+    want = _pool_map(lambda i: _enc(ref, blocks[i], level), range(24))
+    assert [i for i in range(24) if enc[i] != want[i]] == []
+
+
+def test_partial_and_dictionary_decode_vs_compiled_reference(ref, syslz4):
+    """next-row N1 against LL64.LZ4_decompress_safe_partial / _usingDict themselves (LL64.dec.cs:479-556): return values and bytes"""
+    from k4os.compression.lz4_amd._native import FLAG_RAW_RETURN
+    for cls in ("dickens", "xml", "mr"):
+        data = corpus.class_bytes(cls, 30000, 8)
+        r, d = ref.compress_fast(data)
+        comp = d[:r].copy()
+        for want in (0, 1, 13, 64, 1000, 12345, 29990, 29999, 30000, 30001, 40000):
+            tgt = np.full(want + 32, 0xCD, np.uint8)
+            n = LZ4Codec.PartialDecode(comp, 0, comp.size, tgt, 0, want)
+            rn, rd = ref.decompress_partial(comp, want, want)
+            assert n == (-1 if rn <= 0 else rn), (cls, want, n, rn)
+            if n > 0:
+                assert tgt[:n].tobytes() == rd[:n].tobytes()
+        dictionary = corpus.class_bytes(cls, 40000, 9)
+        block = syslz4.compress_with_dict(data, dictionary)
+        cases = [(block, data.size, dictionary), (block, data.size - 1, dictionary), (block, data.size + 9, dictionary),
+                 (block, data.size, dictionary[1:]), (block[:-3], data.size, dictionary)]
+        src, soff, slen = pack_blocks([c for c, _, _ in cases])
+        dpk, doffs, dlens = pack_blocks([x for _, _, x in cases])
+        caps = np.array([c for _, c, _ in cases], np.int32)
+        dst, doff = make_arena(caps)
+        out = LZ4Codec.DecodeDictBatchPacked(src, soff, slen, dst, doff, caps, dpk, doffs, dlens, flags=FLAG_RAW_RETURN)
+        for i, (c, cap, dd) in enumerate(cases):
+            rn, rd = ref.decompress_using_dict(c, cap, np.ascontiguousarray(dd))
+            assert out[i] == rn, (cls, i, out[i], rn)
+            if rn > 0:
+                assert dst[int(doff[i]):int(doff[i]) + rn].tobytes() == rd[:rn].tobytes()
