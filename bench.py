@@ -257,8 +257,10 @@ def main():
                         t = time.perf_counter(); el = engine.encode_batch(src_h, off, lens, ref_dst, ref_off, caps, threads=threads); te.append(time.perf_counter() - t)
                     for _ in range(2):
                         t = time.perf_counter(); engine.decode_batch(ref_dst, ref_off, el, out_h, out_off, lens, threads=threads); td.append(time.perf_counter() - t)
-                    t = time.perf_counter(); engine.encode_batch(src_h, off[:k1], lens[:k1], ref_dst, ref_off[:k1], caps[:k1], threads=1); t1e = time.perf_counter() - t
-                    t = time.perf_counter(); engine.decode_batch(ref_dst, ref_off[:k1], el[:k1], out_h, out_off[:k1], lens[:k1], threads=1); t1d = time.perf_counter() - t
+                    t1e = t1d = 1e9
+                    for _ in range(2):
+                        t = time.perf_counter(); engine.encode_batch(src_h, off[:k1], lens[:k1], ref_dst, ref_off[:k1], caps[:k1], threads=1); t1e = min(t1e, time.perf_counter() - t)
+                        t = time.perf_counter(); engine.decode_batch(ref_dst, ref_off[:k1], el[:k1], out_h, out_off[:k1], lens[:k1], threads=1); t1d = min(t1d, time.perf_counter() - t)
                     return {"value": round(gib / (min(te) + min(td)), 3), "encode_GiBs": round(gib / min(te), 3), "decode_GiBs": round(gib / min(td), 3),
                             "one_thread_encode_GiBs": round(k1 * bs / 2 ** 30 / t1e, 3), "one_thread_decode_GiBs": round(k1 * bs / 2 ** 30 / t1d, 3),
                             "what": label}
@@ -288,8 +290,10 @@ def main():
                         lz_dst = np.empty((k1, bound), np.uint8)           # buffers made beforehand: the loop below is the calls, nothing else
                         lz_out = np.empty(bs, np.uint8)
                         ptr = lambda a: a.ctypes.data_as(u8p)
-                        t = time.perf_counter(); lz_len = [sl.lib.LZ4_compress_fast(ptr(blocks[i]), ptr(lz_dst[i]), bs, bound, 1) for i in range(k1)]; t1e = time.perf_counter() - t
-                        t = time.perf_counter(); [sl.lib.LZ4_decompress_safe(ptr(lz_dst[i]), ptr(lz_out), lz_len[i], bs) for i in range(k1)]; t1d = time.perf_counter() - t
+                        t1e = t1d = 1e9
+                        for _ in range(2):          # best of 2: the first pass touches the buffers' pages
+                            t = time.perf_counter(); lz_len = [sl.lib.LZ4_compress_fast(ptr(blocks[i]), ptr(lz_dst[i]), bs, bound, 1) for i in range(k1)]; t1e = min(t1e, time.perf_counter() - t)
+                            t = time.perf_counter(); [sl.lib.LZ4_decompress_safe(ptr(lz_dst[i]), ptr(lz_out), lz_len[i], bs) for i in range(k1)]; t1d = min(t1d, time.perf_counter() - t)
                         lz = {"version": sl.version, "one_thread_encode_GiBs": round(k1 * bs / 2 ** 30 / t1e, 3), "one_thread_decode_GiBs": round(k1 * bs / 2 ** 30 / t1d, 3),
                               "what": "liblz4.so.1 through ctypes, per-block calls, 256 blocks (sanity column, not the reference)"}
                 except Exception:
