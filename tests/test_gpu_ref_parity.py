@@ -87,16 +87,14 @@ def test_ragged_messages_both_engines_vs_compiled_reference(ref):
 def test_acceleration_through_the_llxx_seam(ref):
     """LLxx.LZ4_compress_fast passes `acceleration` through (LLxx.cs:65-75): k4lz4_compress_fast with 1, 2, 8 and an out of
     range value (< 1 -> ACCELERATION_DEFAULT, LL64.fast.cs:522)"""
-    lib = load_library()
-    u8p = C.POINTER(C.c_uint8)
-    lib.k4lz4_compress_fast.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int]
+    lib = load_library()          # (the argument types are the ones _native.SYMBOLS declared: nothing is changed on the shared handle)
     for i, size in enumerate((3000, 65536, 65600, 200000)):
         for cls in ("dickens", "xml", "mr", "sao"):
             data = corpus.class_bytes(cls, size, i)
             cap = LZ4Codec.MaximumOutputSize(size)
             for acc in (1, 2, 8, 0, 70):
                 dst = np.full(cap, 0xCD, np.uint8)
-                r = lib.k4lz4_compress_fast(data.ctypes.data_as(u8p), dst.ctypes.data_as(u8p), size, cap, acc)
+                r = lib.k4lz4_compress_fast(data.ctypes.data, dst.ctypes.data, size, cap, acc)
                 want_r, want = ref.compress_fast(data, accel=acc)
                 assert r == want_r and dst.tobytes() == want.tobytes(), (cls, size, acc)
 
