@@ -473,9 +473,21 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
         bool seg = false;
         if (kind == KIND_ENCODE && (flags & (FLAG_SEGMENTS_OK | K4LZ4_FLAG_SEGMENTS)) && ctx->use_segments && !a.prof && !(flags & K4LZ4_FLAG_ALLOW_COPY)) {
             static_assert(k4::SEG_HDR_DWORDS * 4 == 256, "seg_first_of finds the header in front of the items");
-            const size_t o_items = 256, o_work = o_items + (size_t)k4::SEG_MAX_ITEMS * sizeof(k4::SegItem);
-            const size_t o_blocks = o_work + (size_t)k4::SEG_MAX_ITEMS * 4, o_snaps = (o_blocks + (size_t)k4::SEG_MAX_BLOCKS * 4 + 255) & ~(size_t)255;
-            const size_t o_tables = o_snaps + (size_t)k4::SEG_MAX_ITEMS * k4::SEG_SNAP_DWORDS * 4, total = o_tables + (size_t)k4::SEG_MAX_ITEMS * 16384;
+            /* how many segments the plan can come to: every item costs a 16 KiB snapshot and a 16 KiB table slot, so where the
+             * host knows the lengths the arrays are sized by them (an upper bound: the plan's segments are never shorter than
+             * seg_target, its threshold never below seg_min) instead of by the most a launch may have */
+            size_t max_items = (size_t)k4::SEG_MAX_ITEMS;
+            if (hostLen) {
+                size_t bound = 0;
+                for (int64_t i = 0; i < cnt && bound < max_items; i++) {
+                    const int32_t u = hostLen[first + i];
+                    if (u > 0 && (uint32_t)u >= ctx->seg_min) bound += ((size_t)u + ctx->seg_target - 1) / ctx->seg_target;
+                }
+                max_items = std::min(max_items, std::max<size_t>(bound, 2));
+            }
+            const size_t o_items = 256, o_work = o_items + max_items * sizeof(k4::SegItem);
+            const size_t o_blocks = o_work + max_items * 4, o_snaps = (o_blocks + (size_t)k4::SEG_MAX_BLOCKS * 4 + 255) & ~(size_t)255;
+            const size_t o_tables = o_snaps + max_items * k4::SEG_SNAP_DWORDS * 4, total = o_tables + max_items * 16384;
             if (total > ctx->d_seg_cap || (size_t)cnt * 4 > ctx->d_seg_first_cap) {
                 K4_HIP(ctx, hipStreamSynchronize(stream));
                 K4_HIP(ctx, hipStreamSynchronize(ctx->aux2));
@@ -486,7 +498,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             sg.hdr = (k4::SegHdr *)ctx->d_seg; sg.items = (k4::SegItem *)(ctx->d_seg + o_items); sg.work = (uint32_t *)(ctx->d_seg + o_work);
             sg.blocks = (uint32_t *)(ctx->d_seg + o_blocks); sg.snaps = (uint32_t *)(ctx->d_seg + o_snaps); sg.tables = (uint32_t *)(ctx->d_seg + o_tables);
             sg.first = (int32_t *)ctx->d_seg_first;
-            sg.seg_min = ctx->seg_min; sg.seg_target = ctx->seg_target; sg.seg_warm = ctx->seg_warm; sg.seg_div = ctx->seg_div; sg.seg_target_max = ctx->seg_target_max; sg.spin_max = ctx->seg_spin_max;
+            sg.seg_min = ctx->seg_min; sg.seg_target = ctx->seg_target; sg.seg_warm = ctx->seg_warm; sg.seg_div = ctx->seg_div; sg.seg_target_max = ctx->seg_target_max; sg.spin_max = ctx->seg_spin_max; sg.max_items = (uint32_t)max_items;
             hipLaunchKernelGGL(k4::k4_seg_plan_kernel, dim3(1), dim3(256), 0, stream, a, sg);
             a.seg_first = sg.first; a.seg_items = sg.items; a.seg_snaps = sg.snaps;
             seg = true;
@@ -496,7 +508,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             if (!seg) return K4LZ4_OK;
             K4_HIP(ctx, hipEventRecord(ctx->ev_fork, stream));
             K4_HIP(ctx, hipStreamWaitEvent(ctx->aux2, ctx->ev_fork, 0));
-            hipLaunchKernelGGL(k4::k4_encode_seg_kernel, dim3((unsigned)(k4::SEG_MAX_ITEMS / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, ctx->aux2, a, sg);
+            hipLaunchKernelGGL(k4::k4_encode_seg_kernel, dim3((unsigned)((sg.max_items + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, ctx->aux2, a, sg);
             K4_HIP(ctx, hipEventRecord(ctx->ev_join2, ctx->aux2));
             return K4LZ4_OK;
         };

@@ -312,7 +312,7 @@ __device__ __forceinline__ void hop_chain_pairs(unsigned long long &hmx, unsigne
 constexpr uint32_t SEG_NONE = 0xffffffffu;
 constexpr uint32_t SEG_ITEM_WORDS = 10u;          /* a segment's record (k4lz4_segments.hpp, SegItem) as the words the encoder kernels read and write */
 constexpr int SEG_SNAP_DWORDS = 4096 + 16;          /* [0] cut + 1 (0: not there yet, SEG_NONE: this run never found one), [16..] the table */
-constexpr uint32_t SEG_ITEMS_MAX = 8192u;           /* = SEG_MAX_ITEMS (k4lz4_segments.hpp): segments of all cut blocks of a launch */
+constexpr uint32_t SEG_ITEMS_MAX = 8192u;           /* = SEG_MAX_ITEMS (k4lz4_segments.hpp): segments of all cut blocks of a launch, at most */
 constexpr uint32_t SEG_HDR_DWORDS = 64u;            /* k4lz4_capi.hip lays a launch's segment scratch out as header (256 bytes), then the items */
 constexpr uint32_t SEG_SPIN_MAX = 1u << 20;          /* polls (with s_sleep 8 between them: some tenths of a second) before a run stops waiting for the next one's cut */
 struct SegRun {
@@ -1068,7 +1068,8 @@ __device__ __forceinline__ SegFirst seg_first_of(const BatchArgs &a, long long b
     f.run.stop_at = uni(w[4]);
     f.cap = f.run.stop_at;                                          /* its piece may not reach into the next segment's */
     f.run.snap_chk = a.seg_snaps + (size_t)(it + 1) * SEG_SNAP_DWORDS;
-    f.run.fix = a.seg_snaps + (size_t)SEG_ITEMS_MAX * SEG_SNAP_DWORDS + 4096ull * (unsigned long long)it;    /* SegArgs::tables lies right behind the snapshots */
+    /* SegArgs::tables lies right behind the launch's snapshots (SegHdr::max_items of them, header word 7) */
+    f.run.fix = a.seg_snaps + (size_t)uni(((const uint32_t *)a.seg_items)[-(int)SEG_HDR_DWORDS + 7]) * SEG_SNAP_DWORDS + 4096ull * (unsigned long long)it;
     return f;
 }
 __device__ __forceinline__ void seg_first_done(const BatchArgs &a, long long b, const SegFirst &f, int ret, int lane)

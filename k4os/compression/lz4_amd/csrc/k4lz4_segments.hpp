@@ -40,6 +40,7 @@ static_assert(sizeof(SegItem) == 4u * SEG_ITEM_WORDS, "seg_first_of / seg_first_
 struct SegHdr {
     uint32_t n_items, n_work, n_blocks, spin_max;    /* spin_max: SegRun::spin_max for every run of the launch (word 3: seg_first_of reads it as such) */
     uint32_t n_resumed, n_resume_stops, n_plain;     /* k4_seg_join_kernel's runs: begun from a cut; of those, stopped at a verified boundary; whole blocks again */
+    uint32_t max_items;                              /* word 7: what this launch's arrays hold (<= SEG_MAX_ITEMS); the table slots begin max_items snapshots behind `snaps` */
 };
 
 struct SegArgs {
@@ -55,6 +56,8 @@ struct SegArgs {
     uint32_t seg_min, seg_target, seg_warm;
     uint32_t seg_target_max;     /* the segment size grows with the batch up to this (0 or <= seg_target: fixed size), see k4_seg_plan_kernel */
     uint32_t spin_max;           /* SegRun::spin_max (0: the default) */
+    uint32_t max_items;          /* items the arrays of this launch hold: SEG_MAX_ITEMS, or fewer when the host knows the lengths (a batch of
+                                  * thirteen big messages then takes 3 MB of snapshots and tables instead of 269) */
     uint32_t seg_div;            /* a block is cut only if it is longer than the batch's bytes / seg_div: a wave encodes ~25 MB/s, the whole chip
                                   * ~2 500 times that, so shorter blocks are over before the batch is and cutting them only adds their warm-ups */
 };
@@ -96,14 +99,14 @@ __global__ __launch_bounds__(256) void k4_seg_plan_kernel(BatchArgs a, SegArgs g
     uint32_t ni = 0, nb = 0;
     for (long long b = lo; b < hi; b++) { const uint32_t k = segments_of(b); ni += k; nb += k ? 1u : 0u; }
     items_of[t] = ni; blocks_of[t] = nb;
-    if (t == 0) { g.hdr->n_items = 0u; g.hdr->n_work = 0u; g.hdr->n_blocks = 0u; g.hdr->spin_max = g.spin_max; g.hdr->n_resumed = 0u; g.hdr->n_resume_stops = 0u; g.hdr->n_plain = 0u; }
+    if (t == 0) { g.hdr->n_items = 0u; g.hdr->n_work = 0u; g.hdr->n_blocks = 0u; g.hdr->spin_max = g.spin_max; g.hdr->n_resumed = 0u; g.hdr->n_resume_stops = 0u; g.hdr->n_plain = 0u; g.hdr->max_items = g.max_items; }
     __syncthreads();
     uint32_t base = 0, bi = 0;
     for (int k = 0; k < t; k++) { base += items_of[k]; bi += blocks_of[k]; }
     for (long long b = lo; b < hi; b++) {
         const uint32_t nseg = segments_of(b);
         int32_t at = -1;
-        if (nseg && base + nseg <= (uint32_t)SEG_MAX_ITEMS && bi < (uint32_t)SEG_MAX_BLOCKS) {
+        if (nseg && base + nseg <= g.max_items && bi < (uint32_t)SEG_MAX_BLOCKS) {
             const uint32_t U = (uint32_t)a.srcLen[b];
             /* the first segment is the longer one: its wave has no warm-up to run first, so the runs of a block -- warm-up and
              * segment -- come out about equally long (the warm-up counted for at most half a segment) */

@@ -174,15 +174,15 @@ int k4emu_pickle_seg_batch(const uint8_t *src, const uint64_t *srcOff, const int
     std::vector<uint32_t> work((size_t)k4::SEG_MAX_ITEMS), blocks((size_t)k4::SEG_MAX_BLOCKS);
     k4::SegArgs g{};
     g.hdr = &hdr; g.items = items; g.work = work.data(); g.blocks = blocks.data(); g.first = first.data();
-    g.seg_min = seg_min; g.seg_target = seg_target; g.seg_warm = seg_warm; g.seg_div = 0u;
+    g.seg_min = seg_min; g.seg_target = seg_target; g.seg_warm = seg_warm; g.seg_div = 0u; g.max_items = 600u;      /* (fewer than SEG_MAX_ITEMS: the table slots then begin 600 snapshots in) */
     /* snapshots and, right behind them, one table slot per item (seg_first_of counts on that layout) */
     std::vector<uint32_t> snaps;
-    snaps.assign((size_t)k4::SEG_MAX_ITEMS * k4::SEG_SNAP_DWORDS + 64, 0u);       /* the plan only touches the flags */
+    snaps.assign((size_t)g.max_items * k4::SEG_SNAP_DWORDS + 64, 0u);       /* the plan only touches the flags */
     g.snaps = snaps.data();
     k4emu::launch_fn(dim3(1), dim3(256), [=] { k4::k4_seg_plan_kernel(e, g); }, 1);
-    snaps.resize((size_t)k4::SEG_MAX_ITEMS * k4::SEG_SNAP_DWORDS + (size_t)(hdr.n_items + 2u) * 4096u, 0u);
+    snaps.resize((size_t)g.max_items * k4::SEG_SNAP_DWORDS + (size_t)(hdr.n_items + 2u) * 4096u, 0u);
     g.snaps = snaps.data();
-    g.tables = snaps.data() + (size_t)k4::SEG_MAX_ITEMS * k4::SEG_SNAP_DWORDS;
+    g.tables = snaps.data() + (size_t)g.max_items * k4::SEG_SNAP_DWORDS;
     e.seg_first = g.first; e.seg_items = g.items; e.seg_snaps = g.snaps;
     if (hdr.n_work)
         k4emu::launch_fn(dim3((hdr.n_work + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG), dim3(64 * k4::ENCODE_WAVES_PER_WG), [=] { k4::k4_encode_seg_kernel(e, g); }, 1);
