@@ -409,6 +409,27 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
     const int64_t shortiend = iend - 14 - 2;               /* :152 */
     const int64_t shortoend = oend - 14 - 18;              /* :153 */
     int64_t ip = 0, op = 0;
+    /* LZ4_readVLE (LL.tools.cs:165-193: read a byte, ip++, add it, stop when ip reaches `lencheck` or the byte was not 255), a
+     * wave-full of bytes at a time: lane l looks at stream byte ip + l, the first byte that is not 255 ends the field.  A run of
+     * 4 096 literals is 17 such bytes, a 4 MiB one 16 448: one step (or 257) instead of as many trips through the ring.  The bytes
+     * consumed and the sum (mod 2^32, like the reference's uint) are the scalar loop's: a step never reads past lencheck - 1
+     * except for the one byte the loop reads before it looks.  Returns true when ip reached lencheck (the caller decides what
+     * that means: nothing for a literal length, an error for a match length). */
+    auto read_vle = [&](uint32_t &length, int64_t lencheck) -> bool {
+        for (;;) {
+            win.ensure((uint32_t)ip + win.a0, lane);
+            const uint32_t b = win.read4((uint32_t)ip + win.a0 + (uint32_t)lane) & 0xffu;
+            const unsigned long long nz = ballot(b != 255u);
+            uint32_t n = nz ? (uint32_t)ctz64(nz) + 1u : 64u;
+            const int64_t avail = lencheck - ip;
+            if (avail < (int64_t)n) n = avail > 1 ? (uint32_t)avail : 1u;
+            const uint32_t last = readlane_u32(b, (int)n - 1);
+            length += 255u * (n - 1u) + last;
+            ip += n;
+            if (ip >= lencheck) return true;
+            if (last != 255u) return false;
+        }
+    };
 
     for (;;) {
         /* ======================= PARSE ======================= */
@@ -568,13 +589,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 if (length == RUN_MASK) {                      /* :228-243, LL.tools.cs:165-193 */
                     const int64_t lencheck = iend - RUN_MASK;
                     if (ip >= lencheck) { err = (int)(-ip) - 1; break; }   /* initial_error */
-                    uint32_t s;
-                    do {
-                        s = win.fetch((uint32_t)ip, lane) & 0xffu;
-                        ip++;
-                        length += s;
-                        if (ip >= lencheck) break;             /* loop_error: not fatal here */
-                    } while (s == 255u);
+                    (void)read_vle(length, lencheck);          /* loop_error: not fatal here */
                 }
                 const int64_t cpy = op + (int64_t)length;      /* :246-315 */
                 s_lpos = (uint32_t)ip; s_llen = length; s_out = (uint32_t)op;
@@ -613,14 +628,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
             if (need_match) {                                  /* _copy_match */
                 if (length == ML_MASK) {                       /* :326-334: any error is fatal */
                     const int64_t lencheck = iend - LASTLITERALS + 1;
-                    uint32_t s;
-                    do {
-                        s = win.fetch((uint32_t)ip, lane) & 0xffu;
-                        ip++;
-                        length += s;
-                        if (ip >= lencheck) { err = (int)(-ip) - 1; break; }
-                    } while (s == 255u);
-                    if (err) break;
+                    if (read_vle(length, lencheck)) { err = (int)(-ip) - 1; break; }
                 }
                 length += MINMATCH;
                 if (check_offset && match + chk_size < low_prefix) { err = (int)(-ip) - 1; break; }   /* :338 */

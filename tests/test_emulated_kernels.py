@@ -152,6 +152,26 @@ def test_decode_malformed_parity_with_oracle(emu, oracle):
         assert (dst[int(doff[i]) - 16:int(doff[i])] == 0xCD).all()
 
 
+from stream_cases import long_field_streams as _long_field_streams
+
+
+def test_long_length_fields_a_wave_full_at_a_time(emu, oracle):
+    """the scalar parser reads length fields 64 bytes per step (read_vle): same return values -- the error position included --
+    and bytes as the oracle's byte-at-a-time loop on long literal and match runs, cut and damaged inside the fields"""
+    rng = np.random.default_rng(77)
+    cases = _long_field_streams(oracle, rng)
+    comps, caps = [c for c, _, _ in cases], [k for _, k, _ in cases]
+    src, soff, slen = pack(comps)
+    dst, doff, dcap = arena(caps)
+    out = emu.decode_batch(src, soff, slen, dst, doff, dcap, flags=FLAG_RAW)
+    for i, (c, cap, defined) in enumerate(cases):
+        n, ref = oracle.decompress_safe(c, cap)
+        assert out[i] == n, f"stream {i} ({c.size} B, cap {cap}): kernel {out[i]} oracle {n}"
+        if n >= 0 and defined:
+            assert dst[int(doff[i]):int(doff[i]) + n].tobytes() == ref[:n].tobytes()
+        assert (dst[int(doff[i]) + cap:int(doff[i]) + cap + 16] == 0xCD).all()
+
+
 def test_decode_special_cases(emu, oracle):
     """LL64.dec.cs:160-172 and the LZ4Codec mapping (LZ4Codec.cs:104-115)"""
     comps = [np.array([0], np.uint8), np.array([0], np.uint8), np.array([0x10, 0x41], np.uint8), np.zeros(0, np.uint8),

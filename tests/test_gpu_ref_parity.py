@@ -167,3 +167,20 @@ def test_partial_and_dictionary_decode_vs_compiled_reference(ref, syslz4):
             assert out[i] == rn, (cls, i, out[i], rn)
             if rn > 0:
                 assert dst[int(doff[i]):int(doff[i]) + rn].tobytes() == rd[:rn].tobytes()
+
+
+def test_long_length_fields_vs_compiled_reference(ref, oracle):
+    """length fields that are long runs of 255 (4 KiB of random bytes: 17 bytes; 70 000 equal bytes: 274), whole, cut and damaged
+    inside the runs: LZ4_decompress_safe's return value (error position included) and bytes, against LL64.dec.cs compiled here"""
+    from stream_cases import long_field_streams
+    cases = long_field_streams(oracle, np.random.default_rng(78))
+    src, soff, slen = pack_blocks([c for c, _, _ in cases])
+    caps = np.array([k for _, k, _ in cases], np.int32)
+    dst, doff = make_arena(caps + 32, fill=0xCD)
+    out = LZ4Codec.DecodeBatchPacked(src, soff, slen, dst, doff, caps, flags=FLAG_RAW_RETURN)
+    for i, (c, cap, defined) in enumerate(cases):
+        n, want = ref.decompress_safe(c, int(cap))
+        assert out[i] == n, (i, c.size, cap, out[i], n)
+        if n > 0 and defined:
+            assert dst[int(doff[i]):int(doff[i]) + n].tobytes() == want[:n].tobytes()
+        assert (dst[int(doff[i]) + int(cap):int(doff[i]) + int(cap) + 32] == 0xCD).all()

@@ -259,3 +259,17 @@ def test_partial_and_dictionary_decode(ref, oracle, syslz4):
         for bad in _mutants(block, 60, rng):
             a, b = oracle.decompress_using_dict(bad, data.size, dictionary), ref.decompress_using_dict(bad, data.size, dictionary)
             assert a[0] == b[0] and (a[0] < 0 or a[1][:a[0]].tobytes() == b[1][:a[0]].tobytes())
+
+
+def test_long_length_fields(ref, oracle):
+    """length fields that are long runs of 255 (LL.tools.cs:165-193), whole, cut and damaged inside and right behind the runs:
+    the oracle's LZ4_decompress_safe returns what the compiled reference returns, bytes included where they are defined
+    (a damaged byte may make an offset 0: the reference copies the target onto itself there)"""
+    from stream_cases import long_field_streams
+    cases = long_field_streams(oracle, np.random.default_rng(78))
+    assert len(cases) > 300
+    for i, (c, cap, defined) in enumerate(cases):
+        a, b = oracle.decompress_safe(c, cap), ref.decompress_safe(c, cap)
+        assert a[0] == b[0], (i, c.size, cap)
+        if defined and a[0] > 0:
+            assert a[1][:a[0]].tobytes() == b[1][:a[0]].tobytes(), (i, c.size, cap)
