@@ -29,6 +29,7 @@
 #include "../../../../include/k4lz4.h"
 #include "k4lz4_decode.hpp"
 #include "k4lz4_encode_fast.hpp"
+#include "k4lz4_parse.hpp"
 #include "k4lz4_pickle.hpp"
 #include "k4lz4_segments.hpp"
 #include "k4lz4_encode_hc.hpp"
@@ -110,6 +111,9 @@ struct k4lz4_ctx {
     int pace_min_per_cu = 6;              /* K4LZ4_PACE_MIN: batches of more blocks per CU than this use the priorities (measured: 8 per CU +3 % encode, +7 % decode; 4 per CU -1 %, -4 %) */
     bool use_pace = true;                 /* K4LZ4_NO_PACE: without the late-blocks-first priorities */
     bool prof_gtab = false;               /* K4LZ4_PROF_GTAB: the instrumented encoder keeps its table in global memory */
+    uint8_t *d_parse = nullptr; size_t d_parse_cap = 0;       /* two-kernel fast encoder (k4lz4_parse.hpp): records, per-block counts, tables of the waves without an LDS table */
+    bool use_parse = true;                /* K4LZ4_NO_PARSE: fast-level batches go to the one-kernel encoders as before */
+    int parse_waves = 16;                 /* K4LZ4_PARSE_WAVES: blocks per workgroup (= per CU) of the parse kernel, at most PARSE_MAX_WAVES */
     bool trace = false;         /* K4LZ4_TRACE: host-pointer calls print where their time went (stderr) */
 };
 
@@ -387,6 +391,9 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
         const int64_t parts = (n + 16 * (int64_t)ctx->cu_count - 1) / (16 * (int64_t)ctx->cu_count);
         chunk_max = (n + parts - 1) / parts;
     }
+    const bool parse_path = kind == KIND_ENCODE && level < K4LZ4_L03_HC && ctx->use_parse && ctx->accel == 1 && !ctx->prof &&
+                            !(flags & (FLAG_SEGMENTS_OK | K4LZ4_FLAG_SEGMENTS | K4LZ4_FLAG_NO_SPLIT));
+    if (parse_path) chunk_max = std::min<int64_t>(chunk_max, (int64_t)k4::PARSE_MAX_WAVES * (int64_t)ctx->cu_count);      /* (its scratch is 128 KiB per block) */
     if (encode_like && level >= K4LZ4_L03_HC) {
         const int rc = launch_hc(ctx, kind == KIND_PICKLE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, stream, hostLen);
         if (rc != K4LZ4_OK || kind != KIND_ENCODE || !(flags & K4LZ4_FLAG_ALLOW_COPY)) return rc;
@@ -538,6 +545,35 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             if (two_kernels) a.split = d_hist + 2 * k4::COST_BUCKETS;
         }
         const unsigned wg4 = (unsigned)((cnt + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
+        /* LZ4Codec.Encode's case -- acceleration 1, no segments -- goes through the two-kernel encoder (k4lz4_parse.hpp): which
+         * sequences (one wavefront per block, 64 x K positions per round, 16 blocks per workgroup = per CU dealt from the cost
+         * order, the nine most expensive of a workgroup with their table in LDS), then their bytes (a throughput kernel), then
+         * whatever block the parse left alone (65 547 bytes and more, very short ones) by the one-kernel encoder. */
+        if (kind == KIND_ENCODE && parse_path) {
+            const int64_t waves = std::max<int64_t>(1, std::min<int64_t>(ctx->parse_waves, (cnt + ctx->cu_count - 1) / ctx->cu_count));
+            const int64_t nwg = (cnt + waves - 1) / waves;
+            const size_t o_meta = (size_t)cnt * k4::PARSE_REC_STRIDE * sizeof(uint2), o_gtab = (o_meta + (size_t)cnt * 8 + 255) & ~(size_t)255;
+            const size_t need = o_gtab + (waves > k4::PARSE_LDS_TABLES ? (size_t)nwg * k4::PARSE_MAX_WAVES * 16384 : 0);
+            if (need > ctx->d_parse_cap) K4_HIP(ctx, hipStreamSynchronize(stream));
+            const int rcp = grow(ctx, &ctx->d_parse, &ctx->d_parse_cap, need, false);
+            if (rcp != K4LZ4_OK) return rcp;
+            k4::ParseArgs pa{};
+            pa.recs = (uint2 *)ctx->d_parse; pa.meta = (uint32_t *)(ctx->d_parse + o_meta); pa.gtab = (uint32_t *)(ctx->d_parse + o_gtab);
+            pa.nwg = (uint32_t)nwg;
+            hipLaunchKernelGGL(k4::k4_parse_kernel, dim3((unsigned)nwg), dim3((unsigned)(64 * waves)), 0, stream, a, pa);
+            hipLaunchKernelGGL(k4::k4_emit_kernel, dim3((unsigned)((cnt + k4::EMIT_WAVES_PER_WG - 1) / k4::EMIT_WAVES_PER_WG)), dim3(64 * k4::EMIT_WAVES_PER_WG), 0, stream, a, pa);
+            bool rest = true;          /* (where the host knows the lengths it knows whether there is anything left) */
+            if (hostLen) {
+                rest = false;
+                for (int64_t i = 0; i < cnt && !rest; i++) rest = hostLen[first + i] < (int32_t)k4::PARSE_MIN_LEN || hostLen[first + i] >= k4::LIMIT_64K;
+            }
+            if (rest)
+                hipLaunchKernelGGL(k4::k4_encode_fast_rest_kernel, dim3((unsigned)((cnt + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, a, pa);
+            if (flags & K4LZ4_FLAG_ALLOW_COPY)
+                hipLaunchKernelGGL(k4::k4_allow_copy_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, stream, a);
+            K4_HIP(ctx, hipGetLastError());
+            continue;
+        }
         switch (kind) {
         case KIND_ENCODE:
             if (a.prof && !ctx->prof_stamp) {
@@ -1303,6 +1339,8 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (const char *e = getenv("K4LZ4_SEG_DIV")) ctx->seg_div = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("K4LZ4_PICKLE_SPLIT_MIN")) ctx->pickle_split_min = std::max(0, atoi(e));
     if (const char *e = getenv("K4LZ4_STAGE_THREADS")) ctx->stage_threads = std::max(0, std::min(63, atoi(e) - 1));
+    ctx->use_parse = getenv("K4LZ4_NO_PARSE") == nullptr;
+    if (const char *e = getenv("K4LZ4_PARSE_WAVES")) ctx->parse_waves = std::max(1, std::min(k4::PARSE_MAX_WAVES, atoi(e)));
     ctx->trace = getenv("K4LZ4_TRACE") != nullptr;
     if (e != hipSuccess) { delete ctx; return hip_fail(nullptr, e, "hipStreamCreate"); }
     *out = ctx;
@@ -1341,6 +1379,7 @@ void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_pace) (void)hipFree(ctx->d_pace);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
+    if (ctx->d_parse) (void)hipFree(ctx->d_parse);
     if (ctx->d_dict) (void)hipFree(ctx->d_dict);
     if (ctx->d_src) (void)hipFree(ctx->d_src);
     if (ctx->d_dst) (void)hipFree(ctx->d_dst);

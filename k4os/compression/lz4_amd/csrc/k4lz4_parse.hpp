@@ -1,0 +1,664 @@
+/*
+ * k4lz4_parse.hpp -- the fast-level encoder in two kernels: PARSE (which sequences) and EMIT (their bytes).
+ *
+ * Replaces, for batches of blocks below 65 547 bytes at acceleration 1 -- LZ4Codec.Encode's case
+ * (src/K4os.Compression.LZ4/LZ4Codec.cs:40-52 -> Engine/LLxx.cs:65-75) --, the same reference code as
+ * k4lz4_encode_fast.hpp:
+ *   LL64.LZ4_compress_generic, byU16 arm    Engine/x64/LL64.fast.cs:34-513
+ *   hash4 / table get / put                 Engine/LL.tools.cs:46-51,:80-148
+ *   LZ4_count                               Engine/x64/LL64.tools.cs:86-133
+ * with byte-identical output.  Blocks outside that case are left to the kernels of k4lz4_encode_fast.hpp
+ * (k4_encode_fast_rest_kernel below).
+ *
+ * Why two kernels.  One wavefront owns one block and its time is one long chain of dependent instructions; what the
+ * reference's loop decides -- where a match starts, which earlier position it refers to, how long it is -- is
+ * 8 bytes per sequence, and everything else (backward extension LL64.fast.cs:237-242, token and length bytes :244-382,
+ * the literal copies, the output-limit checks) follows from those 8 bytes and the source alone.  k4_parse_kernel
+ * writes the 8 bytes; k4_emit_kernel, a throughput kernel, turns them into the block.
+ *
+ * How the parse works.  A ROUND looks at 64 * K consecutive probe positions from the cursor (K sub-windows of one
+ * position per lane); all of a round's trips to memory -- the source bytes, the table look-ups, the 16 bytes around every
+ * candidate -- are made for the K sub-windows together, before the first decision, so a round waits for each of them
+ * once per 64 * K positions.  The decisions are then a scalar chain over one sub-window after the other: first lane at
+ * or after the cursor that stops the chain -> lane after its match (k4lz4_encode_fast.hpp, hop_chain).
+ *   A probe's candidate is the table entry as it stood when the round began unless an earlier VISITED position of the
+ * round has the same hash.  Lanes whose hash another lane of the round shares are found through one LDS bit per hash
+ * value; such a lane stops the chain, and its candidate is worked out right there from what has been visited so far --
+ * lazily, in scalar code, for the few lanes the cursor really reaches -- instead of for every lane up front.
+ *   The puts of a round (every visited position, and position end-2 behind every match, LL64.fast.cs:394) are made at
+ * its end: lanes nobody shares a hash with in one store, the others one by one in position order.
+ * After 66 probes without a match the reference's step grows (LL64.fast.cs:156-172): those rounds probe the strided
+ * positions with the same machinery and end at their first match.
+ */
+#pragma once
+#include "k4lz4_encode_fast.hpp"
+#include <type_traits>
+#ifdef K4_PARSE_DEBUG
+#include <stdio.h>
+#include <stdlib.h>
+#endif
+
+namespace k4 {
+
+#ifndef K4_PARSE_K
+#define K4_PARSE_K 2
+#endif
+
+constexpr uint32_t PARSE_REC_STRIDE = 16384u;        /* records per block: a block below LIMIT_64K has fewer than (65546 - 6) / 4 + 1 sequences */
+constexpr uint32_t PARSE_MIN_LEN = 128u;             /* shorter blocks go to the other kernels (the clamped loads below want 16 readable bytes somewhere) */
+constexpr uint32_t PARSE_REST = 0xffffffffu;         /* meta[2 b]: this block is for k4_encode_fast_rest_kernel */
+constexpr int PARSE_MAX_WAVES = 16;                  /* waves (= blocks) per workgroup: one workgroup per CU */
+constexpr int PARSE_LDS_TABLES = 9;                  /* of which so many have their table in LDS (9 x 16 KiB + 16 x 512 B of 160 KiB) */
+constexpr int PARSE_SEEN_DWORDS = 128;               /* one bit per two hash values */
+
+struct ParseArgs {
+    uint2 *recs;            /* PARSE_REC_STRIDE records per block: x = position of the match (before backward extension),
+                             * y = offset | (match length - MINMATCH) << 16 */
+    uint32_t *meta;         /* per block: [0] number of sequences or PARSE_REST, [1] spare */
+    uint32_t *gtab;         /* 4096 dwords per (workgroup, wave) for the waves without an LDS table */
+    uint32_t nwg;           /* workgroups of the parse launch: block of (workgroup w, wave s) = order[s * nwg + w] */
+};
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+
+template <int N> using ic = std::integral_constant<int, N>;
+
+/* bytes [s, s+16) of a stream of which w holds [a, a+16), a <= s (zeros behind the end) */
+__device__ __forceinline__ void shift16(uint32_t &w0, uint32_t &w1, uint32_t &w2, uint32_t &w3, uint32_t sh)
+{
+    if (sh == 0u) return;
+    unsigned long long lo = ((unsigned long long)w1 << 32) | w0, hi = ((unsigned long long)w3 << 32) | w2;
+    if (sh >= 16u) { lo = 0; hi = 0; }
+    else if (sh >= 8u) { lo = sh == 8u ? hi : hi >> (8u * (sh - 8u)); hi = 0; }
+    else { lo = (lo >> (8u * sh)) | (hi << (64u - 8u * sh)); hi >>= 8u * sh; }
+    w0 = (uint32_t)lo; w1 = (uint32_t)(lo >> 32); w2 = (uint32_t)hi; w3 = (uint32_t)(hi >> 32);
+}
+
+/* equal bytes of two 12-byte strings given as xors of their words (no branches: every lane of a round does this) */
+__device__ __forceinline__ uint32_t ext12(uint32_t x0, uint32_t x1, uint32_t x2)
+{
+    const uint32_t t0 = min((uint32_t)(__ffs((int)x0) - 1), 32u);       /* __ffs(0) - 1 = 0xffffffff */
+    const uint32_t t1 = min((uint32_t)(__ffs((int)x1) - 1), 32u);
+    const uint32_t t2 = min((uint32_t)(__ffs((int)x2) - 1), 32u);
+    const uint32_t hi = t1 + (t1 == 32u ? t2 : 0u);
+    return (t0 + (t0 == 32u ? hi : 0u)) >> 3;
+}
+
+/* hop word: bits 0-6 lane after the match (64 and more: outside the sub-window, 127 = "127 or more"), and the reasons to
+ * leave the tight chain (all inside hop_chain's 0xf40): 0x40 = bit 6 of the lane, 0x100 the match runs past the 12 known
+ * bytes, 0x200 a lane that shares its hash with an earlier lane of the round (0x1000 on top: its table candidate is no
+ * hit), 0x400 the block ends behind this match (LL64.fast.cs:391), 0x800 no probe here: the block's last literals begin
+ * (LL64.fast.cs:172) */
+constexpr uint32_t HOP_LONG = 0x100u, HOP_LAZY = 0x200u, HOP_END = 0x400u, HOP_INVALID = 0x800u, HOP_TABMISS = 0x1000u;
+
+/*
+ * LL64.LZ4_compress_generic (byU16, noDict, acceleration 1) for one block, sequences only.  `tab`: the block's 8192 x u16
+ * table (LDS, or global memory with GT), `seen`: PARSE_SEEN_DWORDS dwords of LDS.  Returns the number of records written.
+ */
+template <int K, bool GT>
+__device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32_t U, uint2 *recs, uint16_t *tab, uint32_t *seen, const int lane)
+{
+    const uint32_t mfl1 = U - (uint32_t)MFLIMIT + 1u;          /* mflimitPlusOne */
+    const uint32_t matchlimit = U - (uint32_t)LASTLITERALS;
+    const uint32_t last_valid = U - (uint32_t)MFLIMIT;         /* a probe at p happens iff p + step <= mflimitPlusOne (:172, :391) */
+    const unsigned long long me = 1ull << lane, below_me = me - 1ull;
+
+    for (int k = lane; k < 1024; k += 64) ((uint4 *)tab)[k] = make_uint4(0u, 0u, 0u, 0u);     /* LZ4_initStream; put(hash(0), 0) stores a 0 (:119-122) */
+    for (int k = lane; k < PARSE_SEEN_DWORDS; k += 64) seen[k] = 0u;
+    wave_sync();
+
+    uint32_t c = 1u;              /* position of lane 0 of the round */
+    uint32_t sbase = 1u;          /* first probe of the running search (:466: the position behind a match + 1) */
+    bool test = false;            /* c is the position right behind a match (:393-463) */
+    uint32_t sj = 0u;             /* != 0: the search has used up its 66 contiguous probes; next probe is number sj (0-based) */
+    uint32_t nrec = 0u;
+
+    /* per lane and sub-window */
+    uint32_t seq[K], n0[K], n1[K], n2[K];     /* the 16 source bytes at the position */
+    uint32_t h[K], cpos[K], hop[K], ecode[K], pos[K];
+    bool val[K];
+    /* wave-uniform per sub-window */
+    unsigned long long hmx[K], hits[K], Dm[K], Gall[K], vis[K];
+    uint32_t qent[K];
+    bool tent[K];
+    /* the next round's source bytes */
+    U128u pw[K];
+    uint32_t pre2 = 0u;
+
+    auto prepare = [&]() {
+        if (sj == 0u) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const uint32_t p = c + 64u * (uint32_t)k + (uint32_t)lane;
+                const uint32_t a = p < U - 16u ? p : U - 16u;
+                pw[k] = ld128u(src + a);
+            }
+            pre2 = ld32u(src + (c >= 2u ? c - 2u : 0u));
+        } else {
+            const uint32_t p = sbase + probe_offset(sj + (uint32_t)lane, 1u);
+            const uint32_t a = p < U - 16u ? p : U - 16u;
+            pw[0] = ld128u(src + a);
+        }
+    };
+    prepare();
+
+    /* lanes of sub-window k whose position was put into the table, from the hits `hk` of its chain: not the lanes before its entry
+     * cursor (except the one two before it when the cursor came from a match, :394), not the lanes inside matches (except the lane
+     * two before a match's end), none from lane `upto` on */
+    auto visited = [&](auto kc, unsigned long long hk, uint32_t upto) -> unsigned long long {
+        constexpr int k = decltype(kc)::value;
+        const unsigned long long hb = hk & below_me;
+        const int ph = hb ? 63 - (int)__clzll((long long)hb) : 0;
+        const uint32_t qp = (uint32_t)__shfl((int)hop[k], ph) & 127u;
+        const bool in = hb != 0ull && (uint32_t)lane < qp && (uint32_t)lane + 2u != qp;
+        const bool before = (uint32_t)lane < qent[k] && !(tent[k] && (uint32_t)lane + 2u == qent[k]);
+        const unsigned long long m = ballot(!in && !before && val[k]);
+        return upto < 64u ? m & ((1ull << upto) - 1ull) : m;
+    };
+
+    /* One round.  PLAIN: every lane of every sub-window is a probe, its 16 bytes and its candidate's lie inside the block, no match
+     * measured from them reaches matchlimit or the last probe position -- no clamping, no lane masks anywhere; the other form does
+     * the block's last rounds and the strided ones.  Returns false when the block is done. */
+    auto round = [&](auto plain_c) -> bool {
+        constexpr bool plain = decltype(plain_c)::value;
+        const bool strided = plain ? false : sj != 0u;
+        const uint32_t c0 = c;
+        const int KK = strided ? 1 : K;
+
+        /* ---------------- front: positions, hashes, candidates, what each lane would do as a hit ---------------- */
+        K4_PHASE("front");
+        uint32_t cand[K];
+        bool flagged[K];
+        uint32_t hE2 = 0xffffffffu;
+        if (test) hE2 = FastTable<1>::hash_of(pre2, 0u);         /* the put of c - 2 (:394): made with the round's other puts, seen by its look-ups */
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (k >= KK) { val[k] = false; h[k] = 0u; pos[k] = 0u; hop[k] = 0u; cpos[k] = 0u; ecode[k] = 0u; seq[k] = n0[k] = n1[k] = n2[k] = 0u; cand[k] = 0u; flagged[k] = false; continue; }
+            uint32_t p;
+            if (strided) {
+                p = sbase + probe_offset(sj + (uint32_t)lane, 1u);
+                const uint32_t pn = sbase + probe_offset(sj + (uint32_t)lane + 1u, 1u);
+                val[k] = pn <= mfl1 && pn > p;
+            } else {
+                p = c0 + 64u * (uint32_t)k + (uint32_t)lane;
+                val[k] = plain || p <= last_valid;
+            }
+            pos[k] = p;
+            uint32_t w0 = pw[k].v[0], w1 = pw[k].v[1], w2 = pw[k].v[2], w3 = pw[k].v[3];
+            if (!plain) shift16(w0, w1, w2, w3, p < U - 16u ? 0u : p - (U - 16u));
+            seq[k] = w0; n0[k] = w1; n1[k] = w2; n2[k] = w3;
+            h[k] = FastTable<1>::hash_of(w0, 0u);
+            uint32_t cd = 0u;
+            bool fl = false;
+            if (val[k]) {
+                cd = tab[h[k]];
+                const uint32_t bit = h[k] >> 1;
+                fl = ((atomicOr(&seen[bit >> 5], 1u << (bit & 31u)) >> (bit & 31u)) & 1u) != 0u;
+            }
+            if (h[k] == hE2) cd = c0 - 2u;
+            cand[k] = cd;
+            flagged[k] = fl;
+        }
+        /* the candidates' bytes: the round's one dependent trip to memory */
+        U128u cw[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (k >= KK) { cw[k].v[0] = cw[k].v[1] = cw[k].v[2] = cw[k].v[3] = 0u; continue; }
+            const uint32_t a = plain ? cand[k] : (cand[k] < U - 16u ? cand[k] : U - 16u);
+            cw[k] = ld128u(src + a);
+        }
+        /* (every lane has recorded its hash by now: wipe the words this round touched) */
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < K; k++) if (k < KK && val[k]) seen[h[k] >> 6] = 0u;
+
+        /* lanes that share a hash: Dm = those with an earlier lane of the round in their group, Gall = all of them */
+        K4_PHASE("groups");
+#pragma unroll
+        for (int k = 0; k < K; k++) { Dm[k] = 0ull; Gall[k] = 0ull; }
+        {
+            unsigned long long fl[K];
+            unsigned long long any = 0ull;
+#pragma unroll
+            for (int k = 0; k < K; k++) { fl[k] = ballot(flagged[k]); any |= fl[k]; }
+            if (any) {
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    while (fl[k]) {
+                        const int j = ctz64(fl[k]);
+                        const uint32_t hj = readlane_u32(h[k], j);
+                        unsigned long long m[K];
+                        uint32_t members = 0u;
+#pragma unroll
+                        for (int kk = 0; kk < K; kk++) { m[kk] = ballot(val[kk] && h[kk] == hj); members += (uint32_t)__popcll(m[kk]); fl[kk] &= ~m[kk]; }
+                        fl[k] &= ~(1ull << j);
+                        if (members >= 2u) {
+                            bool first = true;
+#pragma unroll
+                            for (int kk = 0; kk < K; kk++) {
+                                Gall[kk] |= m[kk];
+                                if (m[kk]) { Dm[kk] |= first ? (m[kk] & (m[kk] - 1ull)) : m[kk]; first = false; }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        /* now the candidate bytes: hit or not, how far the match goes, the hop word */
+        K4_PHASE("words");
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (k >= KK) { hmx[k] = 0ull; hits[k] = 0ull; vis[k] = 0ull; qent[k] = 64u; tent[k] = false; continue; }
+            uint32_t v0 = cw[k].v[0], v1 = cw[k].v[1], v2 = cw[k].v[2], v3 = cw[k].v[3];
+            if (!plain) shift16(v0, v1, v2, v3, cand[k] < U - 16u ? 0u : cand[k] - (U - 16u));
+            const bool hit = val[k] && v0 == seq[k];
+            uint32_t e = ext12(v1 ^ n0[k], v2 ^ n1[k], v3 ^ n2[k]);
+            uint32_t word;
+            if (plain) {
+                word = ((uint32_t)lane + (uint32_t)MINMATCH + e) | (e == 12u ? HOP_LONG : 0u);
+            } else {
+                const uint32_t fwd_max = matchlimit - (pos[k] + (uint32_t)MINMATCH);       /* (of no consequence where the lane is no probe) */
+                const bool lng = e == 12u && fwd_max > 12u && fwd_max < 0x80000000u;
+                if (e > fwd_max) e = fwd_max;
+                const uint32_t qn = strided ? 127u : (uint32_t)lane + (uint32_t)MINMATCH + e;
+                word = qn | (lng ? HOP_LONG : 0u) | (pos[k] + (uint32_t)MINMATCH + e >= mfl1 ? HOP_END : 0u) | (val[k] ? 0u : HOP_INVALID);
+            }
+            const bool lazy = ((Dm[k] >> lane) & 1ull) != 0ull;
+            if (lazy) word |= HOP_LAZY | (hit ? 0u : HOP_TABMISS);
+            hop[k] = word;
+            ecode[k] = e;
+            cpos[k] = cand[k];
+            hmx[k] = ballot(hit) | Dm[k] | (plain ? 0ull : ballot(!val[k]));
+            hits[k] = 0ull;
+            vis[k] = 0ull;
+            qent[k] = 64u;
+            tent[k] = false;
+        }
+
+        /* ---------------- the chain ---------------- */
+        K4_PHASE("chain");
+        /* a hop word for lane f of sub-window k worked out in scalar code: the lane's candidate is lane j of sub-window kk */
+        auto word_from_lane = [&](auto kc, int f, auto kkc, int j) -> uint32_t {
+            constexpr int k = decltype(kc)::value, kk = decltype(kkc)::value;
+            if (readlane_u32(seq[k], f) != readlane_u32(seq[kk], j)) return 0xffffffffu;
+            const uint32_t p = readlane_u32(pos[k], f), cp = readlane_u32(pos[kk], j);
+            uint32_t e = ext12(readlane_u32(n0[k], f) ^ readlane_u32(n0[kk], j), readlane_u32(n1[k], f) ^ readlane_u32(n1[kk], j),
+                               readlane_u32(n2[k], f) ^ readlane_u32(n2[kk], j));
+            const uint32_t fwd_max = matchlimit - (p + (uint32_t)MINMATCH);
+            const bool lng = e == 12u && fwd_max > 12u;
+            if (e > fwd_max) e = fwd_max;
+            const uint32_t qn = strided ? 127u : (uint32_t)f + (uint32_t)MINMATCH + e;
+            const uint32_t word = qn | (lng ? HOP_LONG : 0u) | (p + (uint32_t)MINMATCH + e >= mfl1 ? HOP_END : 0u);
+            if (lane == f) { hop[k] = word; ecode[k] = e; cpos[k] = cp; }
+            return word;
+        };
+        /* lane f of sub-window k shares its hash with earlier lanes of the round: its candidate is the latest of them that has
+         * been visited, else what the table held.  Returns its hop word, 0xffffffff when it is no hit. */
+        auto resolve = [&](auto kc, int f) -> uint32_t {
+            constexpr int k = decltype(kc)::value;
+            const uint32_t hf = readlane_u32(h[k], f);
+            {
+                const unsigned long long m = ballot(h[k] == hf) & ((1ull << f) - 1ull) & visited(kc, hits[k] & ~(1ull << f), 64u);
+                if (m) return word_from_lane(kc, f, kc, 63 - (int)__clzll((long long)m));
+            }
+            if constexpr (k >= 1) {
+                const unsigned long long m = ballot(val[k - 1] && h[k - 1] == hf) & visited(ic<k - 1>{}, hits[k - 1], 64u);
+                if (m) return word_from_lane(kc, f, ic<k - 1>{}, 63 - (int)__clzll((long long)m));
+            }
+            if constexpr (k >= 2) {
+                const unsigned long long m = ballot(val[k - 2] && h[k - 2] == hf) & visited(ic<k - 2>{}, hits[k - 2], 64u);
+                if (m) return word_from_lane(kc, f, ic<k - 2>{}, 63 - (int)__clzll((long long)m));
+            }
+            if constexpr (k >= 3) {
+                const unsigned long long m = ballot(val[k - 3] && h[k - 3] == hf) & visited(ic<k - 3>{}, hits[k - 3], 64u);
+                if (m) return word_from_lane(kc, f, ic<k - 3>{}, 63 - (int)__clzll((long long)m));
+            }
+            const uint32_t w = readlane_u32(hop[k], f);
+            if (w & HOP_TABMISS) return 0xffffffffu;
+            const uint32_t word = w & ~HOP_LAZY;
+            if (lane == f) hop[k] = word;
+            return word;
+        };
+
+        int outcome = 0;               /* 0 every sub-window walked, the search goes on; 1 the next round starts behind a match, at `anchor`;
+                                        * 2 the block's last literals begin; 3 the search's contiguous probes are used up */
+        uint32_t anchor = 0u;
+        uint32_t upto_last = 64u;      /* the sub-window the round ended in: lanes from here on were not visited */
+        int klast = KK - 1;            /* the sub-window the round ended in */
+        {
+            uint32_t q = 0u;
+            bool etest = test;
+            bool done = false;
+            auto walk = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (done || k >= KK) return;
+                const uint32_t w0 = c0 + 64u * (uint32_t)k;
+                qent[k] = q;
+                tent[k] = etest;
+                klast = k;
+                bool limited = false;
+                unsigned long long limmask = ~0ull;
+                uint32_t limlane = 64u;
+                if (!strided) {
+                    /* the search's 66th probe (:156-172: the step grows behind it) */
+                    const int lim = (int)(sbase + 65u) - (int)w0;
+                    if (lim < (int)q) { outcome = 3; upto_last = q; done = true; return; }
+                    if (lim < 63) { limited = true; limlane = (uint32_t)lim; limmask = (2ull << lim) - 1ull; }
+                }
+                for (;;) {
+                    uint32_t hv = 0u;
+                    int f = 0;
+                    unsigned long long stop;
+                    unsigned long long hm = hmx[k];
+                    if (limited) {
+                        /* only stops up to the limit count, and only until the first hop (a new search begins behind it): one at a time */
+                        const unsigned long long t = hm & limmask & (~0ull << q);
+                        if (!t) { outcome = 3; upto_last = limlane + 1u; done = true; return; }
+                        hm = t & (0ull - t);
+                    }
+                    hop_chain(hm, hop[k], q, hits[k], f, hv, stop);
+                    if (!stop) {
+                        if (limited) { limited = false; continue; }        /* that one stop was a plain hop */
+                        if (hits[k]) {             /* where the running search began: behind the last match */
+                            const int lf = 63 - (int)__clzll((long long)hits[k]);
+                            sbase = w0 + (readlane_u32(hop[k], lf) & 127u) + 1u;
+                        }
+                        q = 0u;
+                        etest = false;
+                        return;
+                    }
+                    if (hv & HOP_INVALID) { hits[k] &= ~(1ull << f); outcome = 2; upto_last = (uint32_t)f; done = true; return; }
+                    if (hv & HOP_LAZY) {
+                        hv = resolve(kc, f);
+                        if (hv == 0xffffffffu) {
+                            hits[k] &= ~(1ull << f);
+                            hmx[k] &= ~(1ull << f);
+                            q = (uint32_t)f + 1u;
+                            if (q >= 64u) {        /* (the lane was the sub-window's last) */
+                                if (limited) { outcome = 3; upto_last = limlane + 1u; done = true; return; }
+                                if (hits[k]) { const int lf = 63 - (int)__clzll((long long)hits[k]); sbase = w0 + (readlane_u32(hop[k], lf) & 127u) + 1u; }
+                                q = 0u; etest = false; return;
+                            }
+                            continue;
+                        }
+                    }
+                    const uint32_t p = strided ? readlane_u32(pos[k], f) : w0 + (uint32_t)f;
+                    uint32_t e_end;
+                    if (hv & HOP_LONG) {                               /* :326-329 beyond the 12 known bytes */
+                        const uint32_t match = readlane_u32(cpos[k], f);
+                        const uint32_t code = 12u + wave_count(src + p + 16u, src + match + 16u, matchlimit - (p + 16u), lane);
+                        e_end = p + (uint32_t)MINMATCH + code;
+                        const uint32_t qf = (uint32_t)f + (uint32_t)MINMATCH + code;
+                        if (lane == f) { ecode[k] = code; hop[k] = (!strided && qf < 127u) ? qf : 127u; }
+                    } else {
+                        e_end = strided ? p + (uint32_t)MINMATCH + readlane_u32(ecode[k], f) : w0 + (hv & 127u);
+                    }
+                    anchor = e_end;
+                    sbase = e_end + 1u;
+                    limited = false;
+                    if (e_end >= mfl1) { outcome = 2; upto_last = (uint32_t)f + 1u; done = true; return; }      /* :391 */
+                    const uint32_t nq = e_end - w0;
+                    if (strided || nq >= 128u || (nq >= 64u && k + 1 >= KK)) { outcome = 1; upto_last = (uint32_t)f + 1u; done = true; return; }
+                    if (nq >= 64u) { q = nq - 64u; etest = true; return; }
+                    q = nq;
+                }
+            };
+            walk(ic<0>{});
+            if constexpr (K >= 2) walk(ic<1>{});
+            if constexpr (K >= 3) walk(ic<2>{});
+            if constexpr (K >= 4) walk(ic<3>{});
+        }
+
+        /* ---------------- where the next round starts; its source loads go out now ---------------- */
+        K4_PHASE("next");
+        if (outcome == 1) { c = anchor; test = true; sj = 0u; }
+        else if (outcome == 0) {
+            if (strided) sj += 64u;
+            else {
+                c = c0 + 64u * (uint32_t)K;
+                test = false;
+                if (c - sbase >= 66u) sj = 66u;
+            }
+        }
+        else if (outcome == 3) { test = false; sj = 66u; }
+        if (outcome != 2) prepare();
+
+        /* ---------------- the visited lanes ---------------- */
+        K4_PHASE("visited");
+        {
+            auto fin = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (k >= KK) return;
+                if (k > klast) { vis[k] = 0ull; return; }
+                uint32_t upto = k == klast ? upto_last : 64u;
+                /* a match that ends the round: the lanes behind its first are not visited -- except, where the round goes on behind the
+                 * match, the one two before its end if that is still a lane here (:394; the next round puts it once more) */
+                unsigned long long m = visited(kc, hits[k], 64u);
+                if (upto < 64u) {
+                    unsigned long long keep = (1ull << upto) - 1ull;
+                    if (outcome == 1 && k == klast && !strided) {
+                        const uint32_t e2 = anchor - 2u - (c0 + 64u * (uint32_t)k);
+                        if (e2 < 64u && e2 >= upto) keep |= 1ull << e2;
+                    }
+                    m &= keep;
+                }
+                vis[k] = m;
+            };
+            fin(ic<0>{});
+            if constexpr (K >= 2) fin(ic<1>{});
+            if constexpr (K >= 3) fin(ic<2>{});
+            if constexpr (K >= 4) fin(ic<3>{});
+        }
+
+        /* ---------------- records ---------------- */
+        K4_PHASE("records");
+        {
+            uint32_t at = nrec;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if (k >= KK) continue;
+                if (hits[k]) {
+                    if ((hits[k] >> lane) & 1ull)
+                        recs[at + (uint32_t)__popcll(hits[k] & below_me)] = make_uint2(pos[k], (pos[k] - cpos[k]) | (ecode[k] << 16));
+                    at += (uint32_t)__popcll(hits[k]);
+                }
+            }
+            nrec = at;
+        }
+        if (outcome == 2) return false;
+
+        /* ---------------- the round's puts ---------------- */
+        K4_PHASE("commit");
+#ifdef K4_PARSE_DEBUG
+        if (lane == 0 && getenv("K4DBG") && c0 + 64u * K > (uint32_t)atoi(getenv("K4DBG")) && c0 < (uint32_t)atoi(getenv("K4DBG")) + 200u) {
+            printf("round c0=%u test=%d strided=%d plain=%d outcome=%d anchor=%u klast=%d upto=%u sbase=%u hE2=%x\n", c0, (int)(hE2 != 0xffffffffu), (int)strided, (int)plain, outcome, anchor, klast, upto_last, sbase, hE2);
+            for (int k = 0; k < K; k++) printf("   k=%d qent=%u tent=%d hmx=%016llx hits=%016llx vis=%016llx Dm=%016llx Gall=%016llx\n", k, qent[k], (int)tent[k], hmx[k], hits[k], vis[k], Dm[k], Gall[k]);
+        }
+#endif
+        if (hE2 != 0xffffffffu && lane == 0) tab[hE2] = (uint16_t)(c0 - 2u);
+        if (GT) wave_sync(); else __builtin_amdgcn_wave_barrier();      /* a lane of the round may put the same slot: it comes second */
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (k >= KK) continue;
+            if ((vis[k] & ~Gall[k]) >> lane & 1ull) tab[h[k]] = (uint16_t)pos[k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (k >= KK) continue;
+            unsigned long long g = vis[k] & Gall[k];
+            while (g) {
+                const int j = ctz64(g);
+                g &= g - 1ull;
+                if (GT) wave_sync(); else __builtin_amdgcn_wave_barrier();
+                if (lane == j) tab[h[k]] = (uint16_t)pos[k];
+            }
+        }
+        wave_sync();
+        return true;
+    };
+    for (;;) {
+        const bool plain = sj == 0u && c + 64u * (uint32_t)K + 28u <= U;
+        if (plain) { if (!round(std::true_type{})) break; }
+        else if (!round(std::false_type{})) break;
+    }
+    return nrec;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+
+template <int K>
+__device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const ParseArgs &p, uint32_t *lds)
+{
+    const int lane = lane_id();
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t waves = blockDim.x >> 6;
+    const long long idx = (long long)wave * (long long)p.nwg + (long long)blockIdx.x;
+    if (idx >= a.n) return;
+    const long long b = a.order ? (long long)uni(a.order[idx]) : idx;
+    const int src_len = a.srcLen[b];
+    uint32_t *meta = p.meta + 2ull * (unsigned long long)b;
+    if (src_len < (int)PARSE_MIN_LEN || src_len >= LIMIT_64K || a.accel != 1) {
+        if (lane == 0) { meta[0] = PARSE_REST; meta[1] = 0u; }
+        return;
+    }
+    const uint8_t *src = a.src + a.srcOff[b];
+    uint2 *recs = p.recs + (unsigned long long)b * PARSE_REC_STRIDE;
+    const uint32_t lds_tables = waves < (uint32_t)PARSE_LDS_TABLES ? waves : (uint32_t)PARSE_LDS_TABLES;
+    uint32_t *seen = lds + 4096u * (uint32_t)PARSE_LDS_TABLES + (uint32_t)PARSE_SEEN_DWORDS * wave;
+    uint32_t n;
+    if (wave < lds_tables) n = parse_block<K, false>(src, (uint32_t)src_len, recs, (uint16_t *)(lds + 4096u * wave), seen, lane);
+    else n = parse_block<K, true>(src, (uint32_t)src_len, recs, (uint16_t *)(p.gtab + 4096ull * ((unsigned long long)blockIdx.x * PARSE_MAX_WAVES + wave)), seen, lane);
+    if (lane == 0) { meta[0] = n; meta[1] = 0u; }
+}
+
+constexpr int PARSE_LDS_DWORDS = 4096 * PARSE_LDS_TABLES + PARSE_SEEN_DWORDS * PARSE_MAX_WAVES;
+
+__global__ __launch_bounds__(64 * PARSE_MAX_WAVES) void k4_parse_kernel(BatchArgs a, ParseArgs p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[PARSE_LDS_DWORDS];
+    parse_kernel_body<K4_PARSE_K>(a, p, lds);
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+
+/*
+ * EMIT: LL64.fast.cs:237-382 and :469-503 for one block from its records, one wavefront per block, 64 sequences at a time, one per
+ * lane: backward extension (:237-242), the sizes, their prefix sum, the output-limit checks (:251-255, :346-350, :471-476), token /
+ * length bytes / literals / offset.  Runs of more than 32 literals and length fields of more than one byte are moved by the whole
+ * wave.
+ */
+constexpr int EMIT_WAVES_PER_WG = 4;
+
+__device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, uint8_t *dst, const int dst_cap, const uint2 *recs, const uint32_t nseq, const int lane)
+{
+    const bool limited = dst_cap < compress_bound((int)U);         /* :524 */
+    const uint64_t olimit = (uint64_t)(dst_cap < 0 ? 0 : dst_cap);
+    uint32_t op = 0u, emitted_to = 0u;
+    uint2 rn = make_uint2(0u, 0u);
+    if ((uint32_t)lane < nseq) rn = recs[lane];
+    for (uint32_t base = 0u; base < nseq; base += 64u) {
+        const uint32_t n = nseq - base < 64u ? nseq - base : 64u;
+        const bool mine = (uint32_t)lane < n;
+        const uint2 r = rn;
+        if (base + 64u + (uint32_t)lane < nseq) rn = recs[base + 64u + (uint32_t)lane];      /* the next 64, while these are written */
+        const uint32_t pos = r.x, cpos = r.x - (r.y & 0xffffu), code = r.y >> 16;
+        const uint32_t end = mine ? pos + (uint32_t)MINMATCH + code : 0u;
+        const uint32_t prev = (uint32_t)__shfl_up((int)end, 1);
+        const uint32_t ls = lane == 0 ? emitted_to : prev;
+        const uint32_t lit0 = mine ? pos - ls : 0u;
+        const uint32_t maxback = lit0 < cpos ? lit0 : cpos;                /* 0 right after a match */
+        uint32_t back = 0u;
+        if (mine && maxback != 0u) {
+            if (cpos >= 4u) {                                           /* the four bytes before both at once, the rare longer run byte by byte */
+                const uint32_t y = ld32u(src + pos - 4u) ^ ld32u(src + cpos - 4u);
+                back = y ? (uint32_t)__clz(y) >> 3 : 4u;
+                if (back > maxback) back = maxback;
+                if (back == 4u) while (back < maxback && src[pos - 1u - back] == src[cpos - 1u - back]) back++;
+            } else {
+                while (back < maxback && src[pos - 1u - back] == src[cpos - 1u - back]) back++;
+            }
+        }
+        const uint32_t ll = lit0 - back, mc = mine ? code + back : 0u;
+        const bool short_run = mine && ll != 0u && ll <= LANE_COPY_MAX;
+        const uint32_t lx = ll >= (uint32_t)RUN_MASK ? (ll - RUN_MASK) / 255u + 1u : 0u;
+        const uint32_t mx = mc >= (uint32_t)ML_MASK ? (mc - ML_MASK) / 255u + 1u : 0u;
+        const uint32_t sz = mine ? 1u + lx + ll + 2u + mx : 0u;
+        const uint32_t incl = wave_inclusive_scan(sz);
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        const uint32_t o_tok = op + incl - sz;
+        const uint32_t o_lit = o_tok + 1u + lx, o_off = o_lit + ll, o_mx = o_off + 2u;
+        if (limited) {                                      /* :251-255, :346-350 */
+            const bool fail = mine && ((uint64_t)o_tok + 1u + ll + (2 + 1 + LASTLITERALS) + ll / 255u > olimit ||
+                                       (uint64_t)o_mx + (1 + LASTLITERALS) + (mc + 240u) / 255u > olimit);
+            if (ballot(fail)) return 0;
+        }
+        if (mine) {
+            dst[o_tok] = (uint8_t)(((ll < (uint32_t)RUN_MASK ? ll : (uint32_t)RUN_MASK) << ML_BITS) |
+                                   (mc < (uint32_t)ML_MASK ? mc : (uint32_t)ML_MASK));
+            if (lx == 1u) dst[o_tok + 1u] = (uint8_t)(ll - RUN_MASK);
+            ((U16u *)(dst + o_off))->v = (uint16_t)(pos - cpos);   /* :299-304 */
+            if (mx == 1u) dst[o_mx] = (uint8_t)(mc - ML_MASK);
+        }
+        if (short_run) lane_copy32(dst + o_lit, src + ls, ll, U - ls);
+        unsigned long long big = ballot(mine && (ll > LANE_COPY_MAX || lx > 1u || mx > 1u));
+        while (big) {
+            const int g = ctz64(big);
+            big &= big - 1ull;
+            const uint32_t g_ll = readlane_u32(ll, g), g_mc = readlane_u32(mc, g);
+            const uint32_t g_tok = readlane_u32(o_tok, g);
+            if (g_ll >= (uint32_t)RUN_MASK + 255u) emit_length_run(dst, g_tok + 1u, g_ll - RUN_MASK, lane);
+            if (g_ll > LANE_COPY_MAX) wave_copy(dst + readlane_u32(o_lit, g), src + readlane_u32(ls, g), g_ll, lane);
+            if (g_mc >= (uint32_t)ML_MASK + 255u) emit_length_run(dst, readlane_u32(o_mx, g), g_mc - ML_MASK, lane);
+        }
+        op += total;
+        emitted_to = readlane_u32(end, (int)n - 1);
+    }
+    /* ---- _last_literals (:469-503) ---- */
+    const uint32_t last_run = U - emitted_to;
+    if (limited && (uint64_t)op + last_run + 1u + (last_run + 255u - RUN_MASK) / 255u > olimit) return 0;
+    if (last_run >= (uint32_t)RUN_MASK) {
+        if (lane == 0) dst[op] = (uint8_t)(RUN_MASK << ML_BITS);
+        emit_length_run(dst, op + 1u, last_run - RUN_MASK, lane);
+        op += 2u + (last_run - RUN_MASK) / 255u;
+    } else {
+        if (lane == 0) dst[op] = (uint8_t)(last_run << ML_BITS);
+        op++;
+    }
+    wave_copy(dst + op, src + emitted_to, last_run, lane);
+    op += last_run;
+    return (int)op;
+}
+
+__global__ __launch_bounds__(64 * EMIT_WAVES_PER_WG) void k4_emit_kernel(BatchArgs a, ParseArgs p)
+{
+    const int lane = lane_id();
+    const long long b = (long long)blockIdx.x * EMIT_WAVES_PER_WG + (long long)uni(threadIdx.x >> 6);
+    if (b >= a.n) return;
+    const uint32_t nseq = uni(p.meta[2ull * (unsigned long long)b]);
+    if (nseq == PARSE_REST) return;
+    const int src_len = a.srcLen[b];
+    const int cap = a.dstCap[b];
+    const int ret = emit_block(a.src + a.srcOff[b], (uint32_t)src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap,
+                               p.recs + (unsigned long long)b * PARSE_REC_STRIDE, nseq, lane);
+    if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
+}
+
+/* the blocks the parse kernel left alone (PARSE_REST): the one-kernel encoder of k4lz4_encode_fast.hpp, table in LDS */
+__global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) void k4_encode_fast_rest_kernel(BatchArgs a, ParseArgs p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tabs[ENCODE_WAVES_PER_WG][ENCODE_LDS_DWORDS];
+    const int lane = lane_id();
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const long long b = (long long)blockIdx.x * ENCODE_WAVES_PER_WG + (long long)wave;
+    if (b >= a.n) return;
+    if (uni(p.meta[2ull * (unsigned long long)b]) != PARSE_REST) return;
+    const int src_len = a.srcLen[b];
+    const int cap = a.dstCap[b];
+    int ret = 0;
+    if (src_len > 0 || (a.flags & FLAG_RAW_RETURN))
+        ret = compress_fast_block<true, false>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.accel, tabs[wave], lane, nullptr, (a.flags & FLAG_X32) != 0, nullptr);
+    if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
+}
+
+}  // namespace k4

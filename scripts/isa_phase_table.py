@@ -31,7 +31,7 @@ for f in re.split(r"\n\s*\.globl\s+", txt)[1:]:
     for l in lines[:end]:
         m = re.search(r"; k4phase (\S+)", l)
         if m:
-            if m.group(1) == "load":
+            if m.group(1) in ("load", "front"):
                 inst += 1
             phase = f"{m.group(1)} #{inst}" if inst else m.group(1)
             continue

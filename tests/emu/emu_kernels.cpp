@@ -3,6 +3,7 @@
 #include "hip/hip_runtime.h"
 #include "k4lz4_decode.hpp"
 #include "k4lz4_encode_fast.hpp"
+#include "k4lz4_parse.hpp"
 #include "k4lz4_pickle.hpp"
 #include "k4lz4_segments.hpp"
 #include "k4lz4_encode_hc.hpp"
@@ -98,6 +99,43 @@ int k4emu_encode_gtab_batch(const uint8_t *src, const uint64_t *srcOff, const in
     std::vector<uint32_t> tables((size_t)grid * k4::ENCODE_WAVES_PER_WG * 4096u);
     a.gtab = tables.data();
     k4emu::launch_fn(dim3(grid), dim3(64 * k4::ENCODE_WAVES_PER_WG), [=] { k4::k4_encode_fast_gtab_kernel(a); }, threads);
+    return 0;
+}
+
+
+/* the two-kernel fast encoder (k4lz4_parse.hpp): parse -> emit, then the blocks the parse left alone.  K sub-windows per round,
+ * `waves` blocks per workgroup (waves beyond PARSE_LDS_TABLES keep their table in memory), optional dispatch order. */
+} /* extern C */
+template <int K> static void emu_parse_launch(const k4::BatchArgs &a, const k4::ParseArgs &p, unsigned waves, int threads)
+{
+    k4emu::launch_fn(dim3(p.nwg), dim3(64 * waves), [=] {
+        __shared__ __attribute__((aligned(16))) uint32_t lds[k4::PARSE_LDS_DWORDS];
+        k4::parse_kernel_body<K>(a, p, lds);
+    }, threads);
+}
+extern "C" {
+int k4emu_encode_parse_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
+                             const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int accel, int flags,
+                             int K, int waves, const uint32_t *order, uint32_t *nseq_out, int threads)
+{
+    if (n <= 0) return 0;
+    k4::BatchArgs a{};
+    a.src = src; a.srcOff = srcOff; a.srcLen = srcLen; a.dst = dst; a.dstOff = dstOff; a.dstCap = dstCap; a.outLen = outLen;
+    a.n = n; a.accel = accel; a.flags = flags; a.order = order;
+    if (waves < 1) waves = 1;
+    if (waves > k4::PARSE_MAX_WAVES) waves = k4::PARSE_MAX_WAVES;
+    k4::ParseArgs p{};
+    p.nwg = (uint32_t)((n + waves - 1) / waves);
+    std::vector<uint2> recs((size_t)n * k4::PARSE_REC_STRIDE);
+    std::vector<uint32_t> meta((size_t)n * 2, 0x12345678u), gtab((size_t)p.nwg * k4::PARSE_MAX_WAVES * 4096u, 0xdeadbeefu);
+    p.recs = recs.data(); p.meta = meta.data(); p.gtab = gtab.data();
+    if (K == 1) emu_parse_launch<1>(a, p, (unsigned)waves, threads);
+    else if (K == 2) emu_parse_launch<2>(a, p, (unsigned)waves, threads);
+    else if (K == 3) emu_parse_launch<3>(a, p, (unsigned)waves, threads);
+    else emu_parse_launch<4>(a, p, (unsigned)waves, threads);
+    k4emu::launch_fn(dim3((unsigned)((n + k4::EMIT_WAVES_PER_WG - 1) / k4::EMIT_WAVES_PER_WG)), dim3(64 * k4::EMIT_WAVES_PER_WG), [=] { k4::k4_emit_kernel(a, p); }, threads);
+    k4emu::launch_fn(dim3((unsigned)((n + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG), [=] { k4::k4_encode_fast_rest_kernel(a, p); }, threads);
+    if (nseq_out) for (long long i = 0; i < n; i++) nseq_out[i] = meta[(size_t)i * 2];
     return 0;
 }
 
