@@ -62,6 +62,7 @@ struct ParseArgs {
 /* ------------------------------------------------------------------------------------------------------------------ */
 
 template <int N> using ic = std::integral_constant<int, N>;
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) { return ((unsigned long long)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
 
 /* bytes [s, s+16) of a stream of which w holds [a, a+16), a <= s (zeros behind the end) */
 __device__ __forceinline__ void shift16(uint32_t &w0, uint32_t &w1, uint32_t &w2, uint32_t &w3, uint32_t sh)
@@ -96,8 +97,22 @@ constexpr uint32_t HOP_LONG = 0x100u, HOP_LAZY = 0x200u, HOP_END = 0x400u, HOP_I
  * table (LDS, or global memory with GT), `seen`: PARSE_SEEN_DWORDS dwords of LDS.  Returns the number of records written.
  */
 template <int K, bool GT>
-__device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32_t U, uint2 *recs, uint16_t *tab, uint32_t *seen, const int lane)
+__device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32_t U, uint2 *recs, uint16_t *tab, uint32_t *seen, const int lane, unsigned long long *pc = nullptr)
 {
+#ifdef K4_PARSE_PROF
+    /* diagnostic build: cycles per phase of a round (each phase ends by draining its own memory traffic) and event counts */
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pn[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = 0;
+    const unsigned long long pbegin = prof_now<true>();
+#define K4_PT(i) do { const unsigned long long t_ = prof_now<true>(); pt[i] += t_ - plast; plast = t_; } while (0)
+#define K4_PN(i, v) (pn[i] += (v))
+#define K4_TIC() const unsigned long long tic_ = (unsigned long long)__builtin_readcyclecounter()
+#define K4_TOC(i) (pt[i] += (unsigned long long)__builtin_readcyclecounter() - tic_)
+#else
+#define K4_TIC() ((void)0)
+#define K4_TOC(i) ((void)0)
+#define K4_PT(i) ((void)0)
+#define K4_PN(i, v) ((void)0)
+#endif
     const uint32_t mfl1 = U - (uint32_t)MFLIMIT + 1u;          /* mflimitPlusOne */
     const uint32_t matchlimit = U - (uint32_t)LASTLITERALS;
     const uint32_t last_valid = U - (uint32_t)MFLIMIT;         /* a probe at p happens iff p + step <= mflimitPlusOne (:172, :391) */
@@ -164,6 +179,10 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         const bool strided = plain ? false : sj != 0u;
         const uint32_t c0 = c;
         const int KK = strided ? 1 : K;
+#ifdef K4_PARSE_PROF
+        plast = prof_now<true>();
+        K4_PN(0, 1); if (!plain) K4_PN(1, 1); if (strided) K4_PN(2, 1);
+#endif
 
         /* ---------------- front: positions, hashes, candidates, what each lane would do as a hit ---------------- */
         K4_PHASE("front");
@@ -200,6 +219,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
             flagged[k] = fl;
         }
         /* the candidates' bytes: the round's one dependent trip to memory */
+        K4_PT(0);
         U128u cw[K];
 #pragma unroll
         for (int k = 0; k < K; k++) {
@@ -213,6 +233,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         for (int k = 0; k < K; k++) if (k < KK && val[k]) seen[h[k] >> 6] = 0u;
 
         /* lanes that share a hash: Dm = those with an earlier lane of the round in their group, Gall = all of them */
+        K4_PT(1);
         K4_PHASE("groups");
 #pragma unroll
         for (int k = 0; k < K; k++) { Dm[k] = 0ull; Gall[k] = 0ull; }
@@ -225,6 +246,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     while (fl[k]) {
+                        K4_PN(3, 1);
                         const int j = ctz64(fl[k]);
                         const uint32_t hj = readlane_u32(h[k], j);
                         unsigned long long m[K];
@@ -277,6 +299,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         }
 
         /* ---------------- the chain ---------------- */
+        K4_PT(2);
         K4_PHASE("chain");
         /* a hop word for lane f of sub-window k worked out in scalar code: the lane's candidate is lane j of sub-window kk */
         auto word_from_lane = [&](auto kc, int f, auto kkc, int j) -> uint32_t {
@@ -357,7 +380,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                         if (!t) { outcome = 3; upto_last = limlane + 1u; done = true; return; }
                         hm = t & (0ull - t);
                     }
-                    hop_chain(hm, hop[k], q, hits[k], f, hv, stop);
+                    { K4_TIC(); hop_chain(hm, hop[k], q, hits[k], f, hv, stop); K4_TOC(6); K4_PN(7, 1); }
                     if (!stop) {
                         if (limited) { limited = false; continue; }        /* that one stop was a plain hop */
                         if (hits[k]) {             /* where the running search began: behind the last match */
@@ -370,7 +393,8 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                     }
                     if (hv & HOP_INVALID) { hits[k] &= ~(1ull << f); outcome = 2; upto_last = (uint32_t)f; done = true; return; }
                     if (hv & HOP_LAZY) {
-                        hv = resolve(kc, f);
+                        K4_PN(4, 1);
+                        { K4_TIC(); hv = resolve(kc, f); K4_TOC(7); }
                         if (hv == 0xffffffffu) {
                             hits[k] &= ~(1ull << f);
                             hmx[k] &= ~(1ull << f);
@@ -386,6 +410,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                     const uint32_t p = strided ? readlane_u32(pos[k], f) : w0 + (uint32_t)f;
                     uint32_t e_end;
                     if (hv & HOP_LONG) {                               /* :326-329 beyond the 12 known bytes */
+                        K4_PN(5, 1);
                         const uint32_t match = readlane_u32(cpos[k], f);
                         const uint32_t code = 12u + wave_count(src + p + 16u, src + match + 16u, matchlimit - (p + 16u), lane);
                         e_end = p + (uint32_t)MINMATCH + code;
@@ -411,6 +436,8 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         }
 
         /* ---------------- where the next round starts; its source loads go out now ---------------- */
+        K4_PT(3);
+        K4_PN(6, (unsigned long long)klast + 1ull);
         K4_PHASE("next");
         if (outcome == 1) { c = anchor; test = true; sj = 0u; }
         else if (outcome == 0) {
@@ -469,6 +496,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         if (outcome == 2) return false;
 
         /* ---------------- the round's puts ---------------- */
+        K4_PT(4);
         K4_PHASE("commit");
 #ifdef K4_PARSE_DEBUG
         if (lane == 0 && getenv("K4DBG") && c0 + 64u * K > (uint32_t)atoi(getenv("K4DBG")) && c0 < (uint32_t)atoi(getenv("K4DBG")) + 200u) {
@@ -494,14 +522,200 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                 if (lane == j) tab[h[k]] = (uint16_t)pos[k];
             }
         }
-        wave_sync();
+        if (GT) wave_sync(); else lds_sync();       /* (never a wait for the records' stores or the next round's loads) */
+        K4_PT(5);
+        return true;
+    };
+
+    /* The same round once more for the case that is nearly all of a block's rounds -- one sub-window, every lane a probe with its
+     * bytes inside the block, the search's 66-probe limit out of reach -- written for the number of instructions it takes: a wave
+     * alone issues one instruction every five to six cycles whatever the instruction is, so a round costs what it counts.
+     * Differences from the general form: the lanes inside matches come from a DPP max-scan instead of a shuffle, the round's puts are
+     * one store by every visited lane plus a read-back (a position is later than whatever its slot held, so the put that must stand
+     * is the largest: lanes that read back less than their own position store again), a lane that stops the chain for its group's
+     * sake has its candidate's bytes compared in vector code against one broadcast lane. */
+    auto fast_round = [&]() -> bool {
+        const uint32_t c0 = c;
+#ifdef K4_PARSE_PROF
+        plast = prof_now<true>();
+        K4_PN(0, 1);
+#endif
+        K4_PHASE("front");
+        const uint32_t p = c0 + (uint32_t)lane;
+        const uint32_t w0 = pw[0].v[0], w1 = pw[0].v[1], w2 = pw[0].v[2], w3 = pw[0].v[3];
+        const uint32_t hh = FastTable<1>::hash_of(w0, 0u);
+        uint32_t cd = tab[hh];
+        const uint32_t bit = hh >> 1;
+        const bool flg = ((atomicOr(&seen[bit >> 5], 1u << (bit & 31u)) >> (bit & 31u)) & 1u) != 0u;
+        uint32_t hE2 = 0xffffffffu;
+        if (test) {
+            hE2 = FastTable<1>::hash_of(pre2, 0u);
+            if (hh == hE2) cd = c0 - 2u;
+        }
+        K4_PT(0);
+        const U128u cw = ld128u(src + cd);
+        __builtin_amdgcn_wave_barrier();
+        seen[hh >> 6] = 0u;
+        /* groups */
+        K4_PT(1);
+        K4_PHASE("groups");
+        unsigned long long D0 = 0ull, G0 = 0ull;
+        {
+            unsigned long long fl = ballot(flg);
+            while (fl) {
+                K4_PN(3, 1);
+                const uint32_t hj = readlane_u32(hh, ctz64(fl));
+                const unsigned long long m = ballot(hh == hj);
+                fl &= ~m;
+                G0 |= m;
+                D0 |= m & (m - 1ull);
+            }
+        }
+        K4_PHASE("words");
+        const bool hit = cw.v[0] == w0;
+        const uint32_t e = ext12(cw.v[1] ^ w1, cw.v[2] ^ w2, cw.v[3] ^ w3);
+        uint32_t word = ((uint32_t)lane + (uint32_t)MINMATCH + e) | (e == 12u ? HOP_LONG : 0u);
+        if ((D0 >> lane) & 1ull) word |= HOP_LAZY | (hit ? 0u : HOP_TABMISS);
+        uint32_t ec = e, cp = cd;
+        unsigned long long hm = ballot(hit) | D0;
+        K4_PT(2);
+        K4_PHASE("chain");
+        unsigned long long hts = 0ull;
+        uint32_t q = 0u, anchor = 0u, upto = 64u;
+        int outcome = 0;
+        for (;;) {
+            uint32_t hv = 0u;
+            int f = 0;
+            unsigned long long stop;
+            { K4_TIC(); hop_chain(hm, word, q, hts, f, hv, stop); K4_TOC(6); K4_PN(7, 1); }
+            if (!stop) break;
+            if (hv & HOP_LAZY) {
+                K4_PN(4, 1);
+                K4_TIC();
+                /* the latest VISITED lane below f with f's hash, if any: a lane is inside a match -- never put -- when it lies below the
+                 * landing place of the nearest hit below it, other than two before it (:394) */
+                unsigned long long cm = ballot(hh == readlane_u32(hh, f)) & ((1ull << f) - 1ull);
+                const unsigned long long hb = hts & ((1ull << f) - 1ull);
+                unsigned long long m = 0ull;
+                while (cm) {
+                    const int j = 63 - (int)__clzll((long long)cm);
+                    cm &= ~(1ull << j);
+                    const unsigned long long hbj = hb & ((1ull << j) - 1ull);
+                    bool v = true;
+                    if (hbj) { const uint32_t qj = readlane_u32(word, 63 - (int)__clzll((long long)hbj)) & 127u; v = (uint32_t)j >= qj || (uint32_t)j + 2u == qj; }
+                    if (v) { m = 1ull << j; break; }
+                }
+                if (m) {
+                    const int j = 63 - (int)__clzll((long long)m);
+                    const uint32_t s0 = readlane_u32(w0, j), s1 = readlane_u32(w1, j), s2 = readlane_u32(w2, j), s3 = readlane_u32(w3, j);
+                    const uint32_t e2 = ext12(s1 ^ w1, s2 ^ w2, s3 ^ w3);
+                    const uint32_t wj = s0 != w0 ? 0xffffffffu : (((uint32_t)lane + (uint32_t)MINMATCH + e2) | (e2 == 12u ? HOP_LONG : 0u));
+                    hv = readlane_u32(wj, f);
+                    if (lane == f) { word = wj; ec = e2; cp = c0 + (uint32_t)j; }
+                } else {
+                    hv = (hv & HOP_TABMISS) ? 0xffffffffu : (hv & ~HOP_LAZY);
+                    if (lane == f) word = hv;
+                }
+                K4_TOC(7);
+                if (hv == 0xffffffffu) {
+                    hts &= ~(1ull << f);
+                    hm &= ~(1ull << f);
+                    q = (uint32_t)f + 1u;
+                    if (q >= 64u) break;
+                    continue;
+                }
+            }
+            uint32_t e_end = c0 + (hv & 127u);
+            if (hv & HOP_LONG) {                               /* :326-329 beyond the 12 known bytes */
+                K4_PN(5, 1);
+                const uint32_t pf = c0 + (uint32_t)f;
+                const uint32_t match = readlane_u32(cp, f);
+                const uint32_t code = 12u + wave_count(src + pf + 16u, src + match + 16u, matchlimit - (pf + 16u), lane);
+                e_end = pf + (uint32_t)MINMATCH + code;
+                const uint32_t qf = (uint32_t)f + (uint32_t)MINMATCH + code;
+                if (lane == f) { ec = code; word = qf < 127u ? qf : 127u; }
+                if (e_end >= mfl1) { anchor = e_end; outcome = 2; upto = (uint32_t)f + 1u; break; }      /* :391 */
+            }
+            const uint32_t nq = e_end - c0;
+            if (nq >= 64u) { anchor = e_end; outcome = 1; upto = (uint32_t)f + 1u; break; }
+            q = nq;
+        }
+        K4_PT(3);
+        K4_PN(6, 1);
+        K4_PHASE("next");
+        /* (uni(): what the scalar chain hands back counts as per-lane for the compiler, and these go into the next chain's operands) */
+        if (outcome == 1) { c = uni(anchor); test = true; sbase = c + 1u; }
+        else if (outcome == 0) {
+            c = c0 + 64u;
+            test = false;
+            if (hts) sbase = uni(c0 + (readlane_u32(word, 63 - (int)__clzll((long long)hts)) & 127u) + 1u);
+            if (c - sbase >= 66u) sj = 66u;
+        }
+        c = uni(c); sbase = uni(sbase); sj = uni(sj); test = uni(test ? 1u : 0u) != 0u;
+        if (outcome != 2) prepare();
+        K4_PHASE("records");
+        const bool mine = ((hts >> lane) & 1ull) != 0ull;
+        if (hts) {
+            if (mine) recs[nrec + (uint32_t)__popcll(hts & below_me)] = make_uint2(p, (p - cp) | (ec << 16));
+            nrec += (uint32_t)__popcll(hts);
+        }
+        if (outcome == 2) return false;
+        K4_PHASE("visited");
+        /* lanes inside matches: below the landing place of the nearest hit below them, except the lane two before it (:394) */
+        unsigned long long vm;
+        {
+            uint32_t x = mine ? (word & 127u) : 0u;
+            x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));
+            x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));
+            x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));
+            x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));
+            x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
+            x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
+            const uint32_t below = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, true);      /* wave_shr:1 */
+            vm = ballot(!((uint32_t)lane < below && (uint32_t)lane + 2u != below));
+            if (upto < 64u) vm &= (1ull << upto) - 1ull;
+        }
+        K4_PT(4);
+        K4_PHASE("commit");
+        if (hE2 != 0xffffffffu && lane == 0) tab[hE2] = (uint16_t)(c0 - 2u);
+        if (GT) wave_sync(); else __builtin_amdgcn_wave_barrier();      /* a lane of the round may put the same slot: it comes second */
+        const bool vis_me = ((vm >> lane) & 1ull) != 0ull;
+        if (vis_me) tab[hh] = (uint16_t)p;
+        {
+            unsigned long long again = vm & G0;
+            again = (again & (again - 1ull)) ? again : 0ull;         /* two visited lanes of groups at least */
+            while (again) {
+                if (GT) wave_sync(); else lds_sync();
+                const bool redo = ((again >> lane) & 1ull) != 0ull && (uint32_t)tab[hh] < (p & 0xffffu);
+                again = ballot(redo);
+                if (GT) wave_sync(); else __builtin_amdgcn_wave_barrier();
+                if (redo) tab[hh] = (uint16_t)p;
+            }
+        }
+        if (GT) wave_sync(); else lds_sync();       /* (never a wait for the records' stores or the next round's loads) */
+        K4_PT(5);
         return true;
     };
     for (;;) {
         const bool plain = sj == 0u && c + 64u * (uint32_t)K + 28u <= U;
-        if (plain) { if (!round(std::true_type{})) break; }
+        /* (the search's limit: probes up to sbase + 65 are contiguous, the window ends at c + 63) */
+        if (K == 1 && plain && c + 63u <= sbase + 65u) { if (!fast_round()) break; }
+        else if (plain) { if (!round(std::true_type{})) break; }
         else if (!round(std::false_type{})) break;
     }
+#ifdef K4_PARSE_PROF
+    if (pc && lane == 0) {
+        pc[0] = prof_now<true>() - pbegin;
+        for (int i = 0; i < 6; i++) pc[1 + i] = pt[i];
+        /* [8..10] are the placement stamps, [15] says where the table lived */
+        pc[7] = (unsigned long long)nrec | (pn[4] << 32);              /* sequences | lazy stops << 32 */
+        pc[11] = pn[0] | (pn[6] << 32);                                /* rounds | sub-windows entered << 32 */
+        pc[12] = pn[1] | (pn[2] << 32);                                /* rounds of the careful form | strided ones << 32 */
+        pc[13] = (pt[6] & 0xffffffffull) | (pt[7] << 32);              /* cycles inside the tight chain | inside lazy resolutions << 32 (both include ~2 counter reads each) */
+        pc[10] = pn[7];                                                /* entries into the tight chain (overwrites the HW_ID stamp) */
+        pc[14] = pn[3] | (pn[5] << 32);                                /* groups | long counts << 32 */
+    }
+#endif
     return nrec;
 }
 
@@ -527,8 +741,15 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
     const uint32_t lds_tables = waves < (uint32_t)PARSE_LDS_TABLES ? waves : (uint32_t)PARSE_LDS_TABLES;
     uint32_t *seen = lds + 4096u * (uint32_t)PARSE_LDS_TABLES + (uint32_t)PARSE_SEEN_DWORDS * wave;
     uint32_t n;
-    if (wave < lds_tables) n = parse_block<K, false>(src, (uint32_t)src_len, recs, (uint16_t *)(lds + 4096u * wave), seen, lane);
-    else n = parse_block<K, true>(src, (uint32_t)src_len, recs, (uint16_t *)(p.gtab + 4096ull * ((unsigned long long)blockIdx.x * PARSE_MAX_WAVES + wave)), seen, lane);
+    unsigned long long *pc = nullptr;
+#ifdef K4_PARSE_PROF
+    if (a.prof) { pc = a.prof + PROF_STRIDE * b; prof_place<true>(pc, 8, lane); }
+#endif
+    if (wave < lds_tables) n = parse_block<K, false>(src, (uint32_t)src_len, recs, (uint16_t *)(lds + 4096u * wave), seen, lane, pc);
+    else n = parse_block<K, true>(src, (uint32_t)src_len, recs, (uint16_t *)(p.gtab + 4096ull * ((unsigned long long)blockIdx.x * PARSE_MAX_WAVES + wave)), seen, lane, pc);
+#ifdef K4_PARSE_PROF
+    if (a.prof) { if (lane == 0) { pc[9] = __builtin_amdgcn_s_memrealtime(); pc[15] = wave < lds_tables ? 1u : 2u; } }
+#endif
     if (lane == 0) { meta[0] = n; meta[1] = 0u; }
 }
 

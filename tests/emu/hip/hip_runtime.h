@@ -131,6 +131,8 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     if (ctrl >= 0x111 && ctrl <= 0x11f) {
         const int n = ctrl - 0x110;
         if ((l & 15) >= n) srcl = l - n;
+    } else if (ctrl == 0x138) {          /* wave_shr:1 */
+        if (l >= 1) srcl = l - 1;
     } else if (ctrl == 0x142) {
         if (row >= 1) srcl = row * 16 - 1;
     } else if (ctrl == 0x143) {

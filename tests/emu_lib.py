@@ -64,6 +64,7 @@ class Emu:
         self.lib.k4emu_encode_gtab_batch.argtypes = b + [C.c_int, C.c_int, C.c_int, C.c_int]
         self.lib.k4emu_encode_more_batch.argtypes = b + [C.c_int, C.c_int, C.c_int, C.c_int]
         self.more = False      # True: encode_batch runs the 28-known-bytes variant of the LDS-table kernel
+        self.lib.k4emu_encode_parse_batch.argtypes = b + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         self.lib.k4emu_decode_dict_batch.argtypes = b + [C.c_int, _u8p, C.c_void_p, C.c_void_p, C.c_int]
         self.lib.k4emu_decode_pair_batch.argtypes = b + [C.c_int, _u8p, C.c_void_p, C.c_void_p, C.c_int]
         self.pair = False      # True: decode_batch / decode_dict_batch run the two-waves-per-block kernel
@@ -105,6 +106,18 @@ class Emu:
                                          len(src_len), level, accel, flags, threads)
         assert rc == 0
         return out
+
+    def encode_parse_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, accel=1, flags=0, k=2, waves=16, order=None, threads=0):
+        """the two-kernel fast encoder (k4lz4_parse.hpp): parse with k sub-windows per round and `waves` blocks per workgroup
+        (those beyond 9 keep their table in memory), emit, then the one-kernel encoder for the blocks the parse left alone.
+        Returns (outLen, sequences per block -- 0xffffffff where the parse left the block alone)."""
+        out = np.full(len(src_len), -12345, dtype=np.int32)
+        nseq = np.zeros(len(src_len), dtype=np.uint32)
+        rc = self.lib.k4emu_encode_parse_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst), dst_off.ctypes.data,
+                                               dst_cap.ctypes.data, out.ctypes.data, len(src_len), accel, flags, k, waves,
+                                               order.ctypes.data if order is not None else None, nseq.ctypes.data, threads)
+        assert rc == 0
+        return out, nseq
 
     def pickle_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, level=0, flags=0, threads=0):
         out = np.full(len(src_len), -12345, dtype=np.int32)

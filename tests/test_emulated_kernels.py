@@ -59,6 +59,64 @@ def test_encode_fast_matches_oracle(emu, oracle, variant):
     assert (dst[mask] == 0xCD).all()
 
 
+@pytest.mark.parametrize("k,waves", [(1, 1), (2, 16), (2, 9), (3, 12), (4, 5)])
+def test_encode_parse_emit_matches_oracle(emu, oracle, k, waves):
+    """the two-kernel fast encoder (k4lz4_parse.hpp: which sequences, then their bytes): k sub-windows of 64 positions per
+    round, `waves` blocks per workgroup of which those beyond nine keep their table in memory; blocks it leaves alone
+    (under 128 bytes, 65 547 and more) come out of the one-kernel encoder behind it"""
+    blocks = _fixture_blocks()
+    blocks += [corpus.lorem(n) for n in (127, 128, 129, 140, 200, 65546, 65547)] + [corpus.repeated(0xAA, n) for n in (128, 129, 141)]
+    blocks += [corpus.class_bytes(name, 65536, 21) for name in ("nci", "samba", "osdb", "xml", "x-ray", "sao")]
+    # an incompressible stretch long enough for the step to grow (LL64.fast.cs:156-172), then matches again -- also at the block's end
+    rng = np.random.default_rng(8)
+    noise = rng.integers(0, 256, 9000, dtype=np.uint8)
+    blocks += [np.concatenate([corpus.lorem(700), noise, corpus.lorem(900)]), np.concatenate([noise, noise[:5000]]), noise[:4000].copy()]
+    src, soff, slen = pack(blocks)
+    dst, doff, dcap = arena([oracle.compress_bound(b.size) for b in blocks])
+    order = np.random.default_rng(k).permutation(len(blocks)).astype(np.uint32) if waves != 9 else None
+    out, nseq = emu.encode_parse_batch(src, soff, slen, dst, doff, dcap, k=k, waves=waves, order=order)
+    for i, b in enumerate(blocks):
+        want = oracle.encode(b)
+        if b.size == 0:
+            assert out[i] == 0
+            continue
+        got = dst[int(doff[i]):int(doff[i]) + max(int(out[i]), 0)].tobytes()
+        assert out[i] == len(want) and got == want, f"block {i} ({b.size} B)"
+        assert (nseq[i] == 0xFFFFFFFF) == (b.size < 128 or b.size >= 65547), f"block {i} ({b.size} B): who encoded it"
+        if nseq[i] != 0xFFFFFFFF:
+            assert nseq[i] == oracle.count_sequences(np.frombuffer(want, np.uint8)) - 1, f"block {i}: sequences"
+    mask = np.ones(dst.size, bool)
+    for i in range(len(blocks)):
+        mask[int(doff[i]):int(doff[i]) + max(int(out[i]), 0)] = False
+    assert (dst[mask] == 0xCD).all()
+
+
+def test_encode_parse_emit_limited_output_and_acceleration(emu, oracle):
+    """output limits are the emit kernel's (LL64.fast.cs:251-255, :346-350, :471-476): cap == size succeeds, one less fails;
+    another acceleration than 1 is not the parse kernel's case and comes out of the one-kernel encoder all the same"""
+    blocks, caps, wants = [], [], []
+    for name in ("x-ray", "dickens", "xml", "sao", "nci"):
+        b = corpus.class_bytes(name, 30000, 17)
+        n = len(oracle.encode(b))
+        for cap in (n, n - 1, n + 1, n // 2, 0, 13):
+            blocks.append(b); caps.append(cap)
+            r, enc = oracle.compress_fast(b, cap)
+            wants.append((r, bytes(enc[:max(r, 0)])))
+    src, soff, slen = pack(blocks)
+    dst, doff, dcap = arena(caps)
+    out, _ = emu.encode_parse_batch(src, soff, slen, dst, doff, dcap, flags=FLAG_RAW, k=2, waves=7)
+    for i, (r, enc) in enumerate(wants):
+        assert out[i] == (r if r > 0 else 0), (i, caps[i])
+        if r > 0:
+            assert dst[int(doff[i]):int(doff[i]) + r].tobytes() == enc
+    dst2, doff2, dcap2 = arena([oracle.compress_bound(b.size) for b in blocks])
+    out2, nseq2 = emu.encode_parse_batch(src, soff, slen, dst2, doff2, dcap2, accel=5, flags=FLAG_RAW, k=2, waves=4)
+    assert (nseq2 == 0xFFFFFFFF).all()
+    for i, b in enumerate(blocks):
+        r, enc = oracle.compress_fast(b, oracle.compress_bound(b.size), 5)
+        assert out2[i] == r and dst2[int(doff2[i]):int(doff2[i]) + r].tobytes() == bytes(enc[:r])
+
+
 def test_encode_fast_big_block_hash5(emu, oracle):
     """>= 65547 bytes switches to the u32 table + hash5 (LL64.fast.cs:526-544)"""
     blocks = [corpus.lorem(65547), corpus.class_bytes("samba", 200000, 5), corpus.class_bytes("mozilla", 140000, 5),
