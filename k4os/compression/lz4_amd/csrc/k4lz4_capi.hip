@@ -113,6 +113,9 @@ struct k4lz4_ctx {
     bool prof_gtab = false;               /* K4LZ4_PROF_GTAB: the instrumented encoder keeps its table in global memory */
     uint8_t *d_parse = nullptr; size_t d_parse_cap = 0;       /* two-kernel fast encoder (k4lz4_parse.hpp): records, per-block counts, tables of the waves without an LDS table */
     bool use_parse = true;                /* K4LZ4_NO_PARSE: fast-level batches go to the one-kernel encoders as before */
+    bool parse_queue = false;             /* K4LZ4_PARSE_QUEUE */
+    bool parse_inline_emit = true;        /* K4LZ4_NO_INLINE_EMIT: the blocks' bytes by k4_emit_kernel behind the parse instead of by the parsing waves themselves */
+    bool parse_pcost = false;             /* K4LZ4_PCOST: the parse's own cost estimate (k4_pcost_kernel) orders the blocks; measured: costs more than it gains */
     int parse_waves = 16;                 /* K4LZ4_PARSE_WAVES: blocks per workgroup (= per CU) of the parse kernel, at most PARSE_MAX_WAVES */
     bool trace = false;         /* K4LZ4_TRACE: host-pointer calls print where their time went (stderr) */
 };
@@ -456,12 +459,13 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
     uint32_t *d_cost = nullptr, *d_order = nullptr, *d_hist = nullptr;
     if (reorder) {
         const size_t cnt_max = (size_t)std::min<int64_t>(chunk_max, n);
-        const size_t need = cnt_max * 8 + (2 * k4::COST_BUCKETS + 16) * 4 + 64;
+        const size_t hist_words = std::max<size_t>(2 * (size_t)k4::PCOST_BUCKETS, 2 * (size_t)k4::COST_BUCKETS + 16);
+        const size_t need = cnt_max * 8 + hist_words * 4 + 64;
         if (need > ctx->d_sched_cap) K4_HIP(ctx, hipStreamSynchronize(stream));   /* scratch may still be in use */
         int rc = grow(ctx, &ctx->d_sched, &ctx->d_sched_cap, need, false);
         if (rc != K4LZ4_OK) return rc;
         d_hist = (uint32_t *)ctx->d_sched;
-        d_cost = d_hist + 2 * k4::COST_BUCKETS + 16;     /* [2 * COST_BUCKETS]: where the second encoder kernel's part of the order begins */
+        d_cost = d_hist + hist_words;     /* [2 * COST_BUCKETS]: where the second encoder kernel's part of the order begins */
         d_order = d_cost + cnt_max;
     }
     for (int64_t first = 0; first < n; first += chunk_max) {
@@ -534,7 +538,15 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             a.dict = dd->dict; a.dictOff = dd->off + first; a.dictLen = dd->len + first;
             a.dictMode = dd->mode ? dd->mode + first : nullptr;
         }
-        if (reorder) {
+        if (reorder && parse_path && kind == KIND_ENCODE && ctx->parse_pcost) {
+            /* the two-kernel encoder's own estimate and order (k4lz4_parse.hpp, k4_pcost_kernel) */
+            a.cost = d_cost; a.hist = d_hist; a.order_out = d_order;
+            K4_HIP(ctx, hipMemsetAsync(d_hist, 0, 2 * k4::PCOST_BUCKETS * 4, stream));
+            hipLaunchKernelGGL(k4::k4_pcost_kernel, dim3((unsigned)((cnt + k4::PCOST_WAVES_PER_WG - 1) / k4::PCOST_WAVES_PER_WG)), dim3(64 * k4::PCOST_WAVES_PER_WG), 0, stream, a);
+            hipLaunchKernelGGL(k4::k4_porder_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, a);
+            a.order = d_order;
+        }
+        else if (reorder) {
             a.cost = d_cost; a.hist = d_hist; a.order_out = d_order;
             K4_HIP(ctx, hipMemsetAsync(d_hist, 0, (2 * k4::COST_BUCKETS + 16) * 4, stream));
             hipLaunchKernelGGL(k4::k4_cost_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a, encode_like ? 0 : 1);
@@ -556,8 +568,10 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
          * whatever block the parse left alone (65 547 bytes and more, very short ones) by the one-kernel encoder. */
         if (kind == KIND_ENCODE && parse_path) {
             const int64_t waves = std::max<int64_t>(1, std::min<int64_t>(ctx->parse_waves, (cnt + ctx->cu_count - 1) / ctx->cu_count));
-            const int64_t nwg = (cnt + waves - 1) / waves;
-            const size_t o_meta = (size_t)cnt * k4::PARSE_REC_STRIDE * sizeof(uint2), o_gtab = (o_meta + (size_t)cnt * 8 + 255) & ~(size_t)255;
+            /* K4LZ4_PARSE_QUEUE: one workgroup per CU at most, every wave takes the next block of the cost order when it is done with one */
+            const bool queue = ctx->parse_queue && a.order && cnt > waves * (int64_t)ctx->cu_count;
+            const int64_t nwg = queue ? (int64_t)ctx->cu_count : (cnt + waves - 1) / waves;
+            const size_t o_meta = (size_t)cnt * k4::PARSE_REC_STRIDE * sizeof(uint2), o_gtab = (o_meta + (size_t)cnt * 8 + 64 + 255) & ~(size_t)255;
             const size_t need = o_gtab + (waves > k4::PARSE_LDS_TABLES ? (size_t)nwg * k4::PARSE_MAX_WAVES * 16384 : 0);
             if (need > ctx->d_parse_cap) K4_HIP(ctx, hipStreamSynchronize(stream));
             const int rcp = grow(ctx, &ctx->d_parse, &ctx->d_parse_cap, need, false);
@@ -565,8 +579,14 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             k4::ParseArgs pa{};
             pa.recs = (uint2 *)ctx->d_parse; pa.meta = (uint32_t *)(ctx->d_parse + o_meta); pa.gtab = (uint32_t *)(ctx->d_parse + o_gtab);
             pa.nwg = (uint32_t)nwg;
+            pa.inline_emit = ctx->parse_inline_emit ? 1u : 0u;
+            if (queue) {
+                pa.queue = pa.meta + 2 * cnt;
+                K4_HIP(ctx, hipMemsetAsync(pa.queue, 0, 16, stream));
+            }
             hipLaunchKernelGGL(k4::k4_parse_kernel, dim3((unsigned)nwg), dim3((unsigned)(64 * waves)), 0, stream, a, pa);
-            hipLaunchKernelGGL(k4::k4_emit_kernel, dim3((unsigned)((cnt + k4::EMIT_WAVES_PER_WG - 1) / k4::EMIT_WAVES_PER_WG)), dim3(64 * k4::EMIT_WAVES_PER_WG), 0, stream, a, pa);
+            if (!pa.inline_emit)
+                hipLaunchKernelGGL(k4::k4_emit_kernel, dim3((unsigned)((cnt + k4::EMIT_WAVES_PER_WG - 1) / k4::EMIT_WAVES_PER_WG)), dim3(64 * k4::EMIT_WAVES_PER_WG), 0, stream, a, pa);
             bool rest = true;          /* (where the host knows the lengths it knows whether there is anything left) */
             if (hostLen) {
                 rest = false;
@@ -1345,6 +1365,9 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (const char *e = getenv("K4LZ4_PICKLE_SPLIT_MIN")) ctx->pickle_split_min = std::max(0, atoi(e));
     if (const char *e = getenv("K4LZ4_STAGE_THREADS")) ctx->stage_threads = std::max(0, std::min(63, atoi(e) - 1));
     ctx->use_parse = getenv("K4LZ4_NO_PARSE") == nullptr;
+    ctx->parse_queue = getenv("K4LZ4_PARSE_QUEUE") != nullptr;
+    ctx->parse_pcost = getenv("K4LZ4_PCOST") != nullptr;
+    ctx->parse_inline_emit = getenv("K4LZ4_NO_INLINE_EMIT") == nullptr;
     if (const char *e = getenv("K4LZ4_PARSE_WAVES")) ctx->parse_waves = std::max(1, std::min(k4::PARSE_MAX_WAVES, atoi(e)));
     ctx->trace = getenv("K4LZ4_TRACE") != nullptr;
     if (e != hipSuccess) { delete ctx; return hip_fail(nullptr, e, "hipStreamCreate"); }

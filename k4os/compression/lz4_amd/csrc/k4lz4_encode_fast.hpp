@@ -972,7 +972,10 @@ __device__ __forceinline__ int codec_encode_result(int src_len, int ret, int fla
  * estimated by running the encoder without output over its first COST_SAMPLE bytes and scaling
  * the sequence count to the block length; blocks are then bucketed by cost (k4_order_kernel).
  */
-constexpr int COST_SAMPLE = 512;
+#ifndef K4_COST_SAMPLE
+#define K4_COST_SAMPLE 256
+#endif
+constexpr int COST_SAMPLE = K4_COST_SAMPLE;
 constexpr int COST_BUCKETS = 64;
 
 __device__ __forceinline__ uint32_t cost_bucket(unsigned long long cost)

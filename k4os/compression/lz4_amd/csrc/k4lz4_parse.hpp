@@ -41,7 +41,7 @@
 namespace k4 {
 
 #ifndef K4_PARSE_K
-#define K4_PARSE_K 2
+#define K4_PARSE_K 1
 #endif
 
 constexpr uint32_t PARSE_REC_STRIDE = 16384u;        /* records per block: a block below LIMIT_64K has fewer than (65546 - 6) / 4 + 1 sequences */
@@ -57,6 +57,11 @@ struct ParseArgs {
     uint32_t *meta;         /* per block: [0] number of sequences or PARSE_REST, [1] spare */
     uint32_t *gtab;         /* 4096 dwords per (workgroup, wave) for the waves without an LDS table */
     uint32_t nwg;           /* workgroups of the parse launch: block of (workgroup w, wave s) = order[s * nwg + w] */
+    uint32_t inline_emit;   /* != 0: the wave that parsed a block writes it out as well (k4_emit_kernel is not launched): the blocks that are
+                             * through early do that while the others still parse, only the last ones' bytes come on top of the launch */
+    uint32_t *queue;        /* nullptr, or three zeroed words: the launch has fewer waves than blocks and every wave takes the next block
+                             * when it is done with one -- [0] tickets handed out (never more than there are blocks), [1] taken from the front
+                             * of the order (the most expensive: by the waves with a table in LDS), [2] taken from its back (by the others) */
 };
 
 /* ------------------------------------------------------------------------------------------------------------------ */
@@ -85,6 +90,18 @@ __device__ __forceinline__ uint32_t ext12(uint32_t x0, uint32_t x1, uint32_t x2)
     return (t0 + (t0 == 32u ? hi : 0u)) >> 3;
 }
 
+/* the same over 28 bytes (seven words) */
+__device__ __forceinline__ uint32_t ext28(const uint32_t *x)
+{
+    uint32_t acc = min((uint32_t)(__ffs((int)x[6]) - 1), 32u);
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        const uint32_t t = min((uint32_t)(__ffs((int)x[i]) - 1), 32u);
+        acc = t + (t == 32u ? acc : 0u);
+    }
+    return acc >> 3;
+}
+
 /* hop word: bits 0-6 lane after the match (64 and more: outside the sub-window, 127 = "127 or more"), and the reasons to
  * leave the tight chain (all inside hop_chain's 0xf40): 0x40 = bit 6 of the lane, 0x100 the match runs past the 12 known
  * bytes, 0x200 a lane that shares its hash with an earlier lane of the round (0x1000 on top: its table candidate is no
@@ -96,9 +113,14 @@ constexpr uint32_t HOP_LONG = 0x100u, HOP_LAZY = 0x200u, HOP_END = 0x400u, HOP_I
  * LL64.LZ4_compress_generic (byU16, noDict, acceleration 1) for one block, sequences only.  `tab`: the block's 8192 x u16
  * table (LDS, or global memory with GT), `seen`: PARSE_SEEN_DWORDS dwords of LDS.  Returns the number of records written.
  */
-template <int K, bool GT>
-__device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32_t U, uint2 *recs, uint16_t *tab, uint32_t *seen, const int lane, unsigned long long *pc = nullptr)
+struct ParseStats { uint32_t rounds, slow, groups, lazies, longs; };      /* what a DRY run counts (the cost estimate's input) */
+
+template <int K, bool GT, bool DRY = false>
+__device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32_t U, uint2 *recs, uint16_t *tab, uint32_t *seen, const int lane, unsigned long long *pc = nullptr,
+                                                ParseStats *stats = nullptr)
 {
+    ParseStats st = {0u, 0u, 0u, 0u, 0u};
+#define K4_ST(field, v) do { if (DRY) st.field += (v); } while (0)
 #ifdef K4_PARSE_PROF
     /* diagnostic build: cycles per phase of a round (each phase ends by draining its own memory traffic) and event counts */
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pn[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = 0;
@@ -139,6 +161,17 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
     /* the next round's source bytes */
     U128u pw[K];
     uint32_t pre2 = 0u;
+    /* Blocks whose matches often run past the 12 bytes a round knows behind every probe (:326-329 then costs a trip to memory in the
+     * middle of the chain, ~1500 cycles under load) switch to rounds that know 28: 16 more bytes of every probe and candidate, about
+     * 25 more instructions per round.  Decided every 32 rounds from what the rounds before met. */
+#ifdef K4_PARSE_FORCE_MORE
+    bool more = true;                 /* (test builds: every round of the 28-byte form from the first on) */
+#else
+    bool more = false;
+#endif
+    U128u pw2;                      /* ... bytes 16 .. 31 at the probe positions of the next round */
+    uint32_t ahead = 0u;
+    uint32_t long_seen = 0u, long_rounds = 0u;
 
     auto prepare = [&]() {
         if (sj == 0u) {
@@ -148,7 +181,20 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                 const uint32_t a = p < U - 16u ? p : U - 16u;
                 pw[k] = ld128u(src + a);
             }
+            if (K == 1 && more) {
+                const uint32_t p2 = c + 16u + (uint32_t)lane;
+                pw2 = ld128u(src + (p2 < U - 16u ? p2 : U - 16u));
+            }
             pre2 = ld32u(src + (c >= 2u ? c - 2u : 0u));
+#ifdef K4_PARSE_AHEAD
+            /* the lines two rounds on: asked for now (after the loads this round's successor waits for, so that its wait does not
+             * include them), looked at never -- the asm below only keeps the compiler from dropping the load */
+            {
+                asm volatile("" :: "v"(ahead));
+                const uint32_t pa = c + (uint32_t)K4_PARSE_AHEAD + 4u * (uint32_t)lane;
+                ahead = ld32u(src + (pa < U - 4u ? pa : U - 4u));
+            }
+#endif
         } else {
             const uint32_t p = sbase + probe_offset(sj + (uint32_t)lane, 1u);
             const uint32_t a = p < U - 16u ? p : U - 16u;
@@ -156,6 +202,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         }
     };
     prepare();
+    (void)ahead;
 
     /* lanes of sub-window k whose position was put into the table, from the hits `hk` of its chain: not the lanes before its entry
      * cursor (except the one two before it when the cursor came from a match, :394), not the lanes inside matches (except the lane
@@ -183,6 +230,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         plast = prof_now<true>();
         K4_PN(0, 1); if (!plain) K4_PN(1, 1); if (strided) K4_PN(2, 1);
 #endif
+        K4_ST(rounds, 1u); K4_ST(slow, 1u);
 
         /* ---------------- front: positions, hashes, candidates, what each lane would do as a hit ---------------- */
         K4_PHASE("front");
@@ -246,7 +294,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
 #pragma unroll
                 for (int k = 0; k < K; k++) {
                     while (fl[k]) {
-                        K4_PN(3, 1);
+                        K4_PN(3, 1); K4_ST(groups, 1u);
                         const int j = ctz64(fl[k]);
                         const uint32_t hj = readlane_u32(h[k], j);
                         unsigned long long m[K];
@@ -393,7 +441,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                     }
                     if (hv & HOP_INVALID) { hits[k] &= ~(1ull << f); outcome = 2; upto_last = (uint32_t)f; done = true; return; }
                     if (hv & HOP_LAZY) {
-                        K4_PN(4, 1);
+                        K4_PN(4, 1); K4_ST(lazies, 1u);
                         { K4_TIC(); hv = resolve(kc, f); K4_TOC(7); }
                         if (hv == 0xffffffffu) {
                             hits[k] &= ~(1ull << f);
@@ -410,7 +458,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                     const uint32_t p = strided ? readlane_u32(pos[k], f) : w0 + (uint32_t)f;
                     uint32_t e_end;
                     if (hv & HOP_LONG) {                               /* :326-329 beyond the 12 known bytes */
-                        K4_PN(5, 1);
+                        K4_PN(5, 1); K4_ST(longs, 1u);
                         const uint32_t match = readlane_u32(cpos[k], f);
                         const uint32_t code = 12u + wave_count(src + p + 16u, src + match + 16u, matchlimit - (p + 16u), lane);
                         e_end = p + (uint32_t)MINMATCH + code;
@@ -486,7 +534,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
             for (int k = 0; k < K; k++) {
                 if (k >= KK) continue;
                 if (hits[k]) {
-                    if ((hits[k] >> lane) & 1ull)
+                    if (!DRY && ((hits[k] >> lane) & 1ull))
                         recs[at + (uint32_t)__popcll(hits[k] & below_me)] = make_uint2(pos[k], (pos[k] - cpos[k]) | (ecode[k] << 16));
                     at += (uint32_t)__popcll(hits[k]);
                 }
@@ -534,12 +582,15 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
      * one store by every visited lane plus a read-back (a position is later than whatever its slot held, so the put that must stand
      * is the largest: lanes that read back less than their own position store again), a lane that stops the chain for its group's
      * sake has its candidate's bytes compared in vector code against one broadcast lane. */
-    auto fast_round = [&]() -> bool {
+    auto fast_round = [&](auto more_c) -> bool {
+        constexpr bool MORE = decltype(more_c)::value;
+        constexpr uint32_t KNOWN = MORE ? 28u : 12u;
         const uint32_t c0 = c;
 #ifdef K4_PARSE_PROF
         plast = prof_now<true>();
         K4_PN(0, 1);
 #endif
+        K4_ST(rounds, 1u);
         K4_PHASE("front");
         const uint32_t p = c0 + (uint32_t)lane;
         const uint32_t w0 = pw[0].v[0], w1 = pw[0].v[1], w2 = pw[0].v[2], w3 = pw[0].v[3];
@@ -554,27 +605,35 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         }
         K4_PT(0);
         const U128u cw = ld128u(src + cd);
+        U128u cw2 = {{0u, 0u, 0u, 0u}};
+        if (MORE) cw2 = ld128u(src + cd + 16u);
         __builtin_amdgcn_wave_barrier();
         seen[hh >> 6] = 0u;
         /* groups */
         K4_PT(1);
         K4_PHASE("groups");
-        unsigned long long D0 = 0ull, G0 = 0ull;
+        unsigned long long D0 = 0ull;
+        unsigned long long G = me;            /* per lane: the lanes of the window with its hash */
         {
             unsigned long long fl = ballot(flg);
             while (fl) {
-                K4_PN(3, 1);
+                K4_PN(3, 1); K4_ST(groups, 1u);
                 const uint32_t hj = readlane_u32(hh, ctz64(fl));
-                const unsigned long long m = ballot(hh == hj);
+                const bool same = hh == hj;
+                const unsigned long long m = ballot(same);
                 fl &= ~m;
-                G0 |= m;
+                if (same) G = m;
                 D0 |= m & (m - 1ull);
             }
         }
         K4_PHASE("words");
         const bool hit = cw.v[0] == w0;
-        const uint32_t e = ext12(cw.v[1] ^ w1, cw.v[2] ^ w2, cw.v[3] ^ w3);
-        uint32_t word = ((uint32_t)lane + (uint32_t)MINMATCH + e) | (e == 12u ? HOP_LONG : 0u);
+        uint32_t e;
+        if (MORE) {
+            const uint32_t x[7] = {cw.v[1] ^ w1, cw.v[2] ^ w2, cw.v[3] ^ w3, cw2.v[0] ^ pw2.v[0], cw2.v[1] ^ pw2.v[1], cw2.v[2] ^ pw2.v[2], cw2.v[3] ^ pw2.v[3]};
+            e = ext28(x);
+        } else e = ext12(cw.v[1] ^ w1, cw.v[2] ^ w2, cw.v[3] ^ w3);
+        uint32_t word = ((uint32_t)lane + (uint32_t)MINMATCH + e) | (e == KNOWN ? HOP_LONG : 0u);
         if ((D0 >> lane) & 1ull) word |= HOP_LAZY | (hit ? 0u : HOP_TABMISS);
         uint32_t ec = e, cp = cd;
         unsigned long long hm = ballot(hit) | D0;
@@ -590,7 +649,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
             { K4_TIC(); hop_chain(hm, word, q, hts, f, hv, stop); K4_TOC(6); K4_PN(7, 1); }
             if (!stop) break;
             if (hv & HOP_LAZY) {
-                K4_PN(4, 1);
+                K4_PN(4, 1); K4_ST(lazies, 1u);
                 K4_TIC();
                 /* the latest VISITED lane below f with f's hash, if any: a lane is inside a match -- never put -- when it lies below the
                  * landing place of the nearest hit below it, other than two before it (:394) */
@@ -608,8 +667,13 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                 if (m) {
                     const int j = 63 - (int)__clzll((long long)m);
                     const uint32_t s0 = readlane_u32(w0, j), s1 = readlane_u32(w1, j), s2 = readlane_u32(w2, j), s3 = readlane_u32(w3, j);
-                    const uint32_t e2 = ext12(s1 ^ w1, s2 ^ w2, s3 ^ w3);
-                    const uint32_t wj = s0 != w0 ? 0xffffffffu : (((uint32_t)lane + (uint32_t)MINMATCH + e2) | (e2 == 12u ? HOP_LONG : 0u));
+                    uint32_t e2;
+                    if (MORE) {
+                        const uint32_t x[7] = {s1 ^ w1, s2 ^ w2, s3 ^ w3, readlane_u32(pw2.v[0], j) ^ pw2.v[0], readlane_u32(pw2.v[1], j) ^ pw2.v[1],
+                                               readlane_u32(pw2.v[2], j) ^ pw2.v[2], readlane_u32(pw2.v[3], j) ^ pw2.v[3]};
+                        e2 = ext28(x);
+                    } else e2 = ext12(s1 ^ w1, s2 ^ w2, s3 ^ w3);
+                    const uint32_t wj = s0 != w0 ? 0xffffffffu : (((uint32_t)lane + (uint32_t)MINMATCH + e2) | (e2 == KNOWN ? HOP_LONG : 0u));
                     hv = readlane_u32(wj, f);
                     if (lane == f) { word = wj; ec = e2; cp = c0 + (uint32_t)j; }
                 } else {
@@ -627,13 +691,14 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
             }
             uint32_t e_end = c0 + (hv & 127u);
             if (hv & HOP_LONG) {                               /* :326-329 beyond the 12 known bytes */
-                K4_PN(5, 1);
+                K4_PN(5, 1); K4_ST(longs, 1u);
                 const uint32_t pf = c0 + (uint32_t)f;
                 const uint32_t match = readlane_u32(cp, f);
-                const uint32_t code = 12u + wave_count(src + pf + 16u, src + match + 16u, matchlimit - (pf + 16u), lane);
+                const uint32_t code = KNOWN + wave_count(src + pf + 4u + KNOWN, src + match + 4u + KNOWN, matchlimit - (pf + 4u + KNOWN), lane);
                 e_end = pf + (uint32_t)MINMATCH + code;
                 const uint32_t qf = (uint32_t)f + (uint32_t)MINMATCH + code;
                 if (lane == f) { ec = code; word = qf < 127u ? qf : 127u; }
+                long_seen++;
                 if (e_end >= mfl1) { anchor = e_end; outcome = 2; upto = (uint32_t)f + 1u; break; }      /* :391 */
             }
             const uint32_t nq = e_end - c0;
@@ -652,11 +717,15 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
             if (c - sbase >= 66u) sj = 66u;
         }
         c = uni(c); sbase = uni(sbase); sj = uni(sj); test = uni(test ? 1u : 0u) != 0u;
+        const bool mine = ((hts >> lane) & 1ull) != 0ull;
+        if (MORE) long_seen += (uint32_t)__popcll(ballot(mine && ec > 12u));      /* (what a round that knows 12 bytes would have had to count) */
+#ifndef K4_PARSE_FORCE_MORE
+        if (++long_rounds == 32u) { more = uni(long_seen) >= 12u; long_seen = 0u; long_rounds = 0u; }
+#endif
         if (outcome != 2) prepare();
         K4_PHASE("records");
-        const bool mine = ((hts >> lane) & 1ull) != 0ull;
         if (hts) {
-            if (mine) recs[nrec + (uint32_t)__popcll(hts & below_me)] = make_uint2(p, (p - cp) | (ec << 16));
+            if (!DRY && mine) recs[nrec + (uint32_t)__popcll(hts & below_me)] = make_uint2(p, (p - cp) | (ec << 16));
             nrec += (uint32_t)__popcll(hts);
         }
         if (outcome == 2) return false;
@@ -677,21 +746,10 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         }
         K4_PT(4);
         K4_PHASE("commit");
-        if (hE2 != 0xffffffffu && lane == 0) tab[hE2] = (uint16_t)(c0 - 2u);
-        if (GT) wave_sync(); else __builtin_amdgcn_wave_barrier();      /* a lane of the round may put the same slot: it comes second */
-        const bool vis_me = ((vm >> lane) & 1ull) != 0ull;
-        if (vis_me) tab[hh] = (uint16_t)p;
-        {
-            unsigned long long again = vm & G0;
-            again = (again & (again - 1ull)) ? again : 0ull;         /* two visited lanes of groups at least */
-            while (again) {
-                if (GT) wave_sync(); else lds_sync();
-                const bool redo = ((again >> lane) & 1ull) != 0ull && (uint32_t)tab[hh] < (p & 0xffffu);
-                again = ballot(redo);
-                if (GT) wave_sync(); else __builtin_amdgcn_wave_barrier();
-                if (redo) tab[hh] = (uint16_t)p;
-            }
-        }
+        /* one writer per slot: of the visited lanes of a group the highest (the latest position is what a slot holds in the end); the
+         * put of c0 - 2 (:394) came before all of them and stands only where none of them has its hash */
+        if (hE2 != 0xffffffffu && (ballot(hh == hE2) & vm) == 0ull && lane == 0) tab[hE2] = (uint16_t)(c0 - 2u);
+        if (((vm >> lane) & 1ull) && (G & vm & ~(below_me | me)) == 0ull) tab[hh] = (uint16_t)p;
         if (GT) wave_sync(); else lds_sync();       /* (never a wait for the records' stores or the next round's loads) */
         K4_PT(5);
         return true;
@@ -699,7 +757,10 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
     for (;;) {
         const bool plain = sj == 0u && c + 64u * (uint32_t)K + 28u <= U;
         /* (the search's limit: probes up to sbase + 65 are contiguous, the window ends at c + 63) */
-        if (K == 1 && plain && c + 63u <= sbase + 65u) { if (!fast_round()) break; }
+        if (K == 1 && plain && c + 63u <= sbase + 65u) {
+            if (more && c + 108u <= U) { if (!fast_round(std::true_type{})) break; }
+            else if (!fast_round(std::false_type{})) break;
+        }
         else if (plain) { if (!round(std::true_type{})) break; }
         else if (!round(std::false_type{})) break;
     }
@@ -716,10 +777,14 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         pc[14] = pn[3] | (pn[5] << 32);                                /* groups | long counts << 32 */
     }
 #endif
+    if (DRY && stats) *stats = st;
+#undef K4_ST
     return nrec;
 }
 
 /* ------------------------------------------------------------------------------------------------------------------ */
+
+__device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, uint8_t *dst, const int dst_cap, const uint2 *recs, const uint32_t nseq, const int lane);
 
 template <int K>
 __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const ParseArgs &p, uint32_t *lds)
@@ -727,30 +792,50 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
     const int lane = lane_id();
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t waves = blockDim.x >> 6;
-    const long long idx = (long long)wave * (long long)p.nwg + (long long)blockIdx.x;
-    if (idx >= a.n) return;
-    const long long b = a.order ? (long long)uni(a.order[idx]) : idx;
-    const int src_len = a.srcLen[b];
-    uint32_t *meta = p.meta + 2ull * (unsigned long long)b;
-    if (src_len < (int)PARSE_MIN_LEN || src_len >= LIMIT_64K || a.accel != 1) {
-        if (lane == 0) { meta[0] = PARSE_REST; meta[1] = 0u; }
-        return;
-    }
-    const uint8_t *src = a.src + a.srcOff[b];
-    uint2 *recs = p.recs + (unsigned long long)b * PARSE_REC_STRIDE;
     const uint32_t lds_tables = waves < (uint32_t)PARSE_LDS_TABLES ? waves : (uint32_t)PARSE_LDS_TABLES;
     uint32_t *seen = lds + 4096u * (uint32_t)PARSE_LDS_TABLES + (uint32_t)PARSE_SEEN_DWORDS * wave;
-    uint32_t n;
-    unsigned long long *pc = nullptr;
+    const bool in_lds = wave < lds_tables;
+    for (long long idx = (long long)wave * (long long)p.nwg + (long long)blockIdx.x;;) {
+        if (p.queue) {
+            uint32_t t = 0u;
+            if (lane == 0) {
+                t = atomicAdd(p.queue, 1u);
+                if (t < (uint32_t)a.n) t = in_lds ? atomicAdd(p.queue + 1, 1u) : (uint32_t)a.n - 1u - atomicAdd(p.queue + 2, 1u);
+                else t = 0xffffffffu;
+            }
+            t = uni(t);
+            if (t == 0xffffffffu) return;
+            idx = (long long)t;
+        }
+        if (idx >= a.n) return;
+        const long long b = a.order ? (long long)uni(a.order[idx]) : idx;
+        const int src_len = a.srcLen[b];
+        uint32_t *meta = p.meta + 2ull * (unsigned long long)b;
+        if (src_len < (int)PARSE_MIN_LEN || src_len >= LIMIT_64K || a.accel != 1) {
+            if (lane == 0) { meta[0] = PARSE_REST; meta[1] = 0u; }
+        } else {
+            const uint8_t *src = a.src + a.srcOff[b];
+            uint2 *recs = p.recs + (unsigned long long)b * PARSE_REC_STRIDE;
+            uint32_t n;
+            unsigned long long *pc = nullptr;
 #ifdef K4_PARSE_PROF
-    if (a.prof) { pc = a.prof + PROF_STRIDE * b; prof_place<true>(pc, 8, lane); }
+            if (a.prof) { pc = a.prof + PROF_STRIDE * b; prof_place<true>(pc, 8, lane); }
 #endif
-    if (wave < lds_tables) n = parse_block<K, false>(src, (uint32_t)src_len, recs, (uint16_t *)(lds + 4096u * wave), seen, lane, pc);
-    else n = parse_block<K, true>(src, (uint32_t)src_len, recs, (uint16_t *)(p.gtab + 4096ull * ((unsigned long long)blockIdx.x * PARSE_MAX_WAVES + wave)), seen, lane, pc);
+            if (in_lds) n = parse_block<K, false>(src, (uint32_t)src_len, recs, (uint16_t *)(lds + 4096u * wave), seen, lane, pc);
+            else n = parse_block<K, true>(src, (uint32_t)src_len, recs, (uint16_t *)(p.gtab + 4096ull * ((unsigned long long)blockIdx.x * PARSE_MAX_WAVES + wave)), seen, lane, pc);
 #ifdef K4_PARSE_PROF
-    if (a.prof) { if (lane == 0) { pc[9] = __builtin_amdgcn_s_memrealtime(); pc[15] = wave < lds_tables ? 1u : 2u; } }
+            if (a.prof) { if (lane == 0) { pc[9] = __builtin_amdgcn_s_memrealtime(); pc[15] = in_lds ? 1u : 2u; } }
 #endif
-    if (lane == 0) { meta[0] = n; meta[1] = 0u; }
+            if (lane == 0) { meta[0] = n; meta[1] = 0u; }
+            if (p.inline_emit) {
+                wave_sync();                 /* the records are this wave's own stores: in order with the loads that follow */
+                const int cap = a.dstCap[b];
+                const int ret = emit_block(src, (uint32_t)src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, recs, n, lane);
+                if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
+            }
+        }
+        if (!p.queue) return;
+    }
 }
 
 constexpr int PARSE_LDS_DWORDS = 4096 * PARSE_LDS_TABLES + PARSE_SEEN_DWORDS * PARSE_MAX_WAVES;
@@ -759,6 +844,71 @@ __global__ __launch_bounds__(64 * PARSE_MAX_WAVES) void k4_parse_kernel(BatchArg
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[PARSE_LDS_DWORDS];
     parse_kernel_body<K4_PARSE_K>(a, p, lds);
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+
+/*
+ * Which blocks get the tables in LDS.  All blocks of a launch start together and the launch lasts as long as its slowest block; a
+ * block whose table lives in memory pays about two more trips to memory per round (the look-up, the wait for its puts), so the
+ * seven of sixteen waves per workgroup that have no LDS table should get the blocks that are through soonest WITH that penalty --
+ * few rounds count for more there than few sequences.  The estimate: the parse itself, without output, over the block's first
+ * bytes, in cycles by what it met (rounds, sequences, groups of equal hashes, stops for them, matches counted in memory; weights
+ * fitted to the phase probe, profiles/r5*_parse_probe.txt), scaled to the block's length, plus the penalty per round.  The order
+ * is by that figure, most expensive first, in 16 steps per octave.
+ */
+constexpr uint32_t PCOST_SAMPLE = 3072u;
+constexpr int PCOST_BUCKETS = 512;               /* 16 per octave from 2^8 on */
+constexpr int PCOST_WAVES_PER_WG = 8;
+
+__device__ __forceinline__ uint32_t pcost_bucket(unsigned long long cost)
+{
+    if (cost < 256ull) return 0u;
+    const uint32_t l = 63u - (uint32_t)__clzll((long long)cost);
+    const uint32_t b = 16u * (l - 8u) + (uint32_t)((cost >> (l - 4u)) & 15ull) + 1u;
+    return b < (uint32_t)PCOST_BUCKETS ? b : (uint32_t)PCOST_BUCKETS - 1u;
+}
+
+__global__ __launch_bounds__(64 * PCOST_WAVES_PER_WG) void k4_pcost_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[PCOST_WAVES_PER_WG][4096 + PARSE_SEEN_DWORDS];
+    const int lane = lane_id();
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const long long b = (long long)blockIdx.x * PCOST_WAVES_PER_WG + (long long)wave;
+    if (b >= a.n) return;
+    const int src_len = a.srcLen[b];
+    unsigned long long cost = 0ull;
+    if (src_len >= (int)PARSE_MIN_LEN && src_len < LIMIT_64K) {
+        const uint32_t sample = (uint32_t)src_len < PCOST_SAMPLE ? (uint32_t)src_len : PCOST_SAMPLE;
+        ParseStats st;
+        const uint32_t nseq = parse_block<1, false, true>(a.src + a.srcOff[b], sample, nullptr, (uint16_t *)lds[wave], lds[wave] + 4096, lane, nullptr, &st);
+        const unsigned long long cyc = 6500ull * st.rounds + 3000ull * st.slow + 120ull * nseq + 150ull * st.groups + 480ull * st.lazies + 1500ull * st.longs;
+        cost = cyc * (unsigned long long)(uint32_t)src_len / sample;
+    } else if (src_len > 0) {
+        cost = 120ull * (unsigned long long)(uint32_t)src_len;              /* (the one-kernel encoder's blocks: by length) */
+    }
+    if (lane == 0) {
+        const uint32_t bkt = pcost_bucket(cost);
+        a.cost[b] = bkt;
+        atomicAdd(&a.hist[bkt], 1u);
+    }
+}
+
+/* order[] = block indices, most expensive bucket first (hist: PCOST_BUCKETS counts, then PCOST_BUCKETS cursors, zeroed) */
+__global__ __launch_bounds__(256) void k4_porder_kernel(BatchArgs a)
+{
+    __shared__ uint32_t before[PCOST_BUCKETS];
+    for (int k = (int)threadIdx.x; k < PCOST_BUCKETS; k += 256) before[k] = a.hist[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {                     /* suffix sums: blocks in more expensive buckets */
+        uint32_t acc = 0u;
+        for (int k = PCOST_BUCKETS - 1; k >= 0; k--) { const uint32_t c = before[k]; before[k] = acc; acc += c; }
+    }
+    __syncthreads();
+    const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (b >= a.n) return;
+    const uint32_t bkt = a.cost[b];
+    a.order_out[before[bkt] + atomicAdd(&a.hist[PCOST_BUCKETS + bkt], 1u)] = (uint32_t)b;
 }
 
 /* ------------------------------------------------------------------------------------------------------------------ */
@@ -789,19 +939,46 @@ __device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, 
         const uint32_t ls = lane == 0 ? emitted_to : prev;
         const uint32_t lit0 = mine ? pos - ls : 0u;
         const uint32_t maxback = lit0 < cpos ? lit0 : cpos;                /* 0 right after a match */
+        /* everything this pass needs from the source, asked for together -- the four bytes before position and candidate for the
+         * backward extension, and the literal run in 8-byte pieces (a piece that holds a literal lies inside the block: a match
+         * and the last literals follow) -- so that a pass waits for memory once */
+        const bool near = mine && maxback != 0u && cpos >= 8u;
+        uint64_t pb = 0, cb = 1;
+        if (near) { pb = ld64u(src + pos - 8u); cb = ld64u(src + cpos - 8u); }
+        uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        const bool short_run = mine && lit0 != 0u && lit0 <= LANE_COPY_MAX;
+        if (short_run) {
+            v0 = ld64u(src + ls);
+            if (lit0 > 8u) v1 = ld64u(src + ls + 8u);
+            if (lit0 > 16u) v2 = ld64u(src + ls + 16u);
+            if (lit0 > 24u) v3 = ld64u(src + ls + 24u);
+        }
         uint32_t back = 0u;
         if (mine && maxback != 0u) {
-            if (cpos >= 4u) {                                           /* the four bytes before both at once, the rare longer run byte by byte */
-                const uint32_t y = ld32u(src + pos - 4u) ^ ld32u(src + cpos - 4u);
-                back = y ? (uint32_t)__clz(y) >> 3 : 4u;
+            if (cpos >= 8u) {                                           /* eight bytes at once, the rare longer run eight at a time */
+                const uint64_t y = pb ^ cb;
+                back = y ? (uint32_t)__clzll((long long)y) >> 3 : 8u;
                 if (back > maxback) back = maxback;
-                if (back == 4u) while (back < maxback && src[pos - 1u - back] == src[cpos - 1u - back]) back++;
+                bool full = y == 0ull;
+                uint32_t done = 8u;
+                while (full && done < maxback) {
+                    if (done + 8u <= cpos) {
+                        const uint64_t y2 = ld64u(src + pos - 8u - done) ^ ld64u(src + cpos - 8u - done);
+                        back = done + (y2 ? (uint32_t)__clzll((long long)y2) >> 3 : 8u);
+                        if (back > maxback) back = maxback;
+                        full = y2 == 0ull;
+                        done += 8u;
+                    } else {
+                        back = done;
+                        while (back < maxback && src[pos - 1u - back] == src[cpos - 1u - back]) back++;
+                        break;
+                    }
+                }
             } else {
                 while (back < maxback && src[pos - 1u - back] == src[cpos - 1u - back]) back++;
             }
         }
         const uint32_t ll = lit0 - back, mc = mine ? code + back : 0u;
-        const bool short_run = mine && ll != 0u && ll <= LANE_COPY_MAX;
         const uint32_t lx = ll >= (uint32_t)RUN_MASK ? (ll - RUN_MASK) / 255u + 1u : 0u;
         const uint32_t mx = mc >= (uint32_t)ML_MASK ? (mc - ML_MASK) / 255u + 1u : 0u;
         const uint32_t sz = mine ? 1u + lx + ll + 2u + mx : 0u;
@@ -821,15 +998,27 @@ __device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, 
             ((U16u *)(dst + o_off))->v = (uint16_t)(pos - cpos);   /* :299-304 */
             if (mx == 1u) dst[o_mx] = (uint8_t)(mc - ML_MASK);
         }
-        if (short_run) lane_copy32(dst + o_lit, src + ls, ll, U - ls);
-        unsigned long long big = ballot(mine && (ll > LANE_COPY_MAX || lx > 1u || mx > 1u));
+        if (short_run && ll != 0u) {                  /* exactly ll bytes, from the pieces */
+            uint8_t *d = dst + o_lit;
+            if (ll >= 8u) ((U64u *)d)->v = v0;
+            if (ll >= 16u) ((U64u *)(d + 8))->v = v1;
+            if (ll >= 24u) ((U64u *)(d + 16))->v = v2;
+            if (ll >= 32u) ((U64u *)(d + 24))->v = v3;
+            const uint32_t n8 = ll >> 3;
+            uint64_t vt = n8 == 0u ? v0 : n8 == 1u ? v1 : n8 == 2u ? v2 : v3;
+            d += 8u * n8;
+            if (ll & 4u) { ((U32u *)d)->v = (uint32_t)vt; vt >>= 32; d += 4; }
+            if (ll & 2u) { ((U16u *)d)->v = (uint16_t)vt; vt >>= 16; d += 2; }
+            if (ll & 1u) *d = (uint8_t)vt;
+        }
+        unsigned long long big = ballot(mine && (lit0 > LANE_COPY_MAX || lx > 1u || mx > 1u));
         while (big) {
             const int g = ctz64(big);
             big &= big - 1ull;
             const uint32_t g_ll = readlane_u32(ll, g), g_mc = readlane_u32(mc, g);
             const uint32_t g_tok = readlane_u32(o_tok, g);
             if (g_ll >= (uint32_t)RUN_MASK + 255u) emit_length_run(dst, g_tok + 1u, g_ll - RUN_MASK, lane);
-            if (g_ll > LANE_COPY_MAX) wave_copy(dst + readlane_u32(o_lit, g), src + readlane_u32(ls, g), g_ll, lane);
+            if (readlane_u32(lit0, g) > LANE_COPY_MAX) wave_copy(dst + readlane_u32(o_lit, g), src + readlane_u32(ls, g), g_ll, lane);
             if (g_mc >= (uint32_t)ML_MASK + 255u) emit_length_run(dst, readlane_u32(o_mx, g), g_mc - ML_MASK, lane);
         }
         op += total;

@@ -118,6 +118,10 @@ int k4emu_encode_parse_batch(const uint8_t *src, const uint64_t *srcOff, const i
                              const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int accel, int flags,
                              int K, int waves, const uint32_t *order, uint32_t *nseq_out, int threads)
 {
+    /* K + 16: the parsing waves write their blocks out themselves (ParseArgs::inline_emit) and k4_emit_kernel is not launched;
+     * K + 32: fewer waves than blocks, every wave takes the next block of the order when it is done with one (ParseArgs::queue) */
+    const bool inline_emit = (K & 16) != 0, use_queue = (K & 32) != 0;
+    K &= 15;
     if (n <= 0) return 0;
     k4::BatchArgs a{};
     a.src = src; a.srcOff = srcOff; a.srcLen = srcLen; a.dst = dst; a.dstOff = dstOff; a.dstCap = dstCap; a.outLen = outLen;
@@ -129,13 +133,34 @@ int k4emu_encode_parse_batch(const uint8_t *src, const uint64_t *srcOff, const i
     std::vector<uint2> recs((size_t)n * k4::PARSE_REC_STRIDE);
     std::vector<uint32_t> meta((size_t)n * 2, 0x12345678u), gtab((size_t)p.nwg * k4::PARSE_MAX_WAVES * 4096u, 0xdeadbeefu);
     p.recs = recs.data(); p.meta = meta.data(); p.gtab = gtab.data();
+    p.inline_emit = inline_emit ? 1u : 0u;
+    std::vector<uint32_t> q(4, 0u);
+    std::vector<uint32_t> ident;
+    if (use_queue) {
+        p.queue = q.data();
+        if (p.nwg > 2) p.nwg = 2;                       /* two workgroups' waves share the whole batch */
+        if (!a.order) { ident.resize((size_t)n); for (long long i = 0; i < n; i++) ident[(size_t)i] = (uint32_t)i; a.order = ident.data(); }
+    }
     if (K == 1) emu_parse_launch<1>(a, p, (unsigned)waves, threads);
     else if (K == 2) emu_parse_launch<2>(a, p, (unsigned)waves, threads);
     else if (K == 3) emu_parse_launch<3>(a, p, (unsigned)waves, threads);
     else emu_parse_launch<4>(a, p, (unsigned)waves, threads);
-    k4emu::launch_fn(dim3((unsigned)((n + k4::EMIT_WAVES_PER_WG - 1) / k4::EMIT_WAVES_PER_WG)), dim3(64 * k4::EMIT_WAVES_PER_WG), [=] { k4::k4_emit_kernel(a, p); }, threads);
+    if (!inline_emit) k4emu::launch_fn(dim3((unsigned)((n + k4::EMIT_WAVES_PER_WG - 1) / k4::EMIT_WAVES_PER_WG)), dim3(64 * k4::EMIT_WAVES_PER_WG), [=] { k4::k4_emit_kernel(a, p); }, threads);
     k4emu::launch_fn(dim3((unsigned)((n + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG), [=] { k4::k4_encode_fast_rest_kernel(a, p); }, threads);
     if (nseq_out) for (long long i = 0; i < n; i++) nseq_out[i] = meta[(size_t)i * 2];
+    return 0;
+}
+
+/* the two-kernel encoder's own cost estimate (a parse without output over the block's first bytes) and order */
+int k4emu_porder(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, long long n, uint32_t *cost, uint32_t *order, int threads)
+{
+    k4::BatchArgs a{};
+    a.src = src; a.srcOff = srcOff; a.srcLen = srcLen; a.n = n; a.accel = 1;
+    std::vector<uint32_t> hist(2 * k4::PCOST_BUCKETS, 0u);
+    a.cost = cost; a.hist = hist.data(); a.order_out = order;
+    if (n <= 0) return 0;
+    k4emu::launch_fn(dim3((unsigned)((n + k4::PCOST_WAVES_PER_WG - 1) / k4::PCOST_WAVES_PER_WG)), dim3(64 * k4::PCOST_WAVES_PER_WG), [=] { k4::k4_pcost_kernel(a); }, threads);
+    k4emu::launch_fn(dim3((unsigned)((n + 255) / 256)), dim3(256), [=] { k4::k4_porder_kernel(a); }, 1);
     return 0;
 }
 

@@ -107,14 +107,14 @@ class Emu:
         assert rc == 0
         return out
 
-    def encode_parse_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, accel=1, flags=0, k=2, waves=16, order=None, threads=0):
+    def encode_parse_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, accel=1, flags=0, k=1, waves=16, order=None, threads=0, inline_emit=False, queue=False):
         """the two-kernel fast encoder (k4lz4_parse.hpp): parse with k sub-windows per round and `waves` blocks per workgroup
         (those beyond 9 keep their table in memory), emit, then the one-kernel encoder for the blocks the parse left alone.
         Returns (outLen, sequences per block -- 0xffffffff where the parse left the block alone)."""
         out = np.full(len(src_len), -12345, dtype=np.int32)
         nseq = np.zeros(len(src_len), dtype=np.uint32)
         rc = self.lib.k4emu_encode_parse_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst), dst_off.ctypes.data,
-                                               dst_cap.ctypes.data, out.ctypes.data, len(src_len), accel, flags, k, waves,
+                                               dst_cap.ctypes.data, out.ctypes.data, len(src_len), accel, flags, k + (16 if inline_emit else 0) + (32 if queue else 0), waves,
                                                order.ctypes.data if order is not None else None, nseq.ctypes.data, threads)
         assert rc == 0
         return out, nseq
@@ -151,6 +151,15 @@ class Emu:
                                            out.ctypes.data, len(src_len), threads)
         assert rc == 0
         return out
+
+    def porder(self, src, src_off, src_len, threads=0):
+        """k4_pcost_kernel + k4_porder_kernel: (cost bucket per block, dispatch order)"""
+        n = len(src_len)
+        cost = np.zeros(n, np.uint32); order = np.full(n, 0xFFFFFFFF, np.uint32)
+        self.lib.k4emu_porder.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int]
+        rc = self.lib.k4emu_porder(self._p(src), src_off.ctypes.data, src_len.ctypes.data, n, cost.ctypes.data, order.ctypes.data, threads)
+        assert rc == 0
+        return cost, order
 
     def order(self, src, src_off, src_len, by_length=0, threads=0):
         n = len(src_len)

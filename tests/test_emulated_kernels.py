@@ -59,8 +59,8 @@ def test_encode_fast_matches_oracle(emu, oracle, variant):
     assert (dst[mask] == 0xCD).all()
 
 
-@pytest.mark.parametrize("k,waves", [(1, 1), (2, 16), (2, 9), (3, 12), (4, 5)])
-def test_encode_parse_emit_matches_oracle(emu, oracle, k, waves):
+@pytest.mark.parametrize("k,waves,how", [(1, 1, ""), (1, 16, "inline"), (1, 12, "inline+queue"), (2, 16, ""), (2, 9, "inline"), (3, 12, "queue"), (4, 5, "")])
+def test_encode_parse_emit_matches_oracle(emu, oracle, k, waves, how):
     """the two-kernel fast encoder (k4lz4_parse.hpp: which sequences, then their bytes): k sub-windows of 64 positions per
     round, `waves` blocks per workgroup of which those beyond nine keep their table in memory; blocks it leaves alone
     (under 128 bytes, 65 547 and more) come out of the one-kernel encoder behind it"""
@@ -74,7 +74,7 @@ def test_encode_parse_emit_matches_oracle(emu, oracle, k, waves):
     src, soff, slen = pack(blocks)
     dst, doff, dcap = arena([oracle.compress_bound(b.size) for b in blocks])
     order = np.random.default_rng(k).permutation(len(blocks)).astype(np.uint32) if waves != 9 else None
-    out, nseq = emu.encode_parse_batch(src, soff, slen, dst, doff, dcap, k=k, waves=waves, order=order)
+    out, nseq = emu.encode_parse_batch(src, soff, slen, dst, doff, dcap, k=k, waves=waves, order=order, inline_emit="inline" in how, queue="queue" in how)
     for i, b in enumerate(blocks):
         want = oracle.encode(b)
         if b.size == 0:
@@ -104,7 +104,7 @@ def test_encode_parse_emit_limited_output_and_acceleration(emu, oracle):
             wants.append((r, bytes(enc[:max(r, 0)])))
     src, soff, slen = pack(blocks)
     dst, doff, dcap = arena(caps)
-    out, _ = emu.encode_parse_batch(src, soff, slen, dst, doff, dcap, flags=FLAG_RAW, k=2, waves=7)
+    out, _ = emu.encode_parse_batch(src, soff, slen, dst, doff, dcap, flags=FLAG_RAW, k=1, waves=7, inline_emit=True)
     for i, (r, enc) in enumerate(wants):
         assert out[i] == (r if r > 0 else 0), (i, caps[i])
         if r > 0:
