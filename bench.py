@@ -10,11 +10,13 @@ rank works on its own 4096 blocks (weak scaling), no data-path collective; the i
 is all-gathered once outside the timed region.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (the encoder) -- algorithmic bytes per launch (sum(U)+sum(C)+12N)
-                / average launch duration measured with HIP events on the launch stream
+  roofline      dominant kernel (the encoder: k4_parse_kernel, which decides the sequences and writes the blocks
+                out) -- algorithmic bytes per launch (sum(U)+sum(C)+12N) / median launch duration measured
+                with HIP events on the launch stream
   roofline_decode  the same for the decode kernel (the BASELINE.json 50%-of-HBM target)
-  cpu_baseline  the oracle (C restatement of the reference's LL64 engine; the reference is C# and
-                cannot run here) on the host cores, same blocks, T threads
+  cpu_baseline  kind "reference": the reference's own LL64 engine files compiled here (oracle/_ref, built by
+                oracle/make_ref.py + g++) on the host cores, same blocks, T threads; the C restatement
+                (oracle/k4lz4_oracle.c, "port") and liblz4 are kept as columns beside it
 """
 from __future__ import annotations
 
@@ -216,35 +218,61 @@ def main():
     else:
         total_c = sum_c
 
-    result = None
-    if rank == 0:
+    # Bit-exactness is every rank's to show for its OWN blocks: each rank encodes its blocks with the oracle (and with the compiled
+    # reference where oracle/_ref is built), compares every block's bytes with what its GPU wrote, and the verdicts are reduced
+    # with MIN -- `bit_exact` in the line is all ranks' data, not rank 0's share.  (K4LZ4_TEST_CORRUPT_RANK=r: rank r flips one
+    # byte of its copy of the GPU's output first -- the test that the reduction really carries a failure through.)
+    from k4os.compression.lz4_amd import make_arena
+    src_h = blocks.reshape(-1)
+    caps = np.full(n, bound, np.int32)
+    threads = os.cpu_count() or 1
+    oracle = None
+    my_exact, my_ref_equal = None, None
+    ref_dst = ref_off = ref_len = comp_h = coff_h = None
+    t_enc = []
+    if not args.no_verify or (rank == 0 and not args.no_cpu_baseline):
         from oracle_lib import Oracle
         oracle = Oracle()
-        bit_exact = None
-        cpu = None
-        src_h = blocks.reshape(-1)
-        caps = np.full(n, bound, np.int32)
-        from k4os.compression.lz4_amd import make_arena
         ref_dst, ref_off = make_arena(caps)
-        threads = os.cpu_count() or 1
-        if not args.no_verify or not args.no_cpu_baseline:
-            # oracle encode of the whole batch: doubles as the bit-exactness check and the CPU baseline
-            t_enc = []
-            for _ in range(2):
-                t = time.perf_counter()
-                ref_len = oracle.encode_batch(src_h, off, lens, ref_dst, ref_off, caps, threads=threads)
-                t_enc.append(time.perf_counter() - t)
-            comp_h = comp.data.cpu().numpy()
-            coff_h = comp.off.cpu().numpy()
-            bit_exact = bool(np.array_equal(ref_len, clen_h.astype(np.int32)))
-            if bit_exact:
-                for i in range(n):
-                    a = comp_h[coff_h[i]:coff_h[i] + clen_h[i]]
-                    b = ref_dst[int(ref_off[i]):int(ref_off[i]) + int(ref_len[i])]
-                    if not np.array_equal(a, b):
-                        bit_exact = False
-                        break
-            bit_exact = bit_exact and ok_roundtrip
+        for _ in range(2):
+            t = time.perf_counter()
+            ref_len = oracle.encode_batch(src_h, off, lens, ref_dst, ref_off, caps, threads=threads)
+            t_enc.append(time.perf_counter() - t)
+        comp_h = comp.data.cpu().numpy()
+        coff_h = comp.off.cpu().numpy()
+        if os.environ.get("K4LZ4_TEST_CORRUPT_RANK") == str(rank):
+            comp_h = comp_h.copy()
+            comp_h[int(coff_h[n // 2]) + 7] ^= 0x20
+
+        def same_bytes(e_len, e_dst):
+            return bool(np.array_equal(e_len, clen_h.astype(np.int32))) and all(
+                np.array_equal(comp_h[coff_h[i]:coff_h[i] + clen_h[i]], e_dst[int(ref_off[i]):int(ref_off[i]) + int(e_len[i])]) for i in range(n))
+
+        my_exact = same_bytes(ref_len, ref_dst) and ok_roundtrip
+        if not args.no_verify:
+            try:
+                from oracle_lib import RefEngine
+                ref_engine = RefEngine()
+                ref2_dst, _ = make_arena(caps)
+                ref2_len = ref_engine.encode_batch(src_h, off, lens, ref2_dst, ref_off, caps, threads=threads)
+                my_ref_equal = same_bytes(ref2_len, ref2_dst)
+            except FileNotFoundError:
+                my_ref_equal = None
+    all_exact, all_ref_equal, all_roundtrip = my_exact, my_ref_equal, ok_roundtrip
+    if world > 1:
+        # -1 = this rank did not check; the line's flag is true only when every rank checked and every rank's check held
+        v = torch.tensor([-1 if my_exact is None else int(my_exact), -1 if my_ref_equal is None else int(my_ref_equal), int(ok_roundtrip)],
+                         dtype=torch.int32, device=on)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        all_exact = None if int(v[0]) < 0 else bool(int(v[0]))
+        all_ref_equal = None if int(v[1]) < 0 else bool(int(v[1]))
+        all_roundtrip = bool(int(v[2]))
+
+    result = None
+    if rank == 0:
+        bit_exact = all_exact
+        cpu = None
+        if oracle is not None:
             if not args.no_cpu_baseline:
                 out_h, out_off = make_arena(lens)
                 gib = sum_u / 2 ** 30
@@ -272,11 +300,8 @@ def main():
                     ref_engine = RefEngine()
                     ref_cpu = timed(ref_engine, "oracle/_ref/libk4ref.so: the reference's own LL64 engine files (Engine/x64/LL64.fast.cs, LL64.dec.cs) "
                                                 "respelled as C++ by oracle/make_ref.py, g++ -O2 -fwrapv")
-                    # and its bytes against the GPU's, block by block (the restatement's were compared above)
-                    ref2_dst, _ = make_arena(caps)
-                    ref2_len = ref_engine.encode_batch(src_h, off, lens, ref2_dst, ref_off, caps, threads=threads)
-                    ref_cpu["equals_gpu_bytes"] = bool(np.array_equal(ref2_len, clen_h.astype(np.int32))) and all(
-                        np.array_equal(comp_h[coff_h[i]:coff_h[i] + clen_h[i]], ref2_dst[int(ref_off[i]):int(ref_off[i]) + int(ref2_len[i])]) for i in range(n))
+                    # its bytes against the GPU's, block by block, on EVERY rank (reduced above; the restatement's likewise)
+                    ref_cpu["equals_gpu_bytes"] = all_ref_equal
                 except FileNotFoundError:
                     pass
                 # "as sanity, liblz4.so.1" -- one thread (ctypes calls hold no batch entry point), 256 blocks
@@ -393,7 +418,8 @@ def main():
             tr = [traffic.get(k) for k in kernels]
             return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": sum(tr) if tr and all(t is not None for t in tr) else None,
-                    "avg_launch_ms": round(med_ms, 4), "avg_is": "median of the timed launches", "mean_launch_ms": round(mean_ms, 4),
+                    "median_launch_ms": round(med_ms, 4), "mean_launch_ms": round(mean_ms, 4),
+                    "avg_launch_ms": round(med_ms, 4), "avg_is": "median of the timed launches (= median_launch_ms; the rates above derive from it)",
                     "algorithmic_bytes_per_launch": alg_bytes, "issue": iss,
                     "kernel": " || ".join(kernels), "timed": timed}
 
@@ -404,7 +430,15 @@ def main():
             except Exception:
                 n_seq = None
 
-        dec_kernel = "k4_decode_pair_kernel" if n <= 16 * 256 and not os.environ.get("K4LZ4_NO_PAIR") else "k4_decode_kernel"
+        cus = torch.cuda.get_device_properties(device).multi_processor_count or 256
+        dec_kernel = "k4_decode_pair_kernel" if n <= 16 * cus and not os.environ.get("K4LZ4_NO_PAIR") else "k4_decode_kernel"
+        if os.environ.get("K4LZ4_NO_PARSE"):
+            enc_kernels = ["k4_encode_fast_gtab_kernel", "k4_encode_fast_kernel"]
+            enc_timed = "k4lz4_encode_batch_device call, HIP events on the launch stream (cost + order kernels, then both one-kernel encoders concurrently)"
+        else:
+            enc_kernels = ["k4_parse_kernel"] + ([] if not os.environ.get("K4LZ4_NO_INLINE_EMIT") else ["k4_emit_kernel"])
+            enc_timed = ("k4lz4_encode_batch_device call, HIP events on the launch stream: k4_cost_kernel + k4_order_kernel (0.09 ms), then "
+                         "k4_parse_kernel -- sequences and bytes of every block, one wavefront per block, 16 blocks per workgroup")
         result = {
             "metric": "GiB/s encode+decode on batched 64 KiB blocks; bit-exact vs C# ref",
             "value": round(world * sum_u / 2 ** 30 / (elapsed / args.steps), 3),
@@ -422,11 +456,12 @@ def main():
                        "decode_GiBs_per_gpu": round(sum_u / 2 ** 30 / (dec_avg * 1e-3), 3),
                        "parallelism": f"{world} x independent block ranges, no data-path collective"},
             "bit_exact": bit_exact,
-            # what the events bracket: the whole library call on its launch stream.  Encode = k4_cost_kernel + k4_order_kernel
-            # (0.14 ms together), then the two encoder kernels side by side on two queues; the longer of the two is the call.
-            "roofline": roof(enc_avg, float(enc_ms.mean()), ["k4_encode_fast_gtab_kernel", "k4_encode_fast_kernel"],
-                             "k4lz4_encode_batch_device call, HIP events on the launch stream (cost + order kernels, then both encoder kernels concurrently)",
-                             issue(["k4_encode_fast_gtab_kernel", "k4_encode_fast_kernel"], n * bs / 64.0, "wave_insts_per_64_positions", enc_avg)),
+            "bit_exact_scope": f"all {world} rank(s): every rank compares its own {n} blocks with the oracle" +
+                               (" and with the compiled reference" if all_ref_equal is not None else "") + ", verdicts reduced with MIN",
+            "roundtrip_all_ranks": all_roundtrip,
+            # what the events bracket: the whole library call on its launch stream (enc_timed says which kernels that is)
+            "roofline": roof(enc_avg, float(enc_ms.mean()), enc_kernels, enc_timed,
+                             issue(enc_kernels, n * bs / 64.0, "wave_insts_per_64_positions", enc_avg)),
             # batches of up to 16 blocks per CU are decoded by the two-waves-per-block kernel (k4lz4_capi.hip launch())
             "roofline_decode": roof(dec_avg, float(dec_ms.mean()), [dec_kernel],
                                     "k4lz4_decode_batch_device call, HIP events on the launch stream (one kernel)",

@@ -496,3 +496,12 @@ def test_headline_bench_with_two_ranks_is_the_command_the_scaling_run_launches(o
         want += int(oracle.encode_batch(blocks.reshape(-1), off, lens, dst, doff, caps, threads=THREADS).astype(np.int64).sum())
     assert r["config"]["total_compressed_bytes_all_gpus"] == want
     assert r["value"] > 0 and abs(r["value"] - 2 * nb * 65536 / 2 ** 30 / (r["ms_per_step"] * 1e-3)) < 0.01 * r["value"]
+    assert "all 2 rank(s)" in r["bit_exact_scope"] and r["roundtrip_all_ranks"] is True
+    # `bit_exact` vouches for EVERY rank's blocks: one byte of rank 1's output flipped (in its host copy, before its own comparison
+    # with the oracle) must turn the line's flag to false although rank 0's share is intact
+    env_bad = dict(env, K4LZ4_TEST_CORRUPT_RANK="1")
+    cmd_bad = [c if c != "29579" else "29581" for c in cmd]
+    p = subprocess.run(cmd_bad, cwd=root, env=env_bad, capture_output=True, text=True, timeout=900)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and lines, p.stderr[-2000:]
+    assert json.loads(lines[-1])["bit_exact"] is False

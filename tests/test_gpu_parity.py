@@ -411,6 +411,47 @@ def test_dispatch_variants_give_identical_bytes(oracle):
         assert np.array_equal(out, want) and np.array_equal(dst, ref_dst)
 
 
+def test_fast_encoder_paths_give_identical_bytes(oracle):
+    """Which kernels encode a fast-level batch is scheduling only: the two-kernel path of k4lz4_parse.hpp (parse + write-out by
+    the parsing wave, or by k4_emit_kernel: K4LZ4_NO_INLINE_EMIT; 16 or fewer blocks per workgroup: K4LZ4_PARSE_WAVES; waves that
+    take their blocks from a queue: K4LZ4_PARSE_QUEUE) with the one-kernel encoder behind it for the blocks it leaves alone, or
+    the one-kernel encoders alone (K4LZ4_NO_PARSE).  Every one of them: the oracle's bytes, length and failures included."""
+    import os
+    from k4os.compression.lz4_amd import _native
+    rng = np.random.default_rng(21)
+    blocks = [b for b in corpus.silesia_like_blocks(1500, 16384, seed=5)]
+    blocks += [b for b in corpus.silesia_like_blocks(60, 65536, seed=6)]
+    blocks += [corpus.lorem(n) for n in (0, 1, 12, 13, 64, 127, 128, 129, 200, 65546, 65547, 70000)]
+    blocks += [corpus.class_bytes("samba", 150000, 3), corpus.random_bytes(65000, 9), corpus.repeated(7, 65536)]
+    caps = []
+    for b in blocks:
+        bound = LZ4Codec.MaximumOutputSize(b.size)
+        caps.append(bound if rng.random() < 0.8 else int(rng.integers(0, bound + 1)))
+    caps = np.array(caps, np.int32)
+    src, soff, slen = pack_blocks(blocks)
+    ref_dst, ref_off = make_arena(caps + 16, fill=0xCD)
+    want = oracle.encode_batch(src, soff, slen, ref_dst, ref_off, caps, threads=8)
+    envs = [{}, {"K4LZ4_NO_PARSE": "1"}, {"K4LZ4_NO_INLINE_EMIT": "1"}, {"K4LZ4_PARSE_WAVES": "5"},
+            {"K4LZ4_PARSE_QUEUE": "1", "K4LZ4_PARSE_WAVES": "3"}, {"K4LZ4_PCOST": "1"}]
+    for env in envs:
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ctx = _native.Context(-1)            # (the switches are read when a context is made)
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+        for flags in (0, 4):                     # cost order / index order
+            dst, doff = make_arena(caps + 16, fill=0xCD)
+            out = LZ4Codec.EncodeBatchPacked(src, soff, slen, dst, doff, caps, flags=flags, ctx=ctx)
+            assert np.array_equal(out, want), (env, flags, np.nonzero(out != want)[0][:5])
+            for i in np.nonzero(want > 0)[0]:
+                a = dst[int(doff[i]):int(doff[i]) + caps[i] + 16]; b = ref_dst[int(ref_off[i]):int(ref_off[i]) + caps[i] + 16]
+                assert np.array_equal(a[:want[i]], b[:want[i]]) and (a[want[i]:] == 0xCD).all(), (env, flags, int(i))
+        ctx.close()
+
+
 def test_decoder_kernel_variants_give_identical_results(oracle):
     """Which decoder kernel a batch gets is scheduling only: two waves per block (up to 16 blocks per CU), one wave
     per block (K4LZ4_NO_PAIR=1, or up to 24 per CU), the dense build (more).  Same bytes and the same verdict on

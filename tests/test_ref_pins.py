@@ -273,3 +273,18 @@ def test_long_length_fields(ref, oracle):
         assert a[0] == b[0], (i, c.size, cap)
         if defined and a[0] > 0:
             assert a[1][:a[0]].tobytes() == b[1][:a[0]].tobytes(), (i, c.size, cap)
+
+
+def test_signcheck_is_clean():
+    """`make -C oracle ref-signcheck`: the generated C++ under -Wsign-compare -Wsign-conversion.  C# widens mixed int / uint
+    arithmetic to long where C++ converts to unsigned, so a translator change that introduced such a site would change results
+    silently; the build itself runs with -w.  The only lines allowed are the two pointer -> uint casts of LL64.high.cs:1341 /
+    LL32.high.cs (an alignment test, which is why the library is built with -fpermissive)."""
+    import subprocess
+    if not REFERENCE_PRESENT:
+        pytest.skip("/root/reference absent: nothing to translate here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle"), "ref-signcheck"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if "warning" in l]
+    assert len(lines) == 2 and all("LZ4_streamHC_t*" in l and "loses precision [-fpermissive]" in l for l in lines), lines
