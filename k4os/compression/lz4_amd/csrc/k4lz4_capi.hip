@@ -115,6 +115,7 @@ struct k4lz4_ctx {
     bool use_parse = true;                /* K4LZ4_NO_PARSE: fast-level batches go to the one-kernel encoders as before */
     bool parse_queue = false;             /* K4LZ4_PARSE_QUEUE */
     bool parse_inline_emit = true;        /* K4LZ4_NO_INLINE_EMIT: the blocks' bytes by k4_emit_kernel behind the parse instead of by the parsing waves themselves */
+    bool parse_migrate = true;            /* K4LZ4_NO_MIGRATE: blocks whose table lives in memory stay there (k4lz4_parse.hpp, ParseCtl) */
     bool parse_pcost = false;             /* K4LZ4_PCOST: the parse's own cost estimate (k4_pcost_kernel) orders the blocks; measured: costs more than it gains */
     int parse_waves = 16;                 /* K4LZ4_PARSE_WAVES: blocks per workgroup (= per CU) of the parse kernel, at most PARSE_MAX_WAVES */
     bool trace = false;         /* K4LZ4_TRACE: host-pointer calls print where their time went (stderr) */
@@ -580,6 +581,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             pa.recs = (uint2 *)ctx->d_parse; pa.meta = (uint32_t *)(ctx->d_parse + o_meta); pa.gtab = (uint32_t *)(ctx->d_parse + o_gtab);
             pa.nwg = (uint32_t)nwg;
             pa.inline_emit = ctx->parse_inline_emit ? 1u : 0u;
+            pa.migrate = ctx->parse_migrate ? 1u : 0u;
             if (queue) {
                 pa.queue = pa.meta + 2 * cnt;
                 K4_HIP(ctx, hipMemsetAsync(pa.queue, 0, 16, stream));
@@ -1367,6 +1369,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     ctx->use_parse = getenv("K4LZ4_NO_PARSE") == nullptr;
     ctx->parse_queue = getenv("K4LZ4_PARSE_QUEUE") != nullptr;
     ctx->parse_pcost = getenv("K4LZ4_PCOST") != nullptr;
+    ctx->parse_migrate = getenv("K4LZ4_NO_MIGRATE") == nullptr;
     ctx->parse_inline_emit = getenv("K4LZ4_NO_INLINE_EMIT") == nullptr;
     if (const char *e = getenv("K4LZ4_PARSE_WAVES")) ctx->parse_waves = std::max(1, std::min(k4::PARSE_MAX_WAVES, atoi(e)));
     ctx->trace = getenv("K4LZ4_TRACE") != nullptr;

@@ -51,12 +51,15 @@ constexpr int PARSE_MAX_WAVES = 16;                  /* waves (= blocks) per wor
 constexpr int PARSE_LDS_TABLES = 9;                  /* of which so many have their table in LDS (9 x 16 KiB + 16 x 512 B of 160 KiB) */
 constexpr int PARSE_SEEN_DWORDS = 128;               /* one bit per two hash values */
 
+constexpr int PARSE_LDS_DWORDS = 4096 * PARSE_LDS_TABLES + PARSE_SEEN_DWORDS * PARSE_MAX_WAVES + 4;      /* + the workgroup's free-table word */
+
 struct ParseArgs {
     uint2 *recs;            /* PARSE_REC_STRIDE records per block: x = position of the match (before backward extension),
                              * y = offset | (match length - MINMATCH) << 16 */
     uint32_t *meta;         /* per block: [0] number of sequences or PARSE_REST, [1] spare */
     uint32_t *gtab;         /* 4096 dwords per (workgroup, wave) for the waves without an LDS table */
     uint32_t nwg;           /* workgroups of the parse launch: block of (workgroup w, wave s) = order[s * nwg + w] */
+    uint32_t migrate;       /* != 0: blocks without an LDS table move into one when a block of their workgroup is done with it (ParseCtl) */
     uint32_t inline_emit;   /* != 0: the wave that parsed a block writes it out as well (k4_emit_kernel is not launched): the blocks that are
                              * through early do that while the others still parse, only the last ones' bytes come on top of the launch */
     uint32_t *queue;        /* nullptr, or three zeroed words: the launch has fewer waves than blocks and every wave takes the next block
@@ -113,11 +116,23 @@ constexpr uint32_t HOP_LONG = 0x100u, HOP_LAZY = 0x200u, HOP_END = 0x400u, HOP_I
  * LL64.LZ4_compress_generic (byU16, noDict, acceleration 1) for one block, sequences only.  `tab`: the block's 8192 x u16
  * table (LDS, or global memory with GT), `seen`: PARSE_SEEN_DWORDS dwords of LDS.  Returns the number of records written.
  */
-struct ParseStats { uint32_t rounds, slow, groups, lazies, longs; };      /* what a DRY run counts (the cost estimate's input) */
+struct ParseStats { uint32_t rounds, slow, groups, lazies, longs; };
+
+/* A block whose table lives in memory may move into an LDS table that another block of its workgroup has finished with: the
+ * waves with LDS tables set their bit in *free_slots when their parse is through; a wave without one looks at the word every 16
+ * rounds, claims a bit (atomic AND) and returns from parse_block with its state here; the kernel copies the table from memory into
+ * the slot and calls parse_block's LDS form with `resume`.  The encoder's state between two rounds is just these words. */
+struct ParseCtl {
+    uint32_t *free_slots;       /* LDS word of the workgroup, or nullptr */
+    int claimed;                /* out: the slot claimed (parse_block returned early), else -1 */
+    bool resume;                /* in: go on from the state below (the table is in place) */
+    uint32_t c, sbase, sj, nrec, long_seen, long_rounds;
+    bool test, more;
+};      /* what a DRY run counts (the cost estimate's input) */
 
 template <int K, bool GT, bool DRY = false>
 __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32_t U, uint2 *recs, uint16_t *tab, uint32_t *seen, const int lane, unsigned long long *pc = nullptr,
-                                                ParseStats *stats = nullptr)
+                                                ParseStats *stats = nullptr, ParseCtl *ctl = nullptr)
 {
     ParseStats st = {0u, 0u, 0u, 0u, 0u};
 #define K4_ST(field, v) do { if (DRY) st.field += (v); } while (0)
@@ -140,7 +155,8 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
     const uint32_t last_valid = U - (uint32_t)MFLIMIT;         /* a probe at p happens iff p + step <= mflimitPlusOne (:172, :391) */
     const unsigned long long me = 1ull << lane, below_me = me - 1ull;
 
-    for (int k = lane; k < 1024; k += 64) ((uint4 *)tab)[k] = make_uint4(0u, 0u, 0u, 0u);     /* LZ4_initStream; put(hash(0), 0) stores a 0 (:119-122) */
+    const bool resumed = ctl && ctl->resume;
+    if (!resumed) for (int k = lane; k < 1024; k += 64) ((uint4 *)tab)[k] = make_uint4(0u, 0u, 0u, 0u);     /* LZ4_initStream; put(hash(0), 0) stores a 0 (:119-122) */
     for (int k = lane; k < PARSE_SEEN_DWORDS; k += 64) seen[k] = 0u;
     wave_sync();
 
@@ -201,8 +217,13 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
             pw[0] = ld128u(src + a);
         }
     };
+    if (resumed) {
+        c = uni(ctl->c); sbase = uni(ctl->sbase); sj = uni(ctl->sj); nrec = uni(ctl->nrec); test = ctl->test; more = ctl->more;
+        long_seen = uni(ctl->long_seen); long_rounds = uni(ctl->long_rounds);
+    }
     prepare();
     (void)ahead;
+    uint32_t mig_tick = 0u;
 
     /* lanes of sub-window k whose position was put into the table, from the hits `hk` of its chain: not the lanes before its entry
      * cursor (except the one two before it when the cursor came from a match, :394), not the lanes inside matches (except the lane
@@ -755,6 +776,21 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         return true;
     };
     for (;;) {
+        if (GT && ctl && ctl->free_slots && (++mig_tick & 15u) == 0u) {
+            const uint32_t fs = uni(*(volatile uint32_t *)ctl->free_slots);
+            if (fs) {
+                const uint32_t sl = (uint32_t)__ffs((int)fs) - 1u;
+                uint32_t old = 0u;
+                if (lane == 0) old = atomicAnd(ctl->free_slots, ~(1u << sl));
+                if (uni(old) & (1u << sl)) {
+                    ctl->c = c; ctl->sbase = sbase; ctl->sj = sj; ctl->nrec = nrec; ctl->test = test; ctl->more = more;
+                    ctl->long_seen = long_seen; ctl->long_rounds = long_rounds;
+                    ctl->claimed = (int)sl;
+                    wave_sync();             /* the table's last puts are in memory before anybody copies it */
+                    return nrec;
+                }
+            }
+        }
         const bool plain = sj == 0u && c + 64u * (uint32_t)K + 28u <= U;
         /* (the search's limit: probes up to sbase + 65 are contiguous, the window ends at c + 63) */
         if (K == 1 && plain && c + 63u <= sbase + 65u) {
@@ -795,6 +831,10 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
     const uint32_t lds_tables = waves < (uint32_t)PARSE_LDS_TABLES ? waves : (uint32_t)PARSE_LDS_TABLES;
     uint32_t *seen = lds + 4096u * (uint32_t)PARSE_LDS_TABLES + (uint32_t)PARSE_SEEN_DWORDS * wave;
     const bool in_lds = wave < lds_tables;
+    if (p.migrate) {
+        if (threadIdx.x == 0) lds[PARSE_LDS_DWORDS - 1] = 0u;
+        __syncthreads();
+    }
     for (long long idx = (long long)wave * (long long)p.nwg + (long long)blockIdx.x;;) {
         if (p.queue) {
             uint32_t t = 0u;
@@ -821,8 +861,26 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
 #ifdef K4_PARSE_PROF
             if (a.prof) { pc = a.prof + PROF_STRIDE * b; prof_place<true>(pc, 8, lane); }
 #endif
-            if (in_lds) n = parse_block<K, false>(src, (uint32_t)src_len, recs, (uint16_t *)(lds + 4096u * wave), seen, lane, pc);
-            else n = parse_block<K, true>(src, (uint32_t)src_len, recs, (uint16_t *)(p.gtab + 4096ull * ((unsigned long long)blockIdx.x * PARSE_MAX_WAVES + wave)), seen, lane, pc);
+            uint32_t *free_slots = p.migrate ? lds + PARSE_LDS_DWORDS - 1 : nullptr;
+            if (in_lds) {
+                n = parse_block<K, false>(src, (uint32_t)src_len, recs, (uint16_t *)(lds + 4096u * wave), seen, lane, pc);
+                if (free_slots && !p.queue && lane == 0) atomicOr(free_slots, 1u << wave);        /* this wave's table is free now */
+            } else {
+                uint32_t *gt = p.gtab + 4096ull * ((unsigned long long)blockIdx.x * PARSE_MAX_WAVES + wave);
+                ParseCtl ctl;
+                ctl.free_slots = p.queue ? nullptr : free_slots; ctl.claimed = -1; ctl.resume = false;
+                n = parse_block<K, true>(src, (uint32_t)src_len, recs, (uint16_t *)gt, seen, lane, pc, nullptr, &ctl);
+                if (ctl.claimed >= 0) {
+                    uint32_t *slot = lds + 4096u * (uint32_t)ctl.claimed;
+#pragma unroll 4
+                    for (int k = lane; k < 1024; k += 64) ((uint4 *)slot)[k] = ((const uint4 *)gt)[k];
+                    wave_sync();
+                    ctl.resume = true; ctl.free_slots = nullptr;
+                    const int sl = ctl.claimed;
+                    n = parse_block<K, false>(src, (uint32_t)src_len, recs, (uint16_t *)slot, seen, lane, pc, nullptr, &ctl);
+                    if (lane == 0) atomicOr(free_slots, 1u << sl);                                /* ... and free again for the next one */
+                }
+            }
 #ifdef K4_PARSE_PROF
             if (a.prof) { if (lane == 0) { pc[9] = __builtin_amdgcn_s_memrealtime(); pc[15] = in_lds ? 1u : 2u; } }
 #endif
@@ -838,7 +896,6 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
     }
 }
 
-constexpr int PARSE_LDS_DWORDS = 4096 * PARSE_LDS_TABLES + PARSE_SEEN_DWORDS * PARSE_MAX_WAVES;
 
 __global__ __launch_bounds__(64 * PARSE_MAX_WAVES) void k4_parse_kernel(BatchArgs a, ParseArgs p)
 {

@@ -120,7 +120,7 @@ int k4emu_encode_parse_batch(const uint8_t *src, const uint64_t *srcOff, const i
 {
     /* K + 16: the parsing waves write their blocks out themselves (ParseArgs::inline_emit) and k4_emit_kernel is not launched;
      * K + 32: fewer waves than blocks, every wave takes the next block of the order when it is done with one (ParseArgs::queue) */
-    const bool inline_emit = (K & 16) != 0, use_queue = (K & 32) != 0;
+    const bool inline_emit = (K & 16) != 0, use_queue = (K & 32) != 0, migrate = (K & 64) != 0;     /* K + 64: ParseArgs::migrate */
     K &= 15;
     if (n <= 0) return 0;
     k4::BatchArgs a{};
@@ -134,6 +134,7 @@ int k4emu_encode_parse_batch(const uint8_t *src, const uint64_t *srcOff, const i
     std::vector<uint32_t> meta((size_t)n * 2, 0x12345678u), gtab((size_t)p.nwg * k4::PARSE_MAX_WAVES * 4096u, 0xdeadbeefu);
     p.recs = recs.data(); p.meta = meta.data(); p.gtab = gtab.data();
     p.inline_emit = inline_emit ? 1u : 0u;
+    p.migrate = migrate ? 1u : 0u;
     std::vector<uint32_t> q(4, 0u);
     std::vector<uint32_t> ident;
     if (use_queue) {

@@ -59,7 +59,7 @@ def test_encode_fast_matches_oracle(emu, oracle, variant):
     assert (dst[mask] == 0xCD).all()
 
 
-@pytest.mark.parametrize("k,waves,how", [(1, 1, ""), (1, 16, "inline"), (1, 12, "inline+queue"), (2, 16, ""), (2, 9, "inline"), (3, 12, "queue"), (4, 5, "")])
+@pytest.mark.parametrize("k,waves,how", [(1, 1, ""), (1, 16, "inline+migrate"), (1, 12, "inline+queue"), (1, 11, "migrate"), (2, 16, ""), (2, 9, "inline"), (3, 12, "queue"), (4, 5, "")])
 def test_encode_parse_emit_matches_oracle(emu, oracle, k, waves, how):
     """the two-kernel fast encoder (k4lz4_parse.hpp: which sequences, then their bytes): k sub-windows of 64 positions per
     round, `waves` blocks per workgroup of which those beyond nine keep their table in memory; blocks it leaves alone
@@ -74,7 +74,7 @@ def test_encode_parse_emit_matches_oracle(emu, oracle, k, waves, how):
     src, soff, slen = pack(blocks)
     dst, doff, dcap = arena([oracle.compress_bound(b.size) for b in blocks])
     order = np.random.default_rng(k).permutation(len(blocks)).astype(np.uint32) if waves != 9 else None
-    out, nseq = emu.encode_parse_batch(src, soff, slen, dst, doff, dcap, k=k, waves=waves, order=order, inline_emit="inline" in how, queue="queue" in how)
+    out, nseq = emu.encode_parse_batch(src, soff, slen, dst, doff, dcap, k=k, waves=waves, order=order, inline_emit="inline" in how, queue="queue" in how, migrate="migrate" in how)
     for i, b in enumerate(blocks):
         want = oracle.encode(b)
         if b.size == 0:

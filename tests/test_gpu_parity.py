@@ -414,7 +414,7 @@ def test_dispatch_variants_give_identical_bytes(oracle):
 def test_fast_encoder_paths_give_identical_bytes(oracle):
     """Which kernels encode a fast-level batch is scheduling only: the two-kernel path of k4lz4_parse.hpp (parse + write-out by
     the parsing wave, or by k4_emit_kernel: K4LZ4_NO_INLINE_EMIT; 16 or fewer blocks per workgroup: K4LZ4_PARSE_WAVES; waves that
-    take their blocks from a queue: K4LZ4_PARSE_QUEUE) with the one-kernel encoder behind it for the blocks it leaves alone, or
+    take their blocks from a queue: K4LZ4_PARSE_QUEUE; tables that stay in memory: K4LZ4_NO_MIGRATE) with the one-kernel encoder behind it for the blocks it leaves alone, or
     the one-kernel encoders alone (K4LZ4_NO_PARSE).  Every one of them: the oracle's bytes, length and failures included."""
     import os
     from k4os.compression.lz4_amd import _native
@@ -432,7 +432,7 @@ def test_fast_encoder_paths_give_identical_bytes(oracle):
     ref_dst, ref_off = make_arena(caps + 16, fill=0xCD)
     want = oracle.encode_batch(src, soff, slen, ref_dst, ref_off, caps, threads=8)
     envs = [{}, {"K4LZ4_NO_PARSE": "1"}, {"K4LZ4_NO_INLINE_EMIT": "1"}, {"K4LZ4_PARSE_WAVES": "5"},
-            {"K4LZ4_PARSE_QUEUE": "1", "K4LZ4_PARSE_WAVES": "3"}, {"K4LZ4_PCOST": "1"}]
+            {"K4LZ4_PARSE_QUEUE": "1", "K4LZ4_PARSE_WAVES": "3"}, {"K4LZ4_PCOST": "1"}, {"K4LZ4_NO_MIGRATE": "1"}]
     for env in envs:
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
