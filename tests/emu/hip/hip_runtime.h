@@ -157,6 +157,7 @@ static inline void __builtin_amdgcn_wave_barrier() { (void)k4emu::wave_exchange(
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAnd(unsigned *p, unsigned v) { return __atomic_fetch_and(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicCAS(unsigned *p, unsigned cmp, unsigned v) { __atomic_compare_exchange_n(p, &cmp, v, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED); return cmp; }
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicMax(unsigned *p, unsigned v) {
