@@ -8,7 +8,8 @@
 //     public static Algorithm Algorithm => UseNative ? Algorithm.Native : Enforce32 || Mem.System32 ? Algorithm.X32 : Algorithm.X64;
 //   With UseNative, LZ4Codec.Enforce32 (LZ4Codec.cs:21-25) additionally forwards to LLNative.k4lz4_set_enforce32(value ? 1 : 0):
 //   the library then produces the 32-bit engine's bytes for fast-level inputs of 64 KiB and more (the only place where LL32
-//   and LL64 differ in a 64-bit process) -- that arm's parity with LL32 is unpinned, see README.md.
+//   and LL64 differ in a 64-bit process) -- pinned to LL32 itself, compiled here from the reference's x32/LL32.*.cs
+//   (oracle/_ref; tests/test_ref_pins.py, tests/test_gpu_ref_parity.py).
 //
 // Engine/LLxx.cs -- every switch gets the third arm; the members below replace :17-26, :29-39, :41-55, :65-75, :94-103.
 using System;

@@ -53,16 +53,27 @@ namespace K4os.Compression.LZ4
 			if (blocks is null) throw new ArgumentNullException(nameof(blocks));
 			var n = blocks.Length;
 			var result = new byte[n][];
-			// A device call has a floor (one block's time on its wavefront, about 3 ms for 64 KiB at the fast level): below the
-			// batch size the library recommends for this host, the managed engine is the faster one (INTEGRATION.md, "Crossover").
-			if (n > 0 && n < LLNative.k4lz4_recommended_min_batch(level < LZ4Level.L03_HC ? 0 : 2, Math.Max(1, blocks[0]?.Length ?? 1), HostGiBs))
+			// (the per-element check comes first: the device path and the managed path must fail the same way on a null element)
+			long total = 0;
+			for (var i = 0; i < n; i++)
 			{
-				for (var i = 0; i < n; i++)
+				if (blocks[i] is null) throw new ArgumentNullException($"{nameof(blocks)}[{i}]");
+				total += blocks[i].Length;
+			}
+			// A device call has a floor (one block's time on its wavefront, about 2 ms for 64 KiB at the fast level): below the batch
+			// size the library recommends for this host, the managed engine is the faster one (INTEGRATION.md, "Crossover").  The
+			// size asked about is the batch's MEAN block (ragged batches), the host rate the one of ALL host threads -- which is what
+			// the fallback below then really uses: Parallel.For over the managed engine itself (LL64 / LL32), never LLxx's Native
+			// arm, which would be one device call per block.
+			var meanBlock = (int) Math.Max(1, n > 0 ? total / n : 1);
+			if (n > 0 && n < LLNative.k4lz4_recommended_min_batch(level < LZ4Level.L03_HC ? 0 : 2, meanBlock, HostGiBs))
+			{
+				System.Threading.Tasks.Parallel.For(0, n, i =>
 				{
 					var buf = new byte[MaximumOutputSize(blocks[i].Length)];
-					var k = Encode(blocks[i], 0, blocks[i].Length, buf, 0, buf.Length, level);
-					result[i] = k < 0 ? null : buf.AsSpan(0, k).ToArray();
-				}
+					var k = ManagedEncode(blocks[i], buf, level);
+					result[i] = k <= 0 && blocks[i].Length > 0 ? null : buf.AsSpan(0, Math.Max(k, 0)).ToArray();
+				});
 				return result;
 			}
 			for (var first = 0; first < n;)
@@ -71,7 +82,6 @@ namespace K4os.Compression.LZ4
 				var last = first;
 				while (last < n)
 				{
-					if (blocks[last] is null) throw new ArgumentNullException($"{nameof(blocks)}[{last}]");
 					var bound = MaximumOutputSize(blocks[last].Length);
 					if (last > first && (st + blocks[last].Length > MaxPackedBytes || dt + bound > MaxPackedBytes)) break;
 					st += blocks[last].Length; dt += bound; last++;
@@ -80,6 +90,20 @@ namespace K4os.Compression.LZ4
 				first = last;
 			}
 			return result;
+		}
+
+		/// <summary>The reference's managed engine on one block, whatever LL.UseNative says (LZ4Codec.cs:40-52 with the
+		/// Algorithm switch of Engine/LLxx.cs:65-103 resolved to X64 / X32 by hand).</summary>
+		private static unsafe int ManagedEncode(byte[] source, byte[] target, LZ4Level level)
+		{
+			if (source.Length == 0) return 0;
+			fixed (byte* s = source, t = target)
+			{
+				var x32 = LL.Enforce32 || Mem.System32;
+				if (level < LZ4Level.L03_HC)
+					return x32 ? LL32.LZ4_compress_fast(s, t, source.Length, target.Length, 1) : LL64.LZ4_compress_fast(s, t, source.Length, target.Length, 1);
+				return x32 ? LL32.LZ4_compress_HC(s, t, source.Length, target.Length, (int) level) : LL64.LZ4_compress_HC(s, t, source.Length, target.Length, (int) level);
+			}
 		}
 
 		/// <summary>What one packed native call may carry (sources, and targets): below the 2 GiB a byte[] can index.</summary>

@@ -87,7 +87,7 @@ K4LZ4_API int k4lz4_version(void);
 K4LZ4_API int k4lz4_device_count(void);
 
 /* Below which batch size a caller should stay on the managed engine (LZ4Codec.cs:40-52 -> LLxx -> LL64 on the host).
- * One wavefront encodes a 64 KiB block in about 3 ms and decodes it in 0.6 ms however small the batch is (the chip is fast
+ * One wavefront encodes a 64 KiB block in about 2 ms and decodes it in 0.6 ms however small the batch is (the chip is fast
  * because it runs thousands of blocks side by side, not because a block is fast), so a device call has a floor; a host that
  * sustains `hostGiBs` on this work beats it below
  *     floor(kind, blockBytes) * hostGiBs / blockBytes   blocks.

@@ -888,7 +888,8 @@ int staged_download(k4lz4_ctx *ctx, uint8_t *dst, const uint64_t *dstOff, const 
 /* Host memory the caller has page-locked through k4lz4_host_register: the DMA engine reads and writes it directly, so a
  * host-pointer call whose source or destination lies inside such a range skips the pinned staging buffers on that side. */
 std::mutex g_reg_mu;
-std::vector<std::pair<uintptr_t, size_t>> g_reg;   /* [start, bytes), guarded by g_reg_mu */
+struct RegRange { uintptr_t first; size_t second; bool pinned; };      /* pinned: hipHostRegister has succeeded -- until then the range only blocks overlapping registrations */
+std::vector<RegRange> g_reg;   /* [start, bytes), guarded by g_reg_mu */
 
 bool registered(const void *p, size_t bytes)
 {
@@ -896,7 +897,7 @@ bool registered(const void *p, size_t bytes)
     const uintptr_t a = (uintptr_t)p;
     std::lock_guard<std::mutex> g(g_reg_mu);
     for (const auto &r : g_reg)
-        if (a >= r.first && a - r.first <= r.second && bytes <= r.second - (a - r.first)) return true;
+        if (r.pinned && a >= r.first && a - r.first <= r.second && bytes <= r.second - (a - r.first)) return true;
     return false;
 }
 
@@ -1426,13 +1427,13 @@ void k4lz4_ctx_destroy(k4lz4_ctx *ctx)
 
 const char *k4lz4_last_error(const k4lz4_ctx *ctx) { return ctx ? ctx->error.c_str() : tl_error.c_str(); }
 
-/* measured floors of a device call (profiles/r21_block_count_scaling.txt, r18_stamp.txt: a 64 KiB text block alone 2.9 ms to encode,
- * 0.55 ms to decode, 8.7 ms at HC level 3): the time of ONE block on its wavefront, scaled with the block length (a wavefront's
+/* measured floors of a device call (profiles/r5_block_count_scaling.txt: a 64 KiB text block alone 2.0 ms to encode -- 2.9 ms with the
+ * one-kernel encoder of rounds 1-4 --, 0.55 ms to decode; r18_stamp.txt: 8.7 ms at HC level 3): the time of ONE block on its wavefront, scaled with the block length (a wavefront's
  * time per block is linear in its length), never below the launch + synchronisation cost of a call */
 int64_t k4lz4_recommended_min_batch(int kind, int32_t blockBytes, double hostGiBs)
 {
     if (kind < 0 || kind > 2 || blockBytes <= 0) return K4LZ4_E_ARG;
-    static const double floor_ms_64k[3] = {2.9, 0.55, 8.7};
+    static const double floor_ms_64k[3] = {2.0, 0.55, 8.7};
     static const double box_host_GiBs[3] = {32.0, 35.0, 2.2};
     const double host = hostGiBs > 0.0 ? hostGiBs : box_host_GiBs[kind];
     double floor_ms = floor_ms_64k[kind] * (double)blockBytes / 65536.0;
@@ -1461,18 +1462,23 @@ int k4lz4_host_register(void *ptr, size_t bytes)
         std::lock_guard<std::mutex> g(g_reg_mu);
         for (const auto &r : g_reg)
             if (a < r.first + r.second && r.first < a + bytes) { tl_error = "k4lz4_host_register: overlaps a registered range"; return K4LZ4_E_ARG; }
-        g_reg.emplace_back(a, bytes);
+        g_reg.push_back(RegRange{a, bytes, false});
     } catch (const std::bad_alloc &) { tl_error = "k4lz4_host_register: out of host memory"; return K4LZ4_E_NOMEM; }
     const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         {
             std::lock_guard<std::mutex> g(g_reg_mu);
-            auto it = std::find_if(g_reg.begin(), g_reg.end(), [&](const std::pair<uintptr_t, size_t> &r) { return r.first == a && r.second == bytes; });
+            auto it = std::find_if(g_reg.begin(), g_reg.end(), [&](const RegRange &r) { return r.first == a && r.second == bytes && !r.pinned; });
             if (it != g_reg.end()) g_reg.erase(it);
         }
         tl_error = std::string("hipHostRegister: ") + hipGetErrorString(e);
         return e == hipErrorOutOfMemory ? K4LZ4_E_NOMEM : K4LZ4_E_HIP;
+    }
+    {   /* only now do host-pointer calls treat the range as page-locked, and only now can it be unregistered */
+        std::lock_guard<std::mutex> g(g_reg_mu);
+        auto it = std::find_if(g_reg.begin(), g_reg.end(), [&](const RegRange &r) { return r.first == a && r.second == bytes && !r.pinned; });
+        if (it != g_reg.end()) it->pinned = true;
     }
     return K4LZ4_OK;
 }
@@ -1481,7 +1487,7 @@ int k4lz4_host_unregister(void *ptr)
 {
     {
         std::lock_guard<std::mutex> g(g_reg_mu);
-        auto it = std::find_if(g_reg.begin(), g_reg.end(), [&](const std::pair<uintptr_t, size_t> &r) { return r.first == (uintptr_t)ptr; });
+        auto it = std::find_if(g_reg.begin(), g_reg.end(), [&](const RegRange &r) { return r.first == (uintptr_t)ptr && r.pinned; });      /* (a range still being pinned is not there yet) */
         if (it == g_reg.end()) { tl_error = "k4lz4_host_unregister: not a registered range"; return K4LZ4_E_ARG; }
         g_reg.erase(it);
     }

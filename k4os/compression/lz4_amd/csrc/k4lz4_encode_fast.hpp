@@ -330,7 +330,8 @@ struct SegRun {
     uint32_t cut, stop, state;  /* results: first position of the output (the cut; 0), one past its last (verified cut, or U),
                                  * 1 stopped at a verified cut, 2 ran to the end of the block, 3 no use (no cut, no room, gave up waiting),
                                  * 4 stopped at a cut the next run is NOT in step with: the output stands if this run began in step, and its
-                                 * table now lies in the next run's snapshot for a run that goes on from `stop` */
+                                 * table now lies in the item's own table slot (`fix`) for a run that goes on from `stop`; the next run's
+                                 * snapshot is left as that run published it */
 };
 
 /*

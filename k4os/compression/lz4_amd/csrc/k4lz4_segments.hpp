@@ -198,7 +198,8 @@ __global__ __launch_bounds__(64) void k4_seg_join_kernel(BatchArgs a, SegArgs g)
     uint8_t *dst = a.dst + a.dstOff[b];
     const uint32_t nseg = uni(g.items[base].nseg);
     /* Piece by piece.  A piece stands if it begins where the encoding so far ends (`at`) and stopped at a cut (state 1: the next
-     * piece is in step there; state 4: it is not, and this piece left the table of the cut in the next piece's snapshot) or at the
+     * piece is in step there; state 4: it is not, and this piece left the table of the cut in ITS OWN slot of SegArgs::tables -- `fix`; the
+     * next piece's snapshot stays as that piece published it) or at the
      * end of the block (state 2).  Where a piece does not stand, or the boundary behind it did not verify, ONE wave goes on from
      * the last cut with the table that lies there -- and stops at the next boundary whose piece IS in step (the same check the
      * pieces' own runs make), so that the pieces behind a bad boundary are not encoded again when they are good. */

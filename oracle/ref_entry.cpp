@@ -46,13 +46,16 @@ void* worker(void* p) {
 int run(int op, const uint8_t* src, const uint64_t* so, const int32_t* sl, uint8_t* dst, const uint64_t* dof, const int32_t* dc, int32_t* out, int64_t n, int level, int threads) {
 	if (threads < 1) threads = 1;
 	if (threads > 256) threads = 256;
-	pthread_t tid[256]; Job jobs[256];
+	pthread_t tid[256]; Job jobs[256]; bool started[256];
+	for (int t = 0; t < 256; t++) started[t] = true;
 	for (int t = 0; t < threads; t++) {
 		jobs[t] = Job{op, src, so, sl, dst, dof, dc, out, n * t / threads, n * (t + 1) / threads, level};
 		if (threads == 1) worker(&jobs[t]);
-		else if (pthread_create(&tid[t], nullptr, worker, &jobs[t]) != 0) return -1;
+		/* (a thread that cannot be started: its range is done here, and the threads already running are still joined below --
+		 * jobs[] and tid[] live on this stack) */
+		else if (pthread_create(&tid[t], nullptr, worker, &jobs[t]) != 0) { worker(&jobs[t]); started[t] = false; }
 	}
-	if (threads > 1) for (int t = 0; t < threads; t++) pthread_join(tid[t], nullptr);
+	if (threads > 1) for (int t = 0; t < threads; t++) if (started[t]) pthread_join(tid[t], nullptr);
 	return 0;
 }
 }

@@ -141,9 +141,9 @@ def test_one_hip_runtime_whatever_the_import_order():
 def test_recommended_min_batch_is_the_documented_crossover():
     """INTEGRATION.md "Crossover": floor of a device call x what the host sustains / block size; no device needed"""
     from k4os.compression.lz4_amd import LZ4Codec
-    assert LZ4Codec.RecommendedMinBatch(0, 65536, 32.0) == 1521          # 2.9 ms x 32 GiB/s / 64 KiB
+    assert LZ4Codec.RecommendedMinBatch(0, 65536, 32.0) == 1049          # 2.0 ms x 32 GiB/s / 64 KiB
     assert LZ4Codec.RecommendedMinBatch(1, 65536, 35.0) == 316           # 0.55 ms x 35 GiB/s / 64 KiB
-    assert LZ4Codec.RecommendedMinBatch(0, 65536, 0.8) == 39             # one host thread
+    assert LZ4Codec.RecommendedMinBatch(0, 65536, 0.8) == 27             # one host thread
     assert LZ4Codec.RecommendedMinBatch(0, 65536) == LZ4Codec.RecommendedMinBatch(0, 65536, 32.0)
     assert LZ4Codec.RecommendedMinBatch(0, 4096, 32.0) == LZ4Codec.RecommendedMinBatch(0, 65536, 32.0)   # the floor scales with the block
     assert LZ4Codec.RecommendedMinBatch(2, 65536, 2.2) > 100
