@@ -400,7 +400,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
 #else
     const bool parse_prof_ok = false;
 #endif
-    const bool parse_path = kind == KIND_ENCODE && level < K4LZ4_L03_HC && ctx->use_parse && ctx->accel == 1 && (!ctx->prof || parse_prof_ok) &&
+    const bool parse_path = kind == KIND_ENCODE && level < K4LZ4_L03_HC && ctx->use_parse && ctx->accel == 1 && (!ctx->prof || parse_prof_ok || ctx->prof_stamp) &&
                             !(flags & (FLAG_SEGMENTS_OK | K4LZ4_FLAG_SEGMENTS | K4LZ4_FLAG_NO_SPLIT));
     if (parse_path) chunk_max = std::min<int64_t>(chunk_max, (int64_t)k4::PARSE_MAX_WAVES * (int64_t)ctx->cu_count);      /* (its scratch is 128 KiB per block) */
     if (encode_like && level >= K4LZ4_L03_HC) {

@@ -862,6 +862,10 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
             if (a.prof) { pc = a.prof + PROF_STRIDE * b; prof_place<true>(pc, 8, lane); }
 #endif
             uint32_t *free_slots = p.migrate ? lds + PARSE_LDS_DWORDS - 1 : nullptr;
+            bool moved = false;
+#ifndef K4_PARSE_PROF
+            if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 8, lane);
+#endif
             if (in_lds) {
                 n = parse_block<K, false>(src, (uint32_t)src_len, recs, (uint16_t *)(lds + 4096u * wave), seen, lane, pc);
                 if (free_slots && !p.queue && lane == 0) atomicOr(free_slots, 1u << wave);        /* this wave's table is free now */
@@ -871,6 +875,7 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
                 ctl.free_slots = p.queue ? nullptr : free_slots; ctl.claimed = -1; ctl.resume = false;
                 n = parse_block<K, true>(src, (uint32_t)src_len, recs, (uint16_t *)gt, seen, lane, pc, nullptr, &ctl);
                 if (ctl.claimed >= 0) {
+                    moved = true;
                     uint32_t *slot = lds + 4096u * (uint32_t)ctl.claimed;
 #pragma unroll 4
                     for (int k = lane; k < 1024; k += 64) ((uint4 *)slot)[k] = ((const uint4 *)gt)[k];
@@ -885,12 +890,20 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
             if (a.prof) { if (lane == 0) { pc[9] = __builtin_amdgcn_s_memrealtime(); pc[15] = in_lds ? 1u : 2u; } }
 #endif
             if (lane == 0) { meta[0] = n; meta[1] = 0u; }
+#ifndef K4_PARSE_PROF
+            /* k4lz4_profile_batch_device mode 4 (stamps only): [12] when the parse was through, [9] when the block was written, [11]
+             * where its table lived (4 LDS, 5 memory, 6 memory first and an LDS table from some round on) */
+            if (a.prof) { prof_place<true>(a.prof + PROF_STRIDE * b, 12, lane); if (lane == 0) a.prof[PROF_STRIDE * b + 11] = in_lds ? 4u : (moved ? 6u : 5u); }
+#endif
             if (p.inline_emit) {
                 wave_sync();                 /* the records are this wave's own stores: in order with the loads that follow */
                 const int cap = a.dstCap[b];
                 const int ret = emit_block(src, (uint32_t)src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, recs, n, lane);
                 if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
             }
+#ifndef K4_PARSE_PROF
+            if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 9, lane);
+#endif
         }
         if (!p.queue) return;
     }

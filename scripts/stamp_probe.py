@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """When every block of the bench batch starts and ends inside the ORDINARY kernels (k4lz4_profile_batch_device, modes 4 / 5:
-only start / end / placement are recorded), by data class and, for encode, by kernel (1 LDS table, 2 global table)."""
+only start / end / placement are recorded), by data class and, for encode, by kernel (1 LDS table, 2 global table of the one-kernel
+encoders; the parse kernel: 4 table in LDS, 5 in memory, 6 in memory first and in an LDS table another block was done with later;
+for those also when the parse was through, i.e. how long writing the block out took)."""
 import os, sys
 import numpy as np
 import torch
@@ -36,5 +38,9 @@ for mode in (4, 5):
             idx = np.array([i for i in range(ci, n, 12) if sel[i]])
             if idx.size == 0: continue
             d = (en[idx] - st[idx]) / 1e5
+            extra = ""
+            if mode == 4 and kk >= 4:
+                w = (en[idx] - c[idx, 12]) / 1e5
+                extra = " | writing out mean %.3f max %.3f" % (w.mean(), w.max())
             print("   %-8s n %4d  start mean %.3f max %.3f | duration mean %.3f p10 %.3f p90 %.3f max %.3f | end max %.3f" % (
-                name, idx.size, (st[idx].mean() - t0) / 1e5, (st[idx].max() - t0) / 1e5, d.mean(), np.percentile(d, 10), np.percentile(d, 90), d.max(), (en[idx].max() - t0) / 1e5))
+                name, idx.size, (st[idx].mean() - t0) / 1e5, (st[idx].max() - t0) / 1e5, d.mean(), np.percentile(d, 10), np.percentile(d, 90), d.max(), (en[idx].max() - t0) / 1e5) + extra)
