@@ -479,6 +479,22 @@ static int effective_size_of(int value) { return (value > 0xffff || value < 0) ?
 K4O_API int k4o_pickle_bound(int src_len) { return src_len <= 0 ? 0 : 1 + 4 + src_len; }
 
 /*
+ * The V0 header alone, for a block of src_len bytes whose LZ4 block came out as enc_len bytes (pickle.cs:85-105 array path,
+ * :128-148 writer path; header byte :221-222, width :224-228, little-endian diff :214-219).  Writes 1..5 bytes, returns how many.
+ * Pinned to the reference's own helpers over the (src_len, enc_len) plane by tests/test_ref_pins.py.
+ */
+K4O_API int k4o_pickle_header(int src_len, int enc_len, int writer_mode, uint8_t *dst)
+{
+    if (enc_len <= 0 || enc_len >= src_len) { dst[0] = 0; return 1; }   /* :85, :135, :189-194 */
+    int diff = src_len - enc_len;
+    int size_of_diff = writer_mode ? effective_size_of(src_len) : effective_size_of(diff);   /* :128,:161-165 / :97,:174-179 */
+    int code = size_of_diff == 4 ? 3 : size_of_diff;                     /* :228 */
+    dst[0] = (uint8_t)((0 & 7) | ((code & 3) << 6));                     /* :221-222 */
+    for (int i = 0; i < size_of_diff; i++) dst[1 + i] = (uint8_t)((uint32_t)diff >> (8 * i));
+    return 1 + size_of_diff;
+}
+
+/*
  * pickle.cs:51-106 (array/span path, writer_mode == 0) and :113-158 (IBufferWriter path,
  * writer_mode == 1: header width chosen from the source length, :129,:161-165).
  * `scratch` must hold max(src_len, 1024) bytes.  Returns envelope bytes written to dst
@@ -495,11 +511,7 @@ K4O_API int k4o_pickle(const uint8_t *src, int src_len, uint8_t *dst, uint8_t *s
         memcpy(dst + 1, src, (size_t)src_len);
         return 1 + src_len;
     }
-    int diff = src_len - enc;
-    int size_of_diff = writer_mode ? effective_size_of(src_len) : effective_size_of(diff);
-    int code = size_of_diff == 4 ? 3 : size_of_diff;                     /* :228 */
-    dst[0] = (uint8_t)((0 & 7) | ((code & 3) << 6));                     /* :221-222 */
-    for (int i = 0; i < size_of_diff; i++) dst[1 + i] = (uint8_t)((uint32_t)diff >> (8 * i));
+    int size_of_diff = k4o_pickle_header(src_len, enc, writer_mode, dst) - 1;
     memcpy(dst + 1 + size_of_diff, scratch, (size_t)enc);
     return 1 + size_of_diff + enc;
 }

@@ -40,6 +40,14 @@ Rules (R1..R20), all token-level:
   R19 an identifier that is a C++ keyword gets a trailing underscore
   R20 an instance method of a class with only static state -> `static` is NOT added; left as is
   R21 the nested `enum`s of a class are emitted before its other members (declaration order only)
+  R22 a switch EXPRESSION `s switch { p1 => e1, p2 => e2, ... }` (s an identifier or a parenthesised expression) ->
+      `([&](auto _v) { if (c1) return e1; if (c2) return e2; ... })(s)`; patterns: a constant (`_v == k`), a relational
+      pattern (`> k`: `_v > k`), `or` / `and` of those, the discard `_`, `var x` (`auto x = _v;`); an arm `=> throw e`
+      stays a `throw`
+  R23 an interpolated string `$"...{x}..."` -> the plain literal `"...{x}..."` (exception messages: text only, no behaviour)
+  R24 of a class listed in ONLY just the named members are taken (the others are managed-array code: Span, ArrayPool,
+      IBufferWriter); a top-level attribute is dropped and a top-level struct named in TOPLEVEL_SUPPLIED is left to
+      oracle/ref_prelude.hpp
 
 What is NOT C# any more after this: integer promotion.  C# computes `uint (+|-|*) int` in
 `long`; C++ computes it in `unsigned`.  The original C (lz4 1.9.2) these files were ported
@@ -67,7 +75,18 @@ INPUTS = [
     ("LL", ["Engine/LL.types.cs", "Engine/LL.types.high.cs", "Engine/LL.tools.cs", "Engine/LL.high.cs"]),
     ("LL64", ["Engine/x64/LL64.tools.cs", "Engine/x64/LL64.fast.cs", "Engine/x64/LL64.dec.cs", "Engine/x64/LL64.high.cs"]),
     ("LL32", ["Engine/x32/LL32.tools.cs", "Engine/x32/LL32.fast.cs", "Engine/x32/LL32.dec.cs", "Engine/x32/LL32.high.cs"]),
+    # the envelope's header arithmetic (R24: the named members only)
+    ("LZ4Pickler", ["LZ4Pickler.pickle.cs", "LZ4Pickler.unpickle.cs"]),
 ]
+
+# R24: classes of which only these members are taken -- LZ4Pickler's header helpers (LZ4Pickler.pickle.cs:161-229,
+# LZ4Pickler.unpickle.cs:131-148); everything else in those files is Span / ArrayPool / IBufferWriter code
+ONLY = {
+    "LZ4Pickler": {"MAX_STACKALLOC", "VersionMask", "GetPessimisticHeaderSize", "GetUncompressedHeaderSize", "GetCompressedHeaderSize",
+                   "EncodeUncompressedHeader", "EncodeUncompressedHeaderV0", "EncodeCompressedHeader", "EncodeCompressedHeaderV0",
+                   "EncodeHeaderByteV0", "EffectiveSizeOf", "EncodeSizeOf", "DecodeHeader", "DecodeHeaderV0"},
+}
+TOPLEVEL_SUPPLIED = {"PickleHeader"}       # LZ4Pickler.unpickle.cs:163-181: auto-properties; three fields and the constructor in the prelude
 
 # members the rules cannot express: bodies are .NET runtime calls (Unsafe.*, Marshal.*, Buffer.*,
 # properties, generics with managed arrays).  oracle/ref_prelude.hpp supplies each one.
@@ -83,6 +102,10 @@ EXCLUDED = {
     ("LL", "Assert"): "[Conditional(\"DEBUG\")] + CallerArgumentExpression + string",
     ("LL", "Enforce32"): "auto-property (process-wide switch; the entry points take the engine explicitly)",
     ("LL", "Algorithm"): "property returning the managed enum Engine/Algorithm.cs",
+    ("LZ4Pickler", "PokeN"): "Unsafe.CopyBlockUnaligned on `ref target[0]`",
+    ("LZ4Pickler", "PeekN"): "`fixed` + Unsafe.CopyBlockUnaligned",
+    ("LZ4Pickler", "UnexpectedVersion"): "new ArgumentException (managed exception object)",
+    ("LZ4Pickler", "CorruptedPickle"): "new InvalidDataException (managed exception object)",
 }
 
 OUT_TYPES = {"PinnedMemory.Alloc": "PinnedMemory"}          # R17
@@ -93,7 +116,7 @@ CPP_KEYWORDS = {
     "register", "delete", "template", "typename", "union", "and", "or", "not", "xor", "signed", "unsigned", "inline",
     "friend", "mutable", "export", "asm", "bitand", "bitor", "compl", "and_eq", "or_eq", "xor_eq", "not_eq",
     "typedef", "extern", "wchar_t", "near", "far", "errno", "min", "max"}
-EXTERNAL_TYPES = {"PinnedMemory", "BitOperations"}           # prelude structs reached with `.`
+EXTERNAL_TYPES = {"PinnedMemory", "BitOperations", "Debug"}  # prelude structs reached with `.`
 
 TOKEN_RE = re.compile(r"""
   (?P<ws>\s+)
@@ -226,6 +249,8 @@ class Translator:
         self.type_names = set(EXTERNAL_TYPES)
         self.struct_names = set()
         self.excluded_seen = []
+        self.supplied_seen = []
+        self.not_taken = []
         self.parsed = []        # (cls, path, tokens of the class body, aliases)
 
     # ---------------------------------------------------------------- file level
@@ -283,6 +308,19 @@ class Translator:
                 i = k + 1
             elif t.text == "}":
                 i += 1
+            elif t.text == "[":                        # R24: a top-level attribute
+                i = match_close(toks, i, "[", "]") + 1
+                self.counts.hit("R5")
+            elif t.text == "struct" and toks[next_sig(toks, i + 1)].text in TOPLEVEL_SUPPLIED:
+                nm = toks[next_sig(toks, i + 1)].text
+                j = i
+                while toks[j].text != "{":
+                    j += 1
+                i = match_close(toks, j, "{", "}") + 1
+                self.type_names.add(nm)
+                self.struct_names.add(nm)
+                self.supplied_seen.append((nm, rel, t.line))
+                self.counts.hit("R24")
             else:
                 raise SystemExit(f"{rel}:{t.line}: unexpected top-level token {t.text!r}")
         assert body is not None, rel
@@ -382,6 +420,10 @@ class Translator:
             k += 1
         name_idx = prev_sig(rest, (generic_at if generic_at is not None else k) - 1)
         name = rest[name_idx].text
+        if cls in ONLY and enclosing_struct is None and name not in ONLY[cls] and (cls, name) not in EXCLUDED:
+            self.not_taken.append((cls, name, rel, line))
+            self.counts.hit("R24")
+            return f"{where}// not taken: {name} (R24)\n"
         if (cls, name) in EXCLUDED and enclosing_struct is None:
             self.excluded_seen.append((cls, name, rel, line))
             return f"{where}// excluded: {name} -- {EXCLUDED[(cls, name)]}; supplied by oracle/ref_prelude.hpp\n"
@@ -478,7 +520,78 @@ class Translator:
         return ", ".join(res)
 
     # ---------------------------------------------------------------- statement / expression level
+    def switch_exprs(self, toks):
+        """R22: every `s switch { arms }` of the token list replaced by one raw token holding its C++ text"""
+        while True:
+            at = next((i for i, t in enumerate(toks) if t.kind == "id" and t.text == "switch" and
+                       next_sig(toks, i + 1) < len(toks) and toks[next_sig(toks, i + 1)].text == "{"), None)
+            if at is None:
+                return toks
+            pv = prev_sig(toks, at - 1)
+            if toks[pv].text == ")":
+                depth, start = 0, pv
+                while True:
+                    if toks[start].text == ")":
+                        depth += 1
+                    elif toks[start].text == "(":
+                        depth -= 1
+                        if depth == 0:
+                            break
+                    start -= 1
+            else:
+                assert toks[pv].kind == "id", f"switch expression over {toks[pv]} at line {toks[at].line}"
+                start = pv
+            scrut = self.body(toks[start:pv + 1]).strip()
+            b = next_sig(toks, at + 1)
+            e = match_close(toks, b, "{", "}")
+            arms, cur, depth = [], [], 0
+            for t in toks[b + 1:e]:
+                if t.kind == "op" and t.text in "([{":
+                    depth += 1
+                elif t.kind == "op" and t.text in ")]}":
+                    depth -= 1
+                if t.kind == "op" and t.text == "," and depth == 0:
+                    arms.append(cur); cur = []
+                else:
+                    cur.append(t)
+            if any(t.sig for t in cur):
+                arms.append(cur)
+            pieces = []
+            for arm in arms:
+                k = next(i for i, t in enumerate(arm) if t.kind == "op" and t.text == "=>")
+                pat = [t for t in arm[:k] if t.sig]
+                expr = self.body(arm[k + 1:]).strip()
+                bind, conds, i2 = "", [], 0
+                if len(pat) == 1 and pat[0].text == "_":
+                    cond = None
+                elif len(pat) == 2 and pat[0].text == "var":
+                    cond, bind = None, f"auto {self.ident(pat[1].text)} = _v; "
+                else:
+                    txt, i2 = [], 0
+                    while i2 < len(pat):
+                        t = pat[i2]
+                        if t.kind == "id" and t.text in ("or", "and"):
+                            txt.append(" || " if t.text == "or" else " && ")
+                            i2 += 1
+                            continue
+                        rel = "=="
+                        if t.kind == "op" and t.text in ("<", ">", "<=", ">="):
+                            rel = t.text
+                            i2 += 1
+                        j2 = i2
+                        while j2 < len(pat) and not (pat[j2].kind == "id" and pat[j2].text in ("or", "and")):
+                            j2 += 1
+                        txt.append(f"(_v {rel} {self.body(pat[i2:j2]).strip()})")
+                        i2 = j2
+                    cond = "".join(txt)
+                stmt = expr + ";" if expr.startswith("throw ") else f"return {expr};"
+                pieces.append(f"{{ {bind}{stmt} }}" if cond is None else f"if ({cond}) {{ {stmt} }}")
+            self.counts.hit("R22")
+            raw = Tok("raw", f"([&](auto _v) {{ {' '.join(pieces)} }})({scrut})", toks[at].line)
+            toks = toks[:start] + [raw] + toks[e + 1:]
+
     def body(self, toks):
+        toks = self.switch_exprs(list(toks))
         out = []            # text pieces
         stmt_start = 0      # index in `out` where the current statement began (R17)
         i, n = 0, len(toks)
@@ -583,6 +696,9 @@ class Translator:
                     stmt_start = len(out)
                 i += 1
                 continue
+            if t.kind == "str" and x.startswith("$"):
+                x = x.lstrip("$@")                      # R23
+                self.counts.hit("R23")
             out.append(x)
             i += 1
         return "".join(out)
@@ -640,6 +756,8 @@ def main():
         f.write("\n".join(hdr) + text + "} // namespace k4ref\n")
     report = dict(inputs_sha256=digest.hexdigest(), defines=sorted(args.defines), rules=dict(sorted(tr.counts.items())),
                   excluded=[dict(cls=c, member=n, file=rel, line=line, why=EXCLUDED[(c, n)]) for c, n, rel, line in tr.excluded_seen],
+                  not_taken=[dict(cls=c, member=n, file=rel, line=line) for c, n, rel, line in tr.not_taken],
+                  supplied_structs=[dict(name=n, file=rel, line=line) for n, rel, line in tr.supplied_seen],
                   files=[f for _, fs in INPUTS for f in fs], generated_lines=text.count("\n"))
     with open(os.path.join(args.out, "make_ref_report.json"), "w") as f:
         json.dump(report, f, indent=1)

@@ -24,6 +24,40 @@ K4REF_API int k4ref_decompress_safe_partial(const uint8_t* s, uint8_t* d, int n,
 // LLxx.cs:41-51
 K4REF_API int k4ref_decompress_safe_using_dict(const uint8_t* s, uint8_t* d, int n, int cap, const uint8_t* dict, int dictLen) {
 	return LL64::LZ4_decompress_safe_usingDict((byte*) s, d, n, cap, (byte*) dict, dictLen); }
+
+// ---- the envelope's header arithmetic: LZ4Pickler's own private helpers (the reference's statements, respelled), called the way
+// its two Pickle bodies call them.  No LZ4 block is encoded here: `encodedLength` is an argument, so the whole (sourceLength,
+// encodedLength) plane can be swept.  A managed exception comes back as -(kind) (ref_prelude.hpp K4RefManaged).
+K4REF_API int k4ref_pickle_effective_size_of(int value) { return LZ4Pickler::EffectiveSizeOf(value); }        // LZ4Pickler.pickle.cs:224-225
+K4REF_API int k4ref_pickle_encode_size_of(int size) { return LZ4Pickler::EncodeSizeOf(size); }               // :227-228
+K4REF_API int k4ref_pickle_header_byte_v0(int sizeOfDiff) { return LZ4Pickler::EncodeHeaderByteV0(sizeOfDiff); }   // :221-222
+// writer == 0: PickleWithBuffer (LZ4Pickler.pickle.cs:85-105); writer == 1: Pickle<TBufferWriter> (:128,:135-148).  `out` holds
+// `cap` bytes (the reference's span is headerSize + the payload).  Returns the header's length.
+K4REF_API int k4ref_pickle_header(int writer, int version, int sourceLength, int encodedLength, uint8_t* out, int cap) {
+	try {
+		Span<byte> target(out, cap);
+		if (encodedLength <= 0 || encodedLength >= sourceLength) {                                                // :85, :135
+			int headerSize = LZ4Pickler::GetUncompressedHeaderSize(version, sourceLength);                      // :87
+			int offset = LZ4Pickler::EncodeUncompressedHeader(target, version, sourceLength);                   // :90, :137
+			Debug::Assert(writer || headerSize == offset);                                                          // :91
+			return offset;
+		}
+		int headerSize = writer ? LZ4Pickler::GetPessimisticHeaderSize(version, sourceLength)                   // :128
+		                        : LZ4Pickler::GetCompressedHeaderSize(version, sourceLength, encodedLength);    // :97
+		int offset = LZ4Pickler::EncodeCompressedHeader(target, version, headerSize, sourceLength, encodedLength);  // :100-101, :143-144
+		Debug::Assert(headerSize == offset);                                                                    // :102, :145
+		return offset;
+	} catch (const K4RefManaged& e) { return -e.kind; }
+}
+// LZ4Pickler.unpickle.cs:131-148 (DecodeHeader): out = { DataOffset, ResultLength, IsCompressed, Flags }
+K4REF_API int k4ref_unpickle_header(const uint8_t* src, int len, int32_t* out) {
+	try {
+		PickleHeader h = LZ4Pickler::DecodeHeader(ReadOnlySpan<byte>(src, len));
+		out[0] = h.DataOffset; out[1] = h.ResultLength; out[2] = h.IsCompressed() ? 1 : 0; out[3] = h.Flags;
+		return 0;
+	} catch (const K4RefManaged& e) { return -e.kind; }
+}
+
 K4REF_API const char* k4ref_inputs_sha256() { return K4REF_INPUTS_SHA256; }
 
 // ---- threaded batch drivers: bench.py's cpu_baseline (kind "reference") times the reference's own engine on the host cores.

@@ -55,4 +55,46 @@ struct PinnedMemory {
 struct BitOperations {
 	static int TrailingZeroCount(ulong v) { return v ? __builtin_ctzll(v) : 64; }
 };
+
+// ---- the LZ4Pickler header helpers (make_ref.py ONLY["LZ4Pickler"]): the .NET types their bodies touch
+// System.Span<T> / ReadOnlySpan<T>: a pointer and a length; indexer, Length, Slice(start) -- all the helpers use.  Out of range
+// is an IndexOutOfRangeException / ArgumentOutOfRangeException there, K4RefManaged{3} here.
+struct K4RefManaged { int kind; const char* message; };      // kind 1 ArgumentException, 2 InvalidDataException, 3 index/range
+template <class T> struct Span {
+	T* _p; int Length;
+	Span(T* p, int n) : _p(p), Length(n) {}
+	template <class U> Span(const Span<U>& o) : _p((T*) o._p), Length(o.Length) {}
+	T& operator[](int i) const { if ((uint) i >= (uint) Length) throw K4RefManaged{3, "index"}; return _p[i]; }
+	Span Slice(int start) const { if ((uint) start > (uint) Length) throw K4RefManaged{3, "start"}; return Span(_p + start, Length - start); }
+};
+template <class T> using ReadOnlySpan = Span<const T>;
+// System.Diagnostics.Debug.Assert is [Conditional("DEBUG")]; K4REF_CHECKED keeps it so that the pins can see it hold
+struct Debug {
+	static void Assert(bool v, const char* = nullptr) {
+#ifdef K4REF_CHECKED
+		if (!v) throw K4RefManaged{4, "Debug.Assert"};
+#else
+		(void) v;
+#endif
+	}
+};
+// LZ4Pickler.unpickle.cs:163-181: a readonly struct of three auto-properties (make_ref.py TOPLEVEL_SUPPLIED); the constructor is :170-178
+struct PickleHeader {
+	ushort DataOffset; ushort Flags; int ResultLength;
+	bool IsCompressed() const { return (Flags & 0x0001) != 0; }                                           /* :168 */
+	PickleHeader(ushort dataOffset, int resultLength, bool compressed)
+		: DataOffset(dataOffset), Flags((ushort) ((compressed ? 0x0001 : 0x0000) << 0 | 0)), ResultLength(resultLength) {}
+};
+// LZ4Pickler.pickle.cs:214-219 (PokeN), :230-231 (UnexpectedVersion); LZ4Pickler.unpickle.cs:150-158 (PeekN), :160-161 (CorruptedPickle):
+// the same checks, the little-endian Unsafe.CopyBlockUnaligned of `size` bytes spelled memcpy
+#define K4REF_MEMBERS_LZ4Pickler \
+	static void PokeN(Span<byte> target, int value, int size) {                                           /* pickle.cs:214-219 */ \
+		if (size < 0 || size > (int) sizeof(int) || target.Length < size) throw K4RefManaged{1, "Unexpected size"}; \
+		if (size > 0) memcpy(&target[0], &value, (size_t) size); } \
+	static int PeekN(ReadOnlySpan<byte> bytes, int size) {                                                /* unpickle.cs:150-158 */ \
+		int result = 0; \
+		if (size < 0 || size > (int) sizeof(int) || size > bytes.Length) throw CorruptedPickle("Unexpected field size"); \
+		memcpy(&result, bytes._p, (size_t) size); return result; } \
+	static K4RefManaged UnexpectedVersion(int) { return K4RefManaged{1, "Unexpected pickle version"}; }   /* pickle.cs:230-231 */ \
+	static K4RefManaged CorruptedPickle(const char* m) { return K4RefManaged{2, m}; }                     /* unpickle.cs:160-161 */
 } // namespace k4ref

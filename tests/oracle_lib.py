@@ -136,6 +136,13 @@ class Oracle:
         n = self.lib.k4o_pickle(_ptr(src), src.size, _ptr(dst), _ptr(scratch), level, writer_mode)
         return dst[:n].tobytes()
 
+    def pickle_header(self, src_len: int, enc_len: int, writer_mode: int = 0) -> bytes:
+        """the V0 header alone for a block of src_len bytes whose LZ4 block is enc_len bytes"""
+        self.lib.k4o_pickle_header.argtypes = [C.c_int, C.c_int, C.c_int, _u8p]
+        out = np.zeros(8, dtype=np.uint8)
+        n = self.lib.k4o_pickle_header(src_len, enc_len, writer_mode, _ptr(out))
+        return out[:n].tobytes()
+
     def unpickle_header(self, src: bytes):
         a = np.frombuffer(src, dtype=np.uint8)
         off, rl, comp = C.c_int(), C.c_int(), C.c_int()
@@ -367,6 +374,31 @@ class RefEngine:
         dst = np.full(max(cap, 1), 0xCD, dtype=np.uint8)
         ret = self.lib.k4ref_decompress_safe_partial(_ptr(src), _ptr(dst), src.size, target, cap)
         return ret, dst[:cap]
+
+    # ---- LZ4Pickler's own header helpers (LZ4Pickler.pickle.cs:161-229, LZ4Pickler.unpickle.cs:131-148), no block encoded
+    def pickle_effective_size_of(self, value):
+        return self.lib.k4ref_pickle_effective_size_of(C.c_int(value))
+
+    def pickle_encode_size_of(self, size):
+        return self.lib.k4ref_pickle_encode_size_of(C.c_int(size))
+
+    def pickle_header_byte_v0(self, size_of_diff):
+        return self.lib.k4ref_pickle_header_byte_v0(C.c_int(size_of_diff))
+
+    def pickle_header(self, src_len, enc_len, writer_mode=0, version=0, cap=8):
+        """bytes of the header the reference writes, or the negated exception kind (1 Argument, 2 InvalidData, 3 range, 4 Debug.Assert)"""
+        self.lib.k4ref_pickle_header.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        n = self.lib.k4ref_pickle_header(writer_mode, version, src_len, enc_len, _ptr(out), cap)
+        return n if n < 0 else out[:n].tobytes()
+
+    def unpickle_header(self, src: bytes):
+        """(rc, DataOffset, ResultLength, IsCompressed, Flags); rc < 0 = the negated exception kind"""
+        a = np.frombuffer(src, dtype=np.uint8)
+        out = np.zeros(4, dtype=np.int32)
+        self.lib.k4ref_unpickle_header.argtypes = [_u8p, C.c_int, C.c_void_p]
+        rc = self.lib.k4ref_unpickle_header(_ptr(a if a.size else np.zeros(1, np.uint8)), a.size, out.ctypes.data)
+        return (rc,) + tuple(int(v) for v in out)
 
     def encode_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, level=0, threads=1):
         out = np.empty(len(src_len), dtype=np.int32)

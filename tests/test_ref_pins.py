@@ -39,11 +39,16 @@ def _same(a, b, slack=True):
 
 
 def test_translation_report(ref):
-    """what was respelled and what was not: 15 files, 11 runtime-call members supplied by the prelude, nothing else"""
+    """what was respelled and what was not: 15 engine files + the two LZ4Pickler files (header helpers only), 11 + 4 runtime-call
+    members supplied by the prelude, nothing else"""
     import json
     rep = json.load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "_ref", "make_ref_report.json")))
-    assert len(rep["files"]) == 15 and len(rep["excluded"]) == 11
-    assert {e["cls"] for e in rep["excluded"]} == {"Mem", "LL"}            # no member of LL64 / LL32 is hand-written
+    assert len(rep["files"]) == 17 and len(rep["excluded"]) == 15
+    assert {e["cls"] for e in rep["excluded"]} == {"Mem", "LL", "LZ4Pickler"}            # no member of LL64 / LL32 is hand-written
+    assert {e["member"] for e in rep["excluded"] if e["cls"] == "LZ4Pickler"} == {"PokeN", "PeekN", "UnexpectedVersion", "CorruptedPickle"}
+    assert [e["name"] for e in rep["supplied_structs"]] == ["PickleHeader"]
+    # R24: what of LZ4Pickler is NOT taken is its managed-buffer code, by name
+    assert {e["member"] for e in rep["not_taken"]} == {"Pickle", "PickleWithBuffer", "Unpickle", "UnpickledSize", "UnpickleCore"}
     assert rep["inputs_sha256"] == ref.inputs_sha256
 
 
@@ -273,6 +278,89 @@ def test_long_length_fields(ref, oracle):
         assert a[0] == b[0], (i, c.size, cap)
         if defined and a[0] > 0:
             assert a[1][:a[0]].tobytes() == b[1][:a[0]].tobytes(), (i, c.size, cap)
+
+
+_DIFFS = [0, 1, 2, 254, 255, 256, 257, 65534, 65535, 65536, 65537, (1 << 24) - 1, 1 << 24, (1 << 31) - 2, (1 << 31) - 1]
+
+
+def test_pickle_size_helpers_against_the_reference_helpers(ref, oracle):
+    """LZ4Pickler.EffectiveSizeOf / EncodeSizeOf / EncodeHeaderByteV0 (pickle.cs:221-228), the reference's own statements, against
+    the widths the oracle's header carries"""
+    for v in _DIFFS + [-1, -(1 << 31)]:
+        w = ref.pickle_effective_size_of(v)
+        assert w == (4 if (v > 0xffff or v < 0) else 2 if v > 0xff else 1)
+    assert [ref.pickle_encode_size_of(s) for s in (0, 1, 2, 4)] == [0, 1, 2, 3]
+    assert [ref.pickle_header_byte_v0(s) for s in (0, 1, 2, 4)] == [0x00, 0x40, 0x80, 0xC0]
+
+
+@pytest.mark.parametrize("writer_mode", [0, 1], ids=["array", "writer"])
+def test_pickle_header_matches_the_reference_helpers(ref, oracle, writer_mode):
+    """the header bytes of oracle.pickle, for every diff on a width boundary and both header rules (array path: width from the diff,
+    pickle.cs:97,:174-179; writer path: width from the source length, :128,:161-165), against EncodeCompressedHeader /
+    EncodeUncompressedHeader as the reference's two Pickle bodies call them.  No block is encoded: (sourceLength, encodedLength)
+    are swept directly, so 2^31-1 costs nothing."""
+    n = 0
+    for diff in _DIFFS:
+        for enc in (1, 2, 255, 256, 65535, 65536, 1 << 20, (1 << 31) - 1):
+            src_len = diff + enc
+            if src_len > (1 << 31) - 1:
+                continue
+            want = ref.pickle_header(src_len, enc, writer_mode)
+            assert not isinstance(want, int), (src_len, enc, want)        # no exception, no Debug.Assert
+            got = oracle.pickle_header(src_len, enc, writer_mode)
+            assert got == want, (src_len, enc, writer_mode, got.hex(), want.hex())
+            if diff == 0:
+                assert got == b"\x00"                                     # incompressible: enc >= src_len
+            # and back through DecodeHeader: both sides, on header + `enc` payload bytes (only the length matters)
+            env = got + bytes(min(enc, 64))
+            pad = enc - min(enc, 64)
+            r = ref.unpickle_header(env)
+            o = oracle.unpickle_header(env)
+            assert r[0] == 0 and o[0] == 0
+            assert (o[1], o[2], o[3]) == (r[1], r[2], r[3])
+            if diff:
+                assert r[1] == len(got) and r[2] + pad == src_len and r[3] == 1 and r[4] == 1
+            n += 1
+    for enc in (0, -1):                                                    # a failed encode (pickle.cs:85 `encodedLength <= 0`)
+        assert oracle.pickle_header(100, enc, writer_mode) == ref.pickle_header(100, enc, writer_mode) == b"\x00"
+    assert n > 80
+
+
+def test_unpickle_header_matches_the_reference_decode_header(ref, oracle):
+    """every first byte (version bits, width code, the unused bits 3-5) x short / exact / long inputs x field values on the width
+    boundaries: rc class and the three header fields"""
+    rng = np.random.default_rng(5)
+    fields = [0, 1, 255, 256, 65535, 65536, (1 << 31) - 1, 1 << 31, (1 << 32) - 1]
+    n = 0
+    for b0 in range(256):
+        for tail_len in (0, 1, 2, 3, 4, 5, 9):
+            for f in (fields if tail_len >= 4 else fields[:3]):
+                tail = (struct.pack("<I", f) + bytes(rng.integers(0, 256, 8, dtype=np.uint8)))[:tail_len]
+                env = bytes([b0]) + tail
+                r = ref.unpickle_header(env)
+                o = oracle.unpickle_header(env)
+                assert (r[0] < 0) == (o[0] < 0), (env.hex(), r, o)
+                if r[0] == 0:
+                    assert (o[1], o[2], o[3]) == (r[1], r[2], r[3]), (env.hex(), r, o)
+                else:
+                    assert r[0] == -2                                      # InvalidDataException (CorruptedPickle), never a range error
+                n += 1
+    assert n > 5000
+    assert ref.pickle_header(10, 5, 0, version=1) == -1 and ref.pickle_header(10, 5, 1, version=1) == -1   # UnexpectedVersion
+
+
+def test_pickle_whole_envelope_header_is_the_reference_header(ref, oracle):
+    """oracle.pickle on real blocks: the header in front of the payload is the reference helper's, for both rules"""
+    for name, data in list(_fixtures())[:12]:
+        block = np.frombuffer(data, dtype=np.uint8)
+        if block.size == 0:
+            continue
+        for wm in (0, 1):
+            env = oracle.pickle(block, 0, wm)
+            rc, off, rl, comp, _ = ref.unpickle_header(env)
+            assert rc == 0 and rl == block.size
+            enc_len = len(env) - off if comp else block.size
+            assert env[:off] == ref.pickle_header(block.size, enc_len, wm), (name, wm)
 
 
 def test_signcheck_is_clean():
