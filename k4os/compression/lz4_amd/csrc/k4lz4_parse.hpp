@@ -150,6 +150,26 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
 #define K4_PT(i) ((void)0)
 #define K4_PN(i, v) ((void)0)
 #endif
+/* fast_round's two spare counters: the chain's scalar loop and its lazy resolutions, or (K4_PARSE_PROF_SPLIT) the part of the
+ * phase behind the chain up to the next round's loads, and the records */
+#if defined(K4_PARSE_PROF) && !defined(K4_PARSE_PROF_SPLIT)
+#define K4_TICA() K4_TIC()
+#define K4_TOCA(i) K4_TOC(i)
+#else
+#define K4_TICA() ((void)0)
+#define K4_TOCA(i) ((void)0)
+#endif
+#if defined(K4_PARSE_PROF) && defined(K4_PARSE_PROF_SPLIT)
+#define K4_TICB() const unsigned long long ticb_ = (unsigned long long)__builtin_readcyclecounter()
+#define K4_TOCB(i) (pt[i] += (unsigned long long)__builtin_readcyclecounter() - ticb_)
+#define K4_TICC() const unsigned long long ticc_ = (unsigned long long)__builtin_readcyclecounter()
+#define K4_TOCC(i) (pt[i] += (unsigned long long)__builtin_readcyclecounter() - ticc_)
+#else
+#define K4_TICB() ((void)0)
+#define K4_TOCB(i) ((void)0)
+#define K4_TICC() ((void)0)
+#define K4_TOCC(i) ((void)0)
+#endif
     const uint32_t mfl1 = U - (uint32_t)MFLIMIT + 1u;          /* mflimitPlusOne */
     const uint32_t matchlimit = U - (uint32_t)LASTLITERALS;
     const uint32_t last_valid = U - (uint32_t)MFLIMIT;         /* a probe at p happens iff p + step <= mflimitPlusOne (:172, :391) */
@@ -201,7 +221,14 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                 const uint32_t p2 = c + 16u + (uint32_t)lane;
                 pw2 = ld128u(src + (p2 < U - 16u ? p2 : U - 16u));
             }
-            pre2 = ld32u(src + (c >= 2u ? c - 2u : 0u));
+            /* (the word at c - 2 is the same in every lane, and a compiler that knows it moves it to a scalar register on the spot --
+             * `s_waitcnt vmcnt(0)` right here, in front of everything the loads above were issued early to overlap with; an address
+             * it cannot see through keeps the word a vector register until the next round's front looks at it) */
+            uint32_t o2 = c >= 2u ? c - 2u : 0u;
+#if !defined(K4_HOST_EMU) && !defined(K4_EXP_PRE2_SCALAR)
+            asm("" : "+v"(o2));
+#endif
+            pre2 = ld32u(src + o2);
 #ifdef K4_PARSE_AHEAD
             /* the lines two rounds on: asked for now (after the loads this round's successor waits for, so that its wait does not
              * include them), looked at never -- the asm below only keeps the compiler from dropping the load */
@@ -667,11 +694,11 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
             uint32_t hv = 0u;
             int f = 0;
             unsigned long long stop;
-            { K4_TIC(); hop_chain(hm, word, q, hts, f, hv, stop); K4_TOC(6); K4_PN(7, 1); }
+            { K4_TICA(); hop_chain(hm, word, q, hts, f, hv, stop); K4_TOCA(6); K4_PN(7, 1); }
             if (!stop) break;
             if (hv & HOP_LAZY) {
                 K4_PN(4, 1); K4_ST(lazies, 1u);
-                K4_TIC();
+                K4_TICA();
                 /* the latest VISITED lane below f with f's hash, if any: a lane is inside a match -- never put -- when it lies below the
                  * landing place of the nearest hit below it, other than two before it (:394) */
                 unsigned long long cm = ballot(hh == readlane_u32(hh, f)) & ((1ull << f) - 1ull);
@@ -701,7 +728,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                     hv = (hv & HOP_TABMISS) ? 0xffffffffu : (hv & ~HOP_LAZY);
                     if (lane == f) word = hv;
                 }
-                K4_TOC(7);
+                K4_TOCA(7);
                 if (hv == 0xffffffffu) {
                     hts &= ~(1ull << f);
                     hm &= ~(1ull << f);
@@ -729,6 +756,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         K4_PT(3);
         K4_PN(6, 1);
         K4_PHASE("next");
+        K4_TICB();
         /* (uni(): what the scalar chain hands back counts as per-lane for the compiler, and these go into the next chain's operands) */
         if (outcome == 1) { c = uni(anchor); test = true; sbase = c + 1u; }
         else if (outcome == 0) {
@@ -744,11 +772,14 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         if (++long_rounds == 32u) { more = uni(long_seen) >= 12u; long_seen = 0u; long_rounds = 0u; }
 #endif
         if (outcome != 2) prepare();
+        K4_TOCB(6);
         K4_PHASE("records");
+        K4_TICC();
         if (hts) {
             if (!DRY && mine) recs[nrec + (uint32_t)__popcll(hts & below_me)] = make_uint2(p, (p - cp) | (ec << 16));
             nrec += (uint32_t)__popcll(hts);
         }
+        K4_TOCC(7);
         if (outcome == 2) return false;
         K4_PHASE("visited");
         /* lanes inside matches: below the landing place of the nearest hit below them, except the lane two before it (:394) */
