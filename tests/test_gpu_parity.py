@@ -411,6 +411,15 @@ def test_dispatch_variants_give_identical_bytes(oracle):
         assert np.array_equal(out, want) and np.array_equal(dst, ref_dst)
 
 
+def test_randomised_ragged_batches_through_the_default_fast_encoder(oracle):
+    """tests/tools/gpu_stress_encode.py, two rounds: 2 x 1500 blocks of 0 .. 100 000 bytes (adversarial generator + corpus classes),
+    ragged output limits, through k4_parse_kernel and the one-kernel encoder behind it: return value, bytes, untouched slack"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import gpu_stress_encode
+    assert gpu_stress_encode.run(2, 5, 1500, oracle) == 0
+
+
 def test_fast_encoder_paths_give_identical_bytes(oracle):
     """Which kernels encode a fast-level batch is scheduling only: the two-kernel path of k4lz4_parse.hpp (parse + write-out by
     the parsing wave, or by k4_emit_kernel: K4LZ4_NO_INLINE_EMIT; 16 or fewer blocks per workgroup: K4LZ4_PARSE_WAVES; waves that
