@@ -550,7 +550,8 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
         else if (reorder) {
             a.cost = d_cost; a.hist = d_hist; a.order_out = d_order;
             K4_HIP(ctx, hipMemsetAsync(d_hist, 0, (2 * k4::COST_BUCKETS + 16) * 4, stream));
-            hipLaunchKernelGGL(k4::k4_cost_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a, encode_like ? 0 : 1);
+            hipLaunchKernelGGL(k4::k4_cost_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a, encode_like ? 0 : 1,
+                               kind == KIND_ENCODE && parse_path ? k4::COST_SAMPLE_PARSE : k4::COST_SAMPLE);
             /* the split between the two encoder kernels by cost (see k4_order_kernel): 48 % of it, at least one residency of
              * the LDS-table kernel; K4LZ4_SPLIT_PCT fixes a share of the NUMBER of blocks instead */
             const bool two_kernels = kind == KIND_ENCODE && !a.prof && cnt > 512 && !(flags & K4LZ4_FLAG_NO_SPLIT) &&

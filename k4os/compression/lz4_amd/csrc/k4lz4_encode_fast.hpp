@@ -973,10 +973,12 @@ __device__ __forceinline__ int codec_encode_result(int src_len, int ret, int fla
  * estimated by running the encoder without output over its first COST_SAMPLE bytes and scaling
  * the sequence count to the block length; blocks are then bucketed by cost (k4_order_kernel).
  */
-#ifndef K4_COST_SAMPLE
-#define K4_COST_SAMPLE 256
-#endif
-constexpr int COST_SAMPLE = K4_COST_SAMPLE;
+/* The sample: 256 bytes for the two-step encoder's batches (blocks under 64 KiB, all resident at once: the order only decides which
+ * nine of a workgroup's sixteen start with their table in LDS, and the estimate is part of the timed call -- 512 bytes cost the bench
+ * batch 1 % more than their better order brings), 512 for everything else (ragged batches of pickles: the split between the
+ * kernels and the longest-first order hang on it; with 256 rank 0's share of configs[3] comes out at 96 or at 120 ms from one
+ * run to the next, with 512 at 98-106, gpurun_out/r96). */
+constexpr int COST_SAMPLE = 512, COST_SAMPLE_PARSE = 256;
 constexpr int COST_BUCKETS = 64;
 
 __device__ __forceinline__ uint32_t cost_bucket(unsigned long long cost)
@@ -988,7 +990,7 @@ __device__ __forceinline__ uint32_t cost_bucket(unsigned long long cost)
 }
 
 /* a.cost[b] = bucket of block b; a.hist[bucket]++.  mode 0: encoder sample, mode 1: by length */
-__global__ __launch_bounds__(64) void k4_cost_kernel(BatchArgs a, int by_length)
+__global__ __launch_bounds__(64) void k4_cost_kernel(BatchArgs a, int by_length, int sample_bytes = COST_SAMPLE)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tab[ENCODE_LDS_DWORDS];
     const int lane = lane_id();
@@ -999,7 +1001,7 @@ __global__ __launch_bounds__(64) void k4_cost_kernel(BatchArgs a, int by_length)
         if (by_length || src_len <= 64) {
             cost = (unsigned long long)src_len;
         } else {
-            const int sample = src_len < COST_SAMPLE ? src_len : COST_SAMPLE;
+            const int sample = src_len < sample_bytes ? src_len : sample_bytes;
             uint32_t nseq = 0;
             (void)encode_fast_block<true>(a.src + a.srcOff[b], sample, nullptr, 0x7fffffff, 1u, tab, lane, nullptr, true, &nseq);
             /* ~3 probe positions per sequence-free stretch count too: base cost by length */
