@@ -172,7 +172,6 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
 #endif
     const uint32_t mfl1 = U - (uint32_t)MFLIMIT + 1u;          /* mflimitPlusOne */
     const uint32_t matchlimit = U - (uint32_t)LASTLITERALS;
-    const uint32_t last_valid = U - (uint32_t)MFLIMIT;         /* a probe at p happens iff p + step <= mflimitPlusOne (:172, :391) */
     const unsigned long long me = 1ull << lane, below_me = me - 1ull;
 
     const bool resumed = ctl && ctl->resume;
@@ -296,7 +295,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                 val[k] = pn <= mfl1 && pn > p;
             } else {
                 p = c0 + 64u * (uint32_t)k + (uint32_t)lane;
-                val[k] = plain || p <= last_valid;
+                val[k] = plain || p + 1u <= mfl1;         /* (:172 for a step of one; the search's probe 65 is the chain's business) */
             }
             pos[k] = p;
             uint32_t w0 = pw[k].v[0], w1 = pw[k].v[1], w2 = pw[k].v[2], w3 = pw[k].v[3];
@@ -458,12 +457,19 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                 klast = k;
                 bool limited = false;
                 unsigned long long limmask = ~0ull;
-                uint32_t limlane = 64u;
+                uint32_t limend = 64u;         /* the first lane the running search does not probe one by one */
                 if (!strided) {
-                    /* the search's 66th probe (:156-172: the step grows behind it) */
+                    /* the search's 66th probe, number 65 (:156-172: the step grows behind it) */
                     const int lim = (int)(sbase + 65u) - (int)w0;
                     if (lim < (int)q) { outcome = 3; upto_last = q; done = true; return; }
-                    if (lim < 63) { limited = true; limlane = (uint32_t)lim; limmask = (2ull << lim) - 1ull; }
+                    /* ... which is itself left with a step of two already (:170-171 work the step out an iteration ahead of its use), so
+                     * at the very end of a block it is not made where a probe with a step of one still would be (:172) */
+                    const bool cut65 = lim <= 63 && w0 + (uint32_t)lim + 2u > mfl1;
+                    if (lim < 63 || cut65) {
+                        limited = true;
+                        limend = cut65 ? (uint32_t)lim : (uint32_t)lim + 1u;
+                        limmask = limend >= 64u ? ~0ull : (1ull << limend) - 1ull;
+                    }
                 }
                 for (;;) {
                     uint32_t hv = 0u;
@@ -473,7 +479,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                     if (limited) {
                         /* only stops up to the limit count, and only until the first hop (a new search begins behind it): one at a time */
                         const unsigned long long t = hm & limmask & (~0ull << q);
-                        if (!t) { outcome = 3; upto_last = limlane + 1u; done = true; return; }
+                        if (!t) { outcome = 3; upto_last = limend; done = true; return; }
                         hm = t & (0ull - t);
                     }
                     { K4_TIC(); hop_chain(hm, hop[k], q, hits[k], f, hv, stop); K4_TOC(6); K4_PN(7, 1); }
@@ -496,7 +502,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                             hmx[k] &= ~(1ull << f);
                             q = (uint32_t)f + 1u;
                             if (q >= 64u) {        /* (the lane was the sub-window's last) */
-                                if (limited) { outcome = 3; upto_last = limlane + 1u; done = true; return; }
+                                if (limited) { outcome = 3; upto_last = limend; done = true; return; }
                                 if (hits[k]) { const int lf = 63 - (int)__clzll((long long)hits[k]); sbase = w0 + (readlane_u32(hop[k], lf) & 127u) + 1u; }
                                 q = 0u; etest = false; return;
                             }

@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+import adversarial_blocks
+
 from emu_lib import Emu, pack, arena
 from k4os.compression.lz4_amd import corpus
 
@@ -59,26 +61,6 @@ def test_encode_fast_matches_oracle(emu, oracle, variant):
     assert (dst[mask] == 0xCD).all()
 
 
-def _dense_four_byte_matches(n_words, total, seed):
-    """a block that is nearly all 4-byte matches with no literals between them: `n_words` words of four bytes with distinct first
-    bytes, once each, then word after word such that no pair of neighbours has stood together before (the match cannot grow into the
-    next word) -- the most sequences per byte the format allows, short of the (65546 - 6) / 4 the records are sized for"""
-    rng = np.random.default_rng(seed)
-    words = np.zeros((n_words, 4), np.uint8)
-    words[:, 0] = rng.permutation(256)[:n_words]
-    words[:, 1:] = rng.integers(0, 256, (n_words, 3))
-    out, cnt = [words[i] for i in range(n_words)], n_words * 4
-    for s in range(1, n_words):
-        x = 0
-        for _ in range(n_words):
-            if cnt + 4 > total - 12:
-                break
-            out.append(words[x]); cnt += 4
-            x = (x + s) % n_words
-    buf = np.concatenate(out)
-    return np.concatenate([buf, rng.integers(0, 256, total - buf.size, dtype=np.uint8)]).astype(np.uint8)
-
-
 @pytest.mark.parametrize("k,waves,how", [(1, 1, ""), (1, 16, "inline+migrate"), (1, 12, "inline+queue"), (1, 11, "migrate"), (2, 16, ""), (2, 9, "inline"), (3, 12, "queue"), (4, 5, "")])
 def test_encode_parse_emit_matches_oracle(emu, oracle, k, waves, how):
     """the two-kernel fast encoder (k4lz4_parse.hpp: which sequences, then their bytes): k sub-windows of 64 positions per
@@ -91,7 +73,8 @@ def test_encode_parse_emit_matches_oracle(emu, oracle, k, waves, how):
     rng = np.random.default_rng(8)
     noise = rng.integers(0, 256, 9000, dtype=np.uint8)
     blocks += [np.concatenate([corpus.lorem(700), noise, corpus.lorem(900)]), np.concatenate([noise, noise[:5000]]), noise[:4000].copy()]
-    blocks.append(_dense_four_byte_matches(128, 65546, 128))      # ~10 500 sequences: a hit on every fourth lane, round after round
+    blocks.append(adversarial_blocks.dense_four_byte_matches(128, 65546, 128))      # ~10 500 sequences: a hit on every fourth lane, round after round
+    blocks += adversarial_blocks.search_limit_at_block_end()                            # the search's 66th probe on either side of mflimitPlusOne
     src, soff, slen = pack(blocks)
     dst, doff, dcap = arena([oracle.compress_bound(b.size) for b in blocks])
     order = np.random.default_rng(k).permutation(len(blocks)).astype(np.uint32) if waves != 9 else None

@@ -417,7 +417,8 @@ def test_randomised_ragged_batches_through_the_default_fast_encoder(oracle):
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
     import gpu_stress_encode
-    assert gpu_stress_encode.run(2, 5, 1500, oracle) == 0
+    assert gpu_stress_encode.run(2, 5, 1500, oracle) == 0          # (seed 5 holds the block that found the 66th-probe corner, round 5)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_fast_encoder_paths_give_identical_bytes(oracle):
@@ -432,10 +433,13 @@ def test_fast_encoder_paths_give_identical_bytes(oracle):
     blocks += [b for b in corpus.silesia_like_blocks(60, 65536, seed=6)]
     blocks += [corpus.lorem(n) for n in (0, 1, 12, 13, 64, 127, 128, 129, 200, 65546, 65547, 70000)]
     blocks += [corpus.class_bytes("samba", 150000, 3), corpus.random_bytes(65000, 9), corpus.repeated(7, 65536)]
+    import adversarial_blocks
+    hard = adversarial_blocks.search_limit_at_block_end() + [adversarial_blocks.dense_four_byte_matches(128, 65546, 128)]
+    blocks += hard
     caps = []
-    for b in blocks:
+    for i, b in enumerate(blocks):
         bound = LZ4Codec.MaximumOutputSize(b.size)
-        caps.append(bound if rng.random() < 0.8 else int(rng.integers(0, bound + 1)))
+        caps.append(bound if i >= len(blocks) - len(hard) or rng.random() < 0.8 else int(rng.integers(0, bound + 1)))
     caps = np.array(caps, np.int32)
     src, soff, slen = pack_blocks(blocks)
     ref_dst, ref_off = make_arena(caps + 16, fill=0xCD)
