@@ -764,7 +764,10 @@ void parallel_copy(k4lz4_ctx *ctx, uint8_t *d, const uint8_t *s, size_t nbytes)
     Pool *p = pool_of(ctx);
     const int parts = p ? (int)std::min<size_t>(p->workers.size() + 1, std::max<size_t>(1, nbytes >> 20)) : 1;
     if (parts <= 1) { memcpy(d, s, nbytes); return; }
-    const size_t per = ((nbytes / (size_t)parts) + 63) & ~(size_t)63;
+    /* (the parts' size rounded UP before it is rounded to 64: with nbytes / parts a multiple of 64 and a remainder left, `parts`
+     * pieces of the rounded-down size stop up to parts - 1 bytes short of the end -- the last bytes of an upload's last chunk
+     * stayed what the pinned buffer held before; found by tests/tools/gpu_stress_encode.py in round 5) */
+    const size_t per = (((nbytes + (size_t)parts - 1) / (size_t)parts) + 63) & ~(size_t)63;
     p->parallel(parts, [=](int i) {
         const size_t lo = per * (size_t)i;
         if (lo < nbytes) memcpy(d + lo, s + lo, std::min(per, nbytes - lo));

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import pytest
 
-from k4os.compression.lz4_amd import LZ4Codec, LZ4Level, LZ4Pickler, corpus, make_arena
+from k4os.compression.lz4_amd import LZ4Codec, LZ4Level, LZ4Pickler, corpus, make_arena, pack_blocks
 from k4os.compression.lz4_amd._native import FLAG_RAW_RETURN, FLAG_SEGMENTS, FLAG_X32
 from k4os.compression.lz4_amd.sharding import byte_balanced_ranges
 
@@ -313,6 +313,33 @@ def test_host_pointer_batches_big_enough_for_the_staged_path_round_trip(oracle):
     assert (got == bs).all()
     for i in range(n):
         assert np.array_equal(back[int(boff[i]):int(boff[i]) + bs], blocks[i]), i
+
+
+@pytest.mark.parametrize("tail", [5, 1, 7, 64 * 8 + 3])
+def test_host_pointer_upload_whose_last_chunk_does_not_divide_by_the_copy_threads(oracle, tail):
+    """A source span of 40 MiB + `tail` bytes goes up in chunks of 16 MiB, each copied into its pinned buffer by up to eight
+    threads: the last chunk is 8 MiB + tail, an eighth of it a whole number of 64-byte lines with `tail` bytes left over -- which
+    the split used to drop (the last bytes of the upload stayed what the buffer held before: round 5, found by
+    tests/tools/gpu_stress_encode.py as 5 wrong bytes at the end of one block in 12 000).  The buffers are dirtied by a first
+    call with other bytes; then every block against the oracle, the last one to its last literal."""
+    bs = 65536
+    n = 640
+    dirt = np.full(n * bs + 4096, 0x5A, np.uint8)
+    off = np.arange(n, dtype=np.uint64) * bs
+    lens = np.full(n, bs, np.int32)
+    caps = np.full(n, LZ4Codec.MaximumOutputSize(bs + 4096), np.int32)
+    dst, doff = make_arena(caps, fill=0xCD)
+    LZ4Codec.EncodeBatchPacked(dirt, off, lens, dst, doff, caps)
+    blocks = [b for b in corpus.silesia_like_blocks(n - 1, bs, seed=13)] + [corpus.class_bytes("dickens", bs + tail, 4)]
+    src, off, lens = pack_blocks(blocks)
+    assert src.size == 40 * (1 << 20) + tail
+    dst, doff = make_arena(caps, fill=0xCD)
+    out = LZ4Codec.EncodeBatchPacked(src, off, lens, dst, doff, caps)
+    ref, roff = make_arena(caps, fill=0xCD)
+    want = oracle.encode_batch(src, off, lens, ref, roff, caps, threads=os.cpu_count() or 8)
+    assert np.array_equal(out, want)
+    for i in range(n):
+        assert np.array_equal(dst[int(doff[i]):int(doff[i]) + want[i]], ref[int(roff[i]):int(roff[i]) + want[i]]), i
 
 
 def test_host_pointer_staging_branches_big_ragged_shuffled(oracle):
