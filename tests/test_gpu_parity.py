@@ -411,6 +411,66 @@ def test_dispatch_variants_give_identical_bytes(oracle):
         assert np.array_equal(out, want) and np.array_equal(dst, ref_dst)
 
 
+def _zero_one_offset(enc: bytes, rng) -> bytes:
+    """the stream with the offset of one of its sequences set to 0 (LL64.dec.cs:408-418 lets it through: the match copies output
+    bytes onto themselves, i.e. leaves what the target held)"""
+    e = bytearray(enc)
+    i, offs = 0, []
+    while i < len(e):
+        t = e[i]; i += 1
+        ll = t >> 4
+        if ll == 15:
+            while True:
+                x = e[i]; i += 1; ll += x
+                if x != 255: break
+        i += ll
+        if i >= len(e): break
+        offs.append(i); i += 2
+        if (t & 15) == 15:
+            while e[i] == 255: i += 1
+            i += 1
+    if offs:
+        k = offs[int(rng.integers(0, len(offs)))]
+        e[k] = 0; e[k + 1] = 0
+    return bytes(e)
+
+
+def test_streams_with_an_offset_of_zero_leave_the_target_as_it_was(oracle):
+    """Hostile streams the reference decodes without complaint: a match with offset 0 copies output bytes onto themselves, so those
+    bytes of the target stay what they were (0xCD here).  The captured stream (tests/golden/mutated_stream_offset0_in_shortcut.npy:
+    found by tests/tools/gpu_stress_all.py in round 5) and 300 made ones."""
+    rng = np.random.default_rng(77)
+    here = os.path.dirname(os.path.abspath(__file__))
+    streams = [np.load(os.path.join(here, "golden", "mutated_stream_offset0_in_shortcut.npy")).tobytes()]
+    sizes = [5813]
+    for i in range(300):
+        b = corpus.class_bytes(corpus.SILESIA_NAMES[i % 12], int(rng.integers(200, 20000)), i)
+        streams.append(_zero_one_offset(oracle.encode(b), rng))
+        sizes.append(b.size + int(rng.choice([0, 0, 7, 100])))
+    src, soff, slen = pack_blocks([np.frombuffer(x, np.uint8) for x in streams])
+    caps = np.array(sizes, np.int32)
+    import torch
+    from k4os.compression.lz4_amd.device import DeviceBatch, DeviceCodec
+    ref, roff = make_arena(caps + 16, fill=0xCD)
+    want = oracle.decode_batch(src, soff, slen, ref, roff, caps, threads=8)
+    # on DEVICE buffers: "as it was" is what the target slot held.  (Through host pointers the target slot is the context's staging
+    # buffer and the caller gets what THAT held: the one place where a host-pointer call and the reference can differ -- in bytes
+    # the reference itself leaves undefined -- see DESIGN.md 8.)
+    dc = DeviceCodec(0)
+    sb = DeviceBatch.from_host(src, soff, slen, dc.device)
+    db = DeviceBatch(torch.full((ref.size,), 0xCD, dtype=torch.uint8, device=dc.device), torch.from_numpy(roff.view(np.int64)).to(dc.device),
+                     torch.from_numpy(caps).to(dc.device))
+    got = dc.decode(sb, db).cpu().numpy()
+    dst, doff = db.data.cpu().numpy(), roff
+    assert np.array_equal(got, want)
+    assert (want > 0).sum() > 200
+    for i in range(len(streams)):
+        if want[i] > 0:
+            a, b = int(doff[i]), int(roff[i])
+            assert np.array_equal(dst[a:a + want[i]], ref[b:b + want[i]]), i          # the bytes left alone included
+            assert (dst[a + caps[i]:a + caps[i] + 16] == 0xCD).all(), i
+
+
 def test_randomised_ragged_batches_through_the_default_fast_encoder(oracle):
     """tests/tools/gpu_stress_encode.py, two rounds: 2 x 1500 blocks of 0 .. 100 000 bytes (adversarial generator + corpus classes),
     ragged output limits, through k4_parse_kernel and the one-kernel encoder behind it: return value, bytes, untouched slack"""

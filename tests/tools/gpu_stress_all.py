@@ -1,0 +1,152 @@
+#!/usr/bin/env python
+"""Randomised stress of the other batch paths ON THE GPU against the oracle (the fast encoder has gpu_stress_encode.py):
+  decode   oracle-encoded ragged blocks into exact / oversize / short targets, through host pointers: lengths, error returns, bytes
+  mutate   the same streams with random bytes flipped / truncated: return value, and the bytes where the oracle succeeds
+  pickle   ragged messages (tiny ... 1 MiB) through LZ4Pickler.PickleBatch (both header rules) and back
+  hc       small ragged batches at levels 3 and 9
+  sizes    host-pointer encode + decode of equal blocks with the batch's total length swept around the 16 MiB staging chunks
+Usage: tests/tools/gpu_stress_all.py [rounds] [seed] [which ...]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+from oracle_lib import Oracle
+from emu_stress_encode import gen
+from k4os.compression.lz4_amd import pack_blocks, make_arena, LZ4Codec, LZ4Pickler, LZ4Level, corpus
+
+
+def blocks_of(rng, count, hi=65547):
+    out = []
+    for _ in range(count):
+        n = int(rng.choice([rng.integers(0, 40), rng.integers(100, 400), rng.integers(300, 6000), rng.integers(6000, hi), rng.integers(max(1, hi - 1500), hi)]))
+        if n == 0: out.append(np.zeros(0, np.uint8))
+        elif rng.random() < 0.5: out.append(gen(rng, n))
+        else: out.append(corpus.class_bytes(corpus.SILESIA_NAMES[int(rng.integers(0, 12))], n, int(rng.integers(0, 1 << 30))))
+    return out
+
+
+def check(name, r, i, ok, msg):
+    if not ok: print(f"{name} round {r} item {i}: {msg}")
+    return 0 if ok else 1
+
+
+def decode_round(rng, oracle, r, mutate):
+    bad = 0
+    blocks = blocks_of(rng, 1500)
+    enc = [np.frombuffer(oracle.encode(b), np.uint8) if b.size else np.zeros(0, np.uint8) for b in blocks]
+    if mutate:
+        enc2 = []
+        for e in enc:
+            e = e.copy()
+            if e.size and rng.random() < 0.8:
+                for _ in range(int(rng.integers(1, 4))):
+                    e[int(rng.integers(0, e.size))] = rng.integers(0, 256)
+                if rng.random() < 0.2: e = e[:int(rng.integers(0, e.size + 1))]
+            enc2.append(e)
+        enc = enc2
+    src, soff, slen = pack_blocks(enc)
+    caps = np.array([b.size if rng.random() < 0.6 else max(0, b.size + int(rng.integers(-40, 200))) for b in blocks], np.int32)
+    d1, o1 = make_arena(caps + 16, fill=0xCD); d2, o2 = make_arena(caps + 16, fill=0xCD)
+    want = oracle.decode_batch(src, soff, slen, d2, o2, caps, threads=32)
+    if mutate:
+        # on device buffers filled like the oracle's: a hostile offset of 0 leaves target bytes as they were (LL64.dec.cs:408-418), and
+        # through host pointers "the target" is the context's staging buffer
+        import torch
+        from k4os.compression.lz4_amd.device import DeviceBatch, DeviceCodec
+        dc = DeviceCodec(0)
+        sb = DeviceBatch.from_host(src, soff, slen, dc.device)
+        db = DeviceBatch(torch.full((d1.size,), 0xCD, dtype=torch.uint8, device=dc.device), torch.from_numpy(o1.view(np.int64)).to(dc.device), torch.from_numpy(caps).to(dc.device))
+        got = dc.decode(sb, db).cpu().numpy()
+        d1 = db.data.cpu().numpy()
+    else:
+        got = LZ4Codec.DecodeBatchPacked(src, soff, slen, d1, o1, caps)
+    for i in range(len(blocks)):
+        ok = got[i] == want[i]
+        if ok and want[i] > 0:
+            a, b = int(o1[i]), int(o2[i])
+            ok = bytes(d1[a:a + want[i]]) == bytes(d2[b:b + want[i]]) and bool((d1[a + caps[i]:a + caps[i] + 16] == 0xCD).all())
+        if not ok:
+            os.makedirs(os.path.join(ROOT, "gpurun_out", "stress_fail"), exist_ok=True)
+            a, b = int(o1[i]), int(o2[i])
+            np.savez(os.path.join(ROOT, "gpurun_out", "stress_fail", f"{'mutate' if mutate else 'decode'}_{r}_{i}.npz"), stream=enc[i], cap=caps[i], want=want[i], got=got[i],
+                     gpu=d1[a:a + caps[i] + 16], ref=d2[b:b + caps[i] + 16])
+        bad += check("mutate" if mutate else "decode", r, i, ok, f"len {slen[i]} cap {caps[i]} want {want[i]} got {got[i]}")
+    return bad, len(blocks)
+
+
+def pickle_round(rng, oracle, r):
+    bad = 0
+    msgs = blocks_of(rng, 400, hi=int(rng.choice([70000, 200000, 600000])))
+    for wm in (False, True):
+        envs = LZ4Pickler.PickleBatch(msgs, writer_mode=wm)
+        for i, m in enumerate(msgs):
+            want = oracle.pickle(m, 0, 1 if wm else 0)
+            bad += check("pickle", r, i, bytes(envs[i]) == want, f"len {m.size} writer {wm}: envelope {len(envs[i])} against {len(want)}")
+        back = LZ4Pickler.UnpickleBatch(envs)
+        for i, m in enumerate(msgs):
+            bad += check("unpickle", r, i, bytes(back[i]) == m.tobytes(), f"len {m.size}")
+    return bad, 2 * len(msgs)
+
+
+def hc_round(rng, oracle, r):
+    bad = 0
+    blocks = blocks_of(rng, 300)
+    src, soff, slen = pack_blocks(blocks)
+    for level in (3, 9):
+        caps = np.array([LZ4Codec.MaximumOutputSize(b.size) if rng.random() < 0.8 else int(rng.integers(0, LZ4Codec.MaximumOutputSize(b.size) + 1)) for b in blocks], np.int32)
+        d1, o1 = make_arena(caps + 16, fill=0xCD); d2, o2 = make_arena(caps + 16, fill=0xCD)
+        want = oracle.encode_batch(src, soff, slen, d2, o2, caps, level=level, threads=32)
+        got = LZ4Codec.EncodeBatchPacked(src, soff, slen, d1, o1, caps, level=LZ4Level(level))
+        for i in range(len(blocks)):
+            ok = got[i] == want[i]
+            if ok and want[i] > 0:
+                a, b = int(o1[i]), int(o2[i])
+                ok = bytes(d1[a:a + want[i]]) == bytes(d2[b:b + want[i]]) and bool((d1[a + want[i]:a + caps[i] + 16] == 0xCD).all())
+            bad += check(f"hc{level}", r, i, ok, f"len {slen[i]} cap {caps[i]} want {want[i]} got {got[i]}")
+    return bad, 2 * len(blocks)
+
+
+def sizes_round(rng, oracle, r):
+    """equal blocks whose total is a few bytes around multiples of the staging chunk and of the copy threads' split"""
+    bad = 0
+    bs = int(rng.choice([65536, 16384, 4096]))
+    total = int(rng.choice([32, 40, 48, 64, 72])) * (1 << 20) + int(rng.integers(-70, 70)) + int(rng.choice([0, 1 << 19, 1 << 20, 3 << 20]))
+    n = total // bs
+    last = total - (n - 1) * bs                      # the last block takes the odd bytes
+    if last > 65546: last = 65546
+    blocks = [b for b in corpus.silesia_like_blocks(n - 1, bs, seed=int(rng.integers(0, 1 << 30)))] + [corpus.class_bytes("webster", last, int(rng.integers(0, 1 << 30)))]
+    src, soff, slen = pack_blocks(blocks)
+    caps = np.array([LZ4Codec.MaximumOutputSize(b.size) for b in blocks], np.int32)
+    d1, o1 = make_arena(caps, fill=0xCD); d2, o2 = make_arena(caps, fill=0xCD)
+    want = oracle.encode_batch(src, soff, slen, d2, o2, caps, threads=32)
+    got = LZ4Codec.EncodeBatchPacked(src, soff, slen, d1, o1, caps)
+    for i in range(n):
+        ok = got[i] == want[i] and bytes(d1[int(o1[i]):int(o1[i]) + want[i]]) == bytes(d2[int(o2[i]):int(o2[i]) + want[i]])
+        bad += check("sizes-encode", r, i, ok, f"total {src.size} block {bs}")
+    back, boff = make_arena(slen, fill=0xCD)
+    dl = LZ4Codec.DecodeBatchPacked(d1, o1, got, back, boff, slen)
+    for i in range(n):
+        ok = dl[i] == slen[i] and bytes(back[int(boff[i]):int(boff[i]) + slen[i]]) == blocks[i].tobytes()
+        bad += check("sizes-decode", r, i, ok, f"total {src.size} block {bs}")
+    return bad, 2 * n
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    which = sys.argv[3:] or ["decode", "mutate", "pickle", "hc", "sizes"]
+    oracle = Oracle()
+    rng = np.random.default_rng(seed)
+    bad = total = 0
+    t = time.time()
+    for r in range(rounds):
+        for w in which:
+            b, n = {"decode": lambda: decode_round(rng, oracle, r, False), "mutate": lambda: decode_round(rng, oracle, r, True),
+                    "pickle": lambda: pickle_round(rng, oracle, r), "hc": lambda: hc_round(rng, oracle, r), "sizes": lambda: sizes_round(rng, oracle, r)}[w]()
+            bad += b; total += n
+    print(f"seed {seed}: {rounds} rounds of {which}, {total} items, {bad} failures, {time.time() - t:.0f}s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
