@@ -5,6 +5,8 @@
   pickle   ragged messages (tiny ... 1 MiB) through LZ4Pickler.PickleBatch (both header rules) and back
   hc       small ragged batches at levels 3 and 9
   sizes    host-pointer encode + decode of equal blocks with the batch's total length swept around the 16 MiB staging chunks
+  bigpickle / flags / many   (not in the default set) messages up to 4 MiB through the segment path; FLAG_X32, FLAG_ALLOW_COPY,
+           FLAG_NO_REORDER; 9 000 .. 14 000 small blocks in one call
 Usage: tests/tools/gpu_stress_all.py [rounds] [seed] [which ...]"""
 import os, sys, time
 import numpy as np
@@ -131,6 +133,66 @@ def sizes_round(rng, oracle, r):
     return bad, 2 * n
 
 
+def bigpickle_round(rng, oracle, r):
+    """messages of 64 KiB .. 4 MiB: the segment path (k4lz4_segments.hpp) -- cut points, warm-up, joins -- against oracle.pickle"""
+    bad = 0
+    msgs = []
+    for _ in range(int(rng.integers(20, 60))):
+        n = int(rng.choice([rng.integers(65547, 200000), rng.integers(200000, 1 << 20), rng.integers(1 << 20, 4 << 20)]))
+        kind = rng.random()
+        if kind < 0.4: msgs.append(gen(rng, n))
+        elif kind < 0.9: msgs.append(corpus.class_bytes(corpus.SILESIA_NAMES[int(rng.integers(0, 12))], n, int(rng.integers(0, 1 << 30))))
+        else: msgs.append(np.concatenate([corpus.class_bytes("dickens", n // 2, 1), rng.integers(0, 256, n - n // 2, dtype=np.uint8)]))
+    msgs += blocks_of(rng, 300)
+    envs = LZ4Pickler.PickleBatch(msgs)
+    for i, m in enumerate(msgs):
+        want = oracle.pickle(m, 0, 0)
+        bad += check("bigpickle", r, i, bytes(envs[i]) == want, f"len {m.size}: envelope {len(envs[i])} against {len(want)}")
+    back = LZ4Pickler.UnpickleBatch(envs)
+    for i, m in enumerate(msgs):
+        bad += check("bigunpickle", r, i, bytes(back[i]) == m.tobytes(), f"len {m.size}")
+    return bad, 2 * len(msgs)
+
+
+def flags_round(rng, oracle, r):
+    """LL32 for big blocks (FLAG_X32 / Enforce32), blocks stored raw when they do not shrink (FLAG_ALLOW_COPY), the order kept"""
+    from k4os.compression.lz4_amd._native import FLAG_X32, FLAG_ALLOW_COPY, FLAG_NO_REORDER
+    bad = 0
+    blocks = blocks_of(rng, 400, hi=int(rng.choice([65547, 200000])))
+    src, soff, slen = pack_blocks(blocks)
+    caps = np.array([LZ4Codec.MaximumOutputSize(b.size) for b in blocks], np.int32)
+    for flags in (FLAG_X32, FLAG_NO_REORDER, FLAG_ALLOW_COPY):
+        d1, o1 = make_arena(caps + 16, fill=0xCD)
+        got = LZ4Codec.EncodeBatchPacked(src, soff, slen, d1, o1, caps, flags=flags)
+        for i, b in enumerate(blocks):
+            if flags == FLAG_X32: n, out = oracle.compress_fast_x32(b, int(caps[i]))
+            else: n, out = oracle.compress_fast(b, int(caps[i]))
+            a = int(o1[i])
+            if flags == FLAG_ALLOW_COPY and b.size and (n <= 0 or n >= b.size):
+                ok = got[i] == -b.size and bytes(d1[a:a + b.size]) == b.tobytes()
+            else:
+                w = 0 if b.size == 0 else (-1 if n <= 0 else n)
+                ok = got[i] == w and (w <= 0 or bytes(d1[a:a + w]) == bytes(out[:w]))
+            bad += check(f"flags{flags}", r, i, ok, f"len {b.size} got {got[i]} oracle {n}")
+    return bad, 3 * len(blocks)
+
+
+def many_round(rng, oracle, r):
+    """more blocks than one launch chunk holds (the parse kernel takes 16 per CU at a time)"""
+    bad = 0
+    n = int(rng.integers(9000, 14000)); bs = int(rng.choice([4096, 8192, 2000]))
+    blocks = [b for b in corpus.silesia_like_blocks(n, bs, seed=int(rng.integers(0, 1 << 30)))]
+    src, soff, slen = pack_blocks(blocks)
+    caps = np.full(n, LZ4Codec.MaximumOutputSize(bs), np.int32)
+    d1, o1 = make_arena(caps, fill=0xCD); d2, o2 = make_arena(caps, fill=0xCD)
+    want = oracle.encode_batch(src, soff, slen, d2, o2, caps, threads=32)
+    got = LZ4Codec.EncodeBatchPacked(src, soff, slen, d1, o1, caps)
+    for i in range(n):
+        ok = got[i] == want[i] and bytes(d1[int(o1[i]):int(o1[i]) + want[i]]) == bytes(d2[int(o2[i]):int(o2[i]) + want[i]])
+        bad += check("many", r, i, ok, f"blocks {n} of {bs}")
+    return bad, n
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -142,7 +204,8 @@ def main():
     for r in range(rounds):
         for w in which:
             b, n = {"decode": lambda: decode_round(rng, oracle, r, False), "mutate": lambda: decode_round(rng, oracle, r, True),
-                    "pickle": lambda: pickle_round(rng, oracle, r), "hc": lambda: hc_round(rng, oracle, r), "sizes": lambda: sizes_round(rng, oracle, r)}[w]()
+                    "pickle": lambda: pickle_round(rng, oracle, r), "hc": lambda: hc_round(rng, oracle, r), "sizes": lambda: sizes_round(rng, oracle, r),
+                    "bigpickle": lambda: bigpickle_round(rng, oracle, r), "flags": lambda: flags_round(rng, oracle, r), "many": lambda: many_round(rng, oracle, r)}[w]()
             bad += b; total += n
     print(f"seed {seed}: {rounds} rounds of {which}, {total} items, {bad} failures, {time.time() - t:.0f}s")
     sys.exit(1 if bad else 0)
