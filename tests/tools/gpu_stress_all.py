@@ -121,15 +121,23 @@ def sizes_round(rng, oracle, r):
     caps = np.array([LZ4Codec.MaximumOutputSize(b.size) for b in blocks], np.int32)
     d1, o1 = make_arena(caps, fill=0xCD); d2, o2 = make_arena(caps, fill=0xCD)
     want = oracle.encode_batch(src, soff, slen, d2, o2, caps, threads=32)
-    got = LZ4Codec.EncodeBatchPacked(src, soff, slen, d1, o1, caps)
-    for i in range(n):
-        ok = got[i] == want[i] and bytes(d1[int(o1[i]):int(o1[i]) + want[i]]) == bytes(d2[int(o2[i]):int(o2[i]) + want[i]])
-        bad += check("sizes-encode", r, i, ok, f"total {src.size} block {bs}")
     back, boff = make_arena(slen, fill=0xCD)
-    dl = LZ4Codec.DecodeBatchPacked(d1, o1, got, back, boff, slen)
-    for i in range(n):
-        ok = dl[i] == slen[i] and bytes(back[int(boff[i]):int(boff[i]) + slen[i]]) == blocks[i].tobytes()
-        bad += check("sizes-decode", r, i, ok, f"total {src.size} block {bs}")
+    reg = rng.random() < 0.5                          # every other round with the caller's three buffers page-locked (k4lz4_host_register)
+    from k4os.compression.lz4_amd import host_register, host_unregister
+    held = []
+    try:
+        if reg:
+            for arr in (src, d1, back): host_register(arr); held.append(arr)
+        got = LZ4Codec.EncodeBatchPacked(src, soff, slen, d1, o1, caps)
+        for i in range(n):
+            ok = got[i] == want[i] and bytes(d1[int(o1[i]):int(o1[i]) + want[i]]) == bytes(d2[int(o2[i]):int(o2[i]) + want[i]])
+            bad += check("sizes-encode", r, i, ok, f"total {src.size} block {bs} registered {reg}")
+        dl = LZ4Codec.DecodeBatchPacked(d1, o1, got, back, boff, slen)
+        for i in range(n):
+            ok = dl[i] == slen[i] and bytes(back[int(boff[i]):int(boff[i]) + slen[i]]) == blocks[i].tobytes()
+            bad += check("sizes-decode", r, i, ok, f"total {src.size} block {bs} registered {reg}")
+    finally:
+        for arr in held: host_unregister(arr)
     return bad, 2 * n
 
 
