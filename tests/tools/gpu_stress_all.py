@@ -5,7 +5,7 @@
   pickle   ragged messages (tiny ... 1 MiB) through LZ4Pickler.PickleBatch (both header rules) and back
   hc       small ragged batches at levels 3 and 9
   sizes    host-pointer encode + decode of equal blocks with the batch's total length swept around the 16 MiB staging chunks
-  bigpickle / flags / many   (not in the default set) messages up to 4 MiB through the segment path; FLAG_X32, FLAG_ALLOW_COPY,
+  bigpickle / flags / many / frames   (not in the default set) messages up to 4 MiB through the segment path; FLAG_X32, FLAG_ALLOW_COPY,
            FLAG_NO_REORDER; 9 000 .. 14 000 small blocks in one call
 Usage: tests/tools/gpu_stress_all.py [rounds] [seed] [which ...]"""
 import os, sys, time
@@ -201,6 +201,41 @@ def many_round(rng, oracle, r):
     return bad, n
 
 
+def frames_round(rng, oracle, r):
+    """LZ4 frames: random contents (0 .. 3 MB), block sizes, checksums -- bit-exact with the frame oracle, decodable by liblz4, and
+    liblz4's own frames (linked blocks included) decodable here"""
+    from oracle_lib import FrameOracle
+    from test_frame_layer import LZ4F
+    from k4os.compression.lz4_amd import LZ4Frame, LZ4EncoderSettings
+    fo = FrameOracle(oracle)
+    try: lz4f = LZ4F()
+    except OSError: lz4f = None
+    bad = 0
+    contents = []
+    for _ in range(24):
+        n = int(rng.choice([rng.integers(0, 100), rng.integers(100, 70000), rng.integers(60000, 300000), rng.integers(300000, 3000000)]))
+        contents.append(gen(rng, n) if rng.random() < 0.5 and n else corpus.class_bytes(corpus.SILESIA_NAMES[int(rng.integers(0, 12))], n, int(rng.integers(0, 1 << 30))) if n else np.zeros(0, np.uint8))
+    bs = int(rng.choice([65536, 262144, 1 << 20, 4 << 20])); bsum = bool(rng.random() < 0.5); csum = bool(rng.random() < 0.5)
+    frames = LZ4Frame.EncodeBatch(contents, LZ4EncoderSettings(BlockSize=bs, BlockChecksum=bsum, ContentChecksum=csum))
+    for i, (data, fr) in enumerate(zip(contents, frames)):
+        bad += check("frame-encode", r, i, fr == fo.frame_encode(data, bs, 0, bsum, csum), f"len {data.size} block {bs} sums {bsum} {csum}")
+        if lz4f is not None:
+            rr, out, used = lz4f.decompress(fr, data.size + 16)
+            bad += check("frame-liblz4", r, i, rr == 0 and used == len(fr) and out == data.tobytes(), f"len {data.size}")
+    back = LZ4Frame.DecodeBatch(frames)
+    for i, data in enumerate(contents):
+        bad += check("frame-decode", r, i, bytes(back[i]) == data.tobytes(), f"len {data.size}")
+    n_items = 3 * len(contents)
+    if lz4f is not None:
+        theirs = [lz4f.compress(c, block_id=int(rng.choice([4, 5, 6, 7])), linked=bool(rng.random() < 0.5), block_checksum=bool(rng.random() < 0.5),
+                                content_checksum=bool(rng.random() < 0.5), content_size=bool(rng.random() < 0.5)) for c in contents]
+        back = LZ4Frame.DecodeBatch(theirs)
+        for i, data in enumerate(contents):
+            bad += check("frame-from-liblz4", r, i, bytes(back[i]) == data.tobytes(), f"len {data.size}")
+        n_items += len(contents)
+    return bad, n_items
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -213,7 +248,7 @@ def main():
         for w in which:
             b, n = {"decode": lambda: decode_round(rng, oracle, r, False), "mutate": lambda: decode_round(rng, oracle, r, True),
                     "pickle": lambda: pickle_round(rng, oracle, r), "hc": lambda: hc_round(rng, oracle, r), "sizes": lambda: sizes_round(rng, oracle, r),
-                    "bigpickle": lambda: bigpickle_round(rng, oracle, r), "flags": lambda: flags_round(rng, oracle, r), "many": lambda: many_round(rng, oracle, r)}[w]()
+                    "bigpickle": lambda: bigpickle_round(rng, oracle, r), "flags": lambda: flags_round(rng, oracle, r), "many": lambda: many_round(rng, oracle, r), "frames": lambda: frames_round(rng, oracle, r)}[w]()
             bad += b; total += n
     print(f"seed {seed}: {rounds} rounds of {which}, {total} items, {bad} failures, {time.time() - t:.0f}s")
     sys.exit(1 if bad else 0)
