@@ -5,7 +5,7 @@
   pickle   ragged messages (tiny ... 1 MiB) through LZ4Pickler.PickleBatch (both header rules) and back
   hc       small ragged batches at levels 3 and 9
   sizes    host-pointer encode + decode of equal blocks with the batch's total length swept around the 16 MiB staging chunks
-  bigpickle / flags / many / frames   (not in the default set) messages up to 4 MiB through the segment path; FLAG_X32, FLAG_ALLOW_COPY,
+  bigpickle / flags / many / frames / partial / dict / hclevels / envelopes   (not in the default set) messages up to 4 MiB through the segment path; FLAG_X32, FLAG_ALLOW_COPY,
            FLAG_NO_REORDER; 9 000 .. 14 000 small blocks in one call
 Usage: tests/tools/gpu_stress_all.py [rounds] [seed] [which ...]"""
 import os, sys, time
@@ -236,6 +236,101 @@ def frames_round(rng, oracle, r):
     return bad, n_items
 
 
+def partial_round(rng, oracle, r):
+    """LZ4Codec.PartialDecode as a batch (FLAG_PARTIAL: the slot capacity is the number of bytes wanted), valid and mutated streams"""
+    from k4os.compression.lz4_amd._native import FLAG_PARTIAL
+    bad = 0
+    blocks = [b for b in blocks_of(rng, 500) if b.size]
+    enc = []
+    for b in blocks:
+        e = np.frombuffer(oracle.encode(b), np.uint8).copy()
+        if rng.random() < 0.25 and e.size: e[int(rng.integers(0, e.size))] = rng.integers(0, 256)
+        enc.append(e)
+    src, soff, slen = pack_blocks(enc)
+    wants = np.array([int(rng.choice([0, 1, rng.integers(0, b.size + 1), b.size, b.size + int(rng.integers(1, 100))])) for b in blocks], np.int32)
+    d1, o1 = make_arena(wants + 32, fill=0xCD)
+    got = LZ4Codec.DecodeBatchPacked(src, soff, slen, d1, o1, wants, flags=FLAG_PARTIAL)
+    for i, b in enumerate(blocks):
+        n, ref = oracle.decompress_partial(enc[i], int(wants[i]), int(wants[i]))
+        n = -1 if n <= 0 else n
+        a = int(o1[i])
+        ok = got[i] == n and (n <= 0 or bytes(d1[a:a + n]) == bytes(ref[:n])) and bool((d1[a + wants[i]:a + wants[i] + 16] == 0xCD).all())
+        bad += check("partial", r, i, ok, f"len {b.size} wanted {wants[i]} oracle {n} got {got[i]}")
+    return bad, len(blocks)
+
+
+def dict_round(rng, oracle, r):
+    """Decode(source, target, dictionary): blocks compressed by liblz4 against a dictionary (external: anywhere; prefix: right in
+    front of the target -- not reachable through packed host arenas, so external only), valid and mutated"""
+    from oracle_lib import SystemLZ4
+    try: sys4 = SystemLZ4()
+    except OSError: return 0, 0
+    bad = 0
+    blocks = [b for b in blocks_of(rng, 300) if b.size >= 16]
+    dicts = [corpus.class_bytes(corpus.SILESIA_NAMES[int(rng.integers(0, 12))], int(rng.integers(4, 70000)), int(rng.integers(0, 1 << 30))) for _ in blocks]
+    # make the dictionary worth something: the block repeats parts of it
+    for i, b in enumerate(blocks):
+        d = dicts[i]
+        if d.size >= 64 and b.size >= 200:
+            k = int(rng.integers(0, d.size - 60)); at = int(rng.integers(0, b.size - 60)); b = b.copy(); b[at:at + 50] = d[k:k + 50]; blocks[i] = b
+    enc = []
+    for b, d in zip(blocks, dicts):
+        e = sys4.compress_with_dict(b, d).copy()
+        if rng.random() < 0.2 and e.size: e[int(rng.integers(0, e.size))] = rng.integers(0, 256)
+        enc.append(e)
+    src, soff, slen = pack_blocks(enc)
+    dsrc, dictoff, dictlen = pack_blocks(dicts)
+    caps = np.array([b.size if rng.random() < 0.7 else b.size + int(rng.integers(-30, 60)) for b in blocks], np.int32).clip(min=0)
+    d1, o1 = make_arena(caps + 16, fill=0xCD)
+    got = LZ4Codec.DecodeDictBatchPacked(src, soff, slen, d1, o1, caps, dsrc, dictoff, dictlen)
+    for i, b in enumerate(blocks):
+        n, ref = oracle.decompress_using_dict(enc[i], int(caps[i]), dicts[i])
+        n = -1 if n < 0 or (n == 0 and enc[i].size) else n
+        a = int(o1[i])
+        ok = (got[i] == n or (n <= 0 and got[i] <= 0)) and (n <= 0 or bytes(d1[a:a + n]) == bytes(ref[:n]))
+        bad += check("dict", r, i, ok, f"len {b.size} dict {dicts[i].size} cap {caps[i]} oracle {n} got {got[i]}")
+    return bad, len(blocks)
+
+
+def hclevels_round(rng, oracle, r):
+    """every HC level on a small ragged batch (chain levels 3..9, the optimal parser 10..12)"""
+    bad = 0
+    blocks = blocks_of(rng, 60, hi=int(rng.choice([20000, 65547])))
+    src, soff, slen = pack_blocks(blocks)
+    caps = np.array([LZ4Codec.MaximumOutputSize(b.size) for b in blocks], np.int32)
+    for level in (4, 5, 6, 7, 8, 10, 11, 12):
+        d1, o1 = make_arena(caps + 16, fill=0xCD); d2, o2 = make_arena(caps + 16, fill=0xCD)
+        want = oracle.encode_batch(src, soff, slen, d2, o2, caps, level=level, threads=32)
+        got = LZ4Codec.EncodeBatchPacked(src, soff, slen, d1, o1, caps, level=LZ4Level(level))
+        for i in range(len(blocks)):
+            ok = got[i] == want[i] and (want[i] <= 0 or bytes(d1[int(o1[i]):int(o1[i]) + want[i]]) == bytes(d2[int(o2[i]):int(o2[i]) + want[i]]))
+            bad += check(f"hc{level}", r, i, ok, f"len {slen[i]} want {want[i]} got {got[i]}")
+    return bad, 8 * len(blocks)
+
+
+def envelopes_round(rng, oracle, r):
+    """hostile pickles: mutated / truncated envelopes through UnpickleBatch's kernels against oracle.unpickle (None = the reference
+    throws InvalidDataException)"""
+    from k4os.compression.lz4_amd import _native
+    bad = 0
+    msgs = [m for m in blocks_of(rng, 300, hi=70000) if m.size]
+    envs = []
+    for m in msgs:
+        e = bytearray(oracle.pickle(m, 0, int(rng.integers(0, 2))))
+        for _ in range(int(rng.integers(0, 3))): e[int(rng.integers(0, len(e)))] = int(rng.integers(0, 256))
+        if rng.random() < 0.1: e = e[:int(rng.integers(1, len(e) + 1))]
+        envs.append(bytes(e))
+    # batch form: one bad envelope fails the call as a whole in the reference's terms, so go one by one on a sample
+    for i in rng.permutation(len(envs))[:80]:
+        e = envs[int(i)]
+        want = oracle.unpickle(e)
+        try: got = bytes(LZ4Pickler.Unpickle(e))
+        except Exception: got = None
+        ok = (got is None and want is None) or (got is not None and want is not None and got == want)
+        bad += check("envelope", r, int(i), ok, f"len {len(e)}: oracle {'throws' if want is None else len(want)} here {'throws' if got is None else len(got)}")
+    return bad, 80
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -248,7 +343,8 @@ def main():
         for w in which:
             b, n = {"decode": lambda: decode_round(rng, oracle, r, False), "mutate": lambda: decode_round(rng, oracle, r, True),
                     "pickle": lambda: pickle_round(rng, oracle, r), "hc": lambda: hc_round(rng, oracle, r), "sizes": lambda: sizes_round(rng, oracle, r),
-                    "bigpickle": lambda: bigpickle_round(rng, oracle, r), "flags": lambda: flags_round(rng, oracle, r), "many": lambda: many_round(rng, oracle, r), "frames": lambda: frames_round(rng, oracle, r)}[w]()
+                    "bigpickle": lambda: bigpickle_round(rng, oracle, r), "flags": lambda: flags_round(rng, oracle, r), "many": lambda: many_round(rng, oracle, r), "frames": lambda: frames_round(rng, oracle, r), "partial": lambda: partial_round(rng, oracle, r),
+                    "dict": lambda: dict_round(rng, oracle, r), "hclevels": lambda: hclevels_round(rng, oracle, r), "envelopes": lambda: envelopes_round(rng, oracle, r)}[w]()
             bad += b; total += n
     print(f"seed {seed}: {rounds} rounds of {which}, {total} items, {bad} failures, {time.time() - t:.0f}s")
     sys.exit(1 if bad else 0)
