@@ -249,12 +249,26 @@ def partial_round(rng, oracle, r):
     src, soff, slen = pack_blocks(enc)
     wants = np.array([int(rng.choice([0, 1, rng.integers(0, b.size + 1), b.size, b.size + int(rng.integers(1, 100))])) for b in blocks], np.int32)
     d1, o1 = make_arena(wants + 32, fill=0xCD)
-    got = LZ4Codec.DecodeBatchPacked(src, soff, slen, d1, o1, wants, flags=FLAG_PARTIAL)
+    # (device buffers: some of the streams are mutated, and a hostile offset of 0 leaves target bytes as they were -- see decode_round)
+    import torch
+    from k4os.compression.lz4_amd.device import DeviceBatch, DeviceCodec
+    dc = DeviceCodec(0)
+    sb = DeviceBatch.from_host(src, soff, slen, dc.device)
+    db = DeviceBatch(torch.full((d1.size,), 0xCD, dtype=torch.uint8, device=dc.device), torch.from_numpy(o1.view(np.int64)).to(dc.device), torch.from_numpy(wants).to(dc.device))
+    got = dc.decode(sb, db, flags=FLAG_PARTIAL).cpu().numpy()
+    d1 = db.data.cpu().numpy()
     for i, b in enumerate(blocks):
         n, ref = oracle.decompress_partial(enc[i], int(wants[i]), int(wants[i]))
         n = -1 if n <= 0 else n
         a = int(o1[i])
-        ok = got[i] == n and (n <= 0 or bytes(d1[a:a + n]) == bytes(ref[:n])) and bool((d1[a + wants[i]:a + wants[i] + 16] == 0xCD).all())
+        same = n <= 0 or bytes(d1[a:a + n]) == bytes(ref[:n])
+        clean = bool((d1[a + wants[i]:a + wants[i] + 16] == 0xCD).all())
+        ok = got[i] == n and same and clean
+        if not ok and got[i] == n and n > 0:
+            x, y = d1[a:a + n], np.asarray(ref[:n]); dd = np.nonzero(x != y)[0]
+            print(f"   bytes same {same} slack clean {clean} differing {dd.size} first {dd[:6]} mutated {not np.array_equal(enc[i], np.frombuffer(oracle.encode(b), np.uint8))}")
+            os.makedirs(os.path.join(ROOT, "gpurun_out", "stress_fail"), exist_ok=True)
+            np.savez(os.path.join(ROOT, "gpurun_out", "stress_fail", f"partial_{r}_{i}.npz"), stream=enc[i], want=wants[i], gpu=d1[a:a + wants[i] + 16], ref=np.asarray(ref))
         bad += check("partial", r, i, ok, f"len {b.size} wanted {wants[i]} oracle {n} got {got[i]}")
     return bad, len(blocks)
 
