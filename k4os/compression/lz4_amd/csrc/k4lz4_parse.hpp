@@ -44,7 +44,11 @@ namespace k4 {
 #define K4_PARSE_K 1
 #endif
 
-constexpr uint32_t PARSE_REC_STRIDE = 16384u;        /* records per block: a block below LIMIT_64K has fewer than (65546 - 6) / 4 + 1 sequences */
+/* records per block.  A sequence is at least four bytes of match, the block's first byte and its last five are literals, so a block
+ * below LIMIT_64K has at most (65546 - 6) / 4 = 16 385 sequences -- on paper: that many would need nothing but 4-byte matches from
+ * the second byte on, and a match needs its bytes to have stood there before (the densest block the tests could build,
+ * tests/adversarial_blocks.py, has 10 500).  The slot holds the paper bound plus a round's worth, so nothing hangs on that argument. */
+constexpr uint32_t PARSE_REC_STRIDE = 16448u;
 constexpr uint32_t PARSE_MIN_LEN = 128u;             /* shorter blocks go to the other kernels (the clamped loads below want 16 readable bytes somewhere) */
 constexpr uint32_t PARSE_REST = 0xffffffffu;         /* meta[2 b]: this block is for k4_encode_fast_rest_kernel */
 constexpr int PARSE_MAX_WAVES = 16;                  /* waves (= blocks) per workgroup: one workgroup per CU */
