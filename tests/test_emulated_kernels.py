@@ -95,6 +95,15 @@ def test_encode_parse_emit_matches_oracle(emu, oracle, k, waves, how):
     assert (dst[mask] == 0xCD).all()
 
 
+def test_encode_parse_block_ends_randomised(emu, oracle):
+    """tests/tools/emu_stress_block_end.py, 4096 blocks: a long literal run with something matchable near the very end of the block --
+    where the search's 66-probe limit, its growing step and mflimitPlusOne meet (the round-5 fix; the code before it fails this seed)"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import emu_stress_block_end
+    assert emu_stress_block_end.run(4096, 3, oracle, emu) == 0
+
+
 def test_encode_parse_emit_limited_output_and_acceleration(emu, oracle):
     """output limits are the emit kernel's (LL64.fast.cs:251-255, :346-350, :471-476): cap == size succeeds, one less fails;
     another acceleration than 1 is not the parse kernel's case and comes out of the one-kernel encoder all the same"""
