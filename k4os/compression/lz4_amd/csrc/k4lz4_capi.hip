@@ -679,7 +679,11 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
                                     dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, a);
             break;
         case KIND_DECODE:
-            if (a.prof && ctx->prof_pair && !ctx->prof_stamp) {
+            if (a.prof && ctx->prof_pair && !ctx->prof_stamp && ctx->use_xdec) {
+                hipLaunchKernelGGL(k4::k4_decode_x_prof_kernel, dim3((unsigned)((cnt + k4::XPAIRS_PER_WG - 1) / k4::XPAIRS_PER_WG)),
+                                   dim3(128 * k4::XPAIRS_PER_WG), 0, stream, a);
+            }
+            else if (a.prof && ctx->prof_pair && !ctx->prof_stamp) {
                 hipLaunchKernelGGL(k4::k4_decode_pair_prof_kernel, dim3((unsigned)((cnt + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
                                    dim3(128 * k4::DECODE_PAIRS_PER_WG), 0, stream, a);
             }

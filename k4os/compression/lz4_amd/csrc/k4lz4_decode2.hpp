@@ -112,9 +112,12 @@ constexpr uint32_t XB_G = 1u << 9, XB_GENERAL = 1u << 11, XB_USABLE = 1u << 12;
  * PARSE (the pair's first wave).  Returns the block's result as LL64.LZ4_decompress_safe would: bytes written, or
  * -(input position) - 1.  The copier is told through the control words.
  */
-template <int W>
-__device__ __forceinline__ int xparse_block(const uint8_t *in, int src_size, int out_size, int lane, uint32_t *lds)
+template <int W, bool PROF = false>
+__device__ __forceinline__ int xparse_block(const uint8_t *in, int src_size, int out_size, int lane, uint32_t *lds, unsigned long long *pc = nullptr)
 {
+    unsigned long long c_room = 0, n_round = 0, n_scalar = 0, c_hyp = 0, c_dbl = 0, c_ent = 0, c_rules = 0, c_scalar = 0;
+    const unsigned long long t_begin = PROF ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
+    auto now = [&]() -> unsigned long long { return PROF ? (unsigned long long)__builtin_readcyclecounter() : 0ull; };
     uint32_t *pipe = lds + X_PIPE;
     uint4 *queue = (uint4 *)(lds + X_QUEUE);
     uint32_t *qout = lds + X_QOUT;
@@ -138,18 +141,31 @@ __device__ __forceinline__ int xparse_block(const uint8_t *in, int src_size, int
     auto room = [&](uint32_t n) -> bool {
         const uint32_t need = head + n + 1u;
         if (need - tail_seen <= (uint32_t)XQ) return true;
+        const unsigned long long t0 = now();
         tail_seen = xpipe_wait(pipe, 1, need - (uint32_t)XQ);
+        if (PROF) c_room += now() - t0;
         return tail_seen != 0xffffffffu;
     };
     /* the records up to `head` are complete and the output continues at `op`: tell the copier */
     auto publish = [&]() {
-        if (lane == 0) qout[head & XQ_MASK] = (uint32_t)op;
-        pipe_store(pipe + 0, head, lane);
+        lds_order();
+        if (lane == 0) {
+            qout[head & XQ_MASK] = (uint32_t)op;
+            xpipe_post(pipe + 0, head);
+        }
+        lds_order();
     };
     auto finish = [&](int result) -> int {
         publish();
-        if (lane == 0) pipe[3] = (uint32_t)result;
-        pipe_store(pipe + 2, 1u, lane);
+        if (lane == 0) {
+            pipe[3] = (uint32_t)result;
+            xpipe_post(pipe + 2, 1u);
+        }
+        lds_order();
+        if (PROF && pc && lane == 0) {
+            pc[0] = now() - t_begin; pc[1] = c_room; pc[2] = n_round; pc[3] = n_scalar; pc[4] = head; pc[5] = c_hyp; pc[6] = c_dbl; pc[7] = c_ent;
+            pc[11] = c_rules; pc[12] = c_scalar;
+        }
         return result;
     };
     /* LZ4_readVLE, a wave-full of bytes at a time: k4lz4_decode.hpp */
@@ -174,6 +190,8 @@ __device__ __forceinline__ int xparse_block(const uint8_t *in, int src_size, int
         bool scalar = true;
         if (ipu + (uint32_t)RUN_MASK + 1u < iendu) {       /* some hypothesis can be usable */
             K4_PHASE("x-hyp");
+            const unsigned long long tp0 = now();
+            if (PROF) n_round++;
             win.ensure_ahead<(64 * W + 384) / 4>(ipu + win.a0, lane);
             uint32_t A[W], B[W], Mlo[W], Mhi[W], J[W];
 #pragma unroll
@@ -206,6 +224,7 @@ __device__ __forceinline__ int xparse_block(const uint8_t *in, int src_size, int
                 J[k] = fast && nxt < 64u ? nxt : (uint32_t)lane;
             }
             K4_PHASE("x-double");
+            const unsigned long long tp1 = now();
             /* M(l) = the usable token lanes on l's chain inside its window, J(l) = the lane that chain ends on (a usable token whose
              * successor lies beyond the window, or one that is not usable): M |= M[J], J = J[J], five times -- a sequence is at
              * least 3 stream bytes, so a window holds at most 22 of them */
@@ -220,6 +239,7 @@ __device__ __forceinline__ int xparse_block(const uint8_t *in, int src_size, int
                 }
             }
             K4_PHASE("x-entries");
+            const unsigned long long tp2 = now();
             /* one hop per window: which lanes are real, where the chain goes on */
             uint32_t Tlo[W], Thi[W];
             uint32_t pos = 0;                               /* relative to ip: the next token */
@@ -238,6 +258,7 @@ __device__ __forceinline__ int xparse_block(const uint8_t *in, int src_size, int
                 }
             }
             K4_PHASE("x-rules");
+            const unsigned long long tp3 = now();
             uint32_t nmax = 0;
 #pragma unroll
             for (int k = 0; k < W; k++) nmax += (uint32_t)__popc(Tlo[k]) + (uint32_t)__popc(Thi[k]);
@@ -296,11 +317,14 @@ __device__ __forceinline__ int xparse_block(const uint8_t *in, int src_size, int
                 if (nrec) publish();
             }
             scalar = stop || nmax == 0u;
+            if (PROF) { const unsigned long long tp4 = now(); c_hyp += tp1 - tp0; c_dbl += tp2 - tp1; c_ent += tp3 - tp2; c_rules += tp4 - tp3; }
         }
         if (!scalar) continue;
 
         /* ---- scalar parser: one sequence, the reference's order of checks (k4lz4_decode.hpp, without the partial / dictionary arms) ---- */
         K4_PHASE("x-scalar");
+        const unsigned long long ts0 = now();
+        if (PROF) n_scalar++;
         int err = 0;
         uint32_t w = win.fetch((uint32_t)ip, lane);
         const uint32_t token = w & 0xffu;
@@ -372,15 +396,18 @@ __device__ __forceinline__ int xparse_block(const uint8_t *in, int src_size, int
         op += adv;
         if (last) return finish((int)op);
         publish();
+        if (PROF) c_scalar += now() - ts0;
     }
 }
 
 /*
  * COPY (the pair's second wave): the block's bytes, 64 at a time.  Returns the block's result (the parser's).
- * PD = how many windows the loads from global memory are issued ahead of their use.
+ * PD = how many windows the loads from global memory are issued ahead of their use: a window's look-up (A) and its completion (B)
+ * are PD steps apart, the windows in between wait in PD + 1 register slots that are addressed statically (the loop is unrolled
+ * PD + 1 times -- moving a slot's registers would wait for its load).
  */
-template <int PD>
-__device__ __forceinline__ int xcopy_block(const uint8_t *in, int src_size, uint8_t *out, int out_size, int lane, uint32_t *lds)
+template <int PD, bool PROF = false>
+__device__ __forceinline__ int xcopy_block(const uint8_t *in, int src_size, uint8_t *out, int out_size, int lane, uint32_t *lds, unsigned long long *pc = nullptr)
 {
     uint32_t *pipe = lds + X_PIPE;
     const uint4 *queue = (const uint4 *)(lds + X_QUEUE);
@@ -392,107 +419,117 @@ __device__ __forceinline__ int xcopy_block(const uint8_t *in, int src_size, uint
         if (xdecode_trivial(in, src_size, out_size, lane, &r)) return r;
     }
     constexpr uint32_t RESOLVED = 0xffffffffu;
-    uint32_t pv[PD + 1], ps[PD + 1], plim[PD + 1];          /* windows on their way: the byte, where it comes from if not loaded yet, how many bytes */
+    constexpr int NS = PD + 1;
+    uint32_t pv[NS], ps[NS], plim[NS];                      /* windows on their way: the byte, where it comes from if not loaded, how many bytes */
 #pragma unroll
-    for (int i = 0; i <= PD; i++) { pv[i] = 0u; ps[i] = RESOLVED; plim[i] = 0u; }
+    for (int i = 0; i < NS; i++) { pv[i] = 0u; ps[i] = RESOLVED; plim[i] = 0u; }
     uint32_t kcov = 0xffffffffu;                           /* index of the last record that begins below baseA */
     uint32_t baseA = 0, baseB = 0, F = 0;                  /* next window to look up / to finish; bytes below F are in memory */
     uint32_t head = 0, avail = 0;                          /* records published as last seen, and the output position they reach */
-    bool done = false, more = true;
+    bool done = false, more = true, go = true;
     int result = 0;
-    uint32_t inflight = 0;
+    uint32_t inflight = 0, spin = 0;
+    unsigned long long c_wait = 0, n_win = 0, n_poll = 0, n_inw = 0, n_idle = 0;
+    const unsigned long long t_begin = PROF ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
 
-    while (more || inflight) {
-        /* ---------------- A: records and sources of window [baseA, baseA + 64) ---------------- */
-        uint32_t lim = 0;
-        if (more) {
-            uint32_t spin = 0;
-            while (!done && avail < baseA + 64u) {
-                const uint32_t d = pipe_load(pipe + 2);
-                head = pipe_load(pipe + 0);
-                avail = uni(qout[head & XQ_MASK]);
-                if (d) {
-                    done = true;
-                    result = (int)uni(pipe[3]);
-                } else if (avail < baseA + 64u) {
-                    if (inflight) break;                    /* finish an older window meanwhile */
-                    if (++spin >= PIPE_SPIN_MAX) {
-                        dev_status_raise((uint32_t *)(uintptr_t)((unsigned long long)pipe[6] | ((unsigned long long)pipe[7] << 32)), (uint32_t)DEV_STATUS_PIPE_TIMEOUT);
-                        return PIPE_TIMEOUT;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            if (done && result < 0) return result;          /* (what a failed block leaves in its slot is not defined) */
-            if (avail >= baseA + 64u) lim = 64u;
-            else if (done) { lim = avail - baseA; more = false; }
-        }
-        if (lim != 0u) {
-            K4_PHASE("x-copy-a");
-            const uint32_t p = baseA + (uint32_t)lane;
-            if (lane < 16) ((uint32_t *)flags)[lane] = 0u;
-            lds_order();
-            const uint32_t ci = kcov + 1u + (uint32_t)lane;
-            const bool cv = (int32_t)(head - ci) > 0;
-            const uint32_t co = cv ? qout[ci & XQ_MASK] - baseA : 64u;
-            if (co < 64u) flags[co] = 1;
-            lds_order();
-            const unsigned long long S = ballot(flags[lane] != 0);
-            const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(S >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)S, 0u)) + (uint32_t)((S >> lane) & 1ull);
-            const uint4 rec = queue[(kcov + r) & XQ_MASK];
-            kcov += (uint32_t)__popcll(S);
-            lds_order();
-            /* the records below kcov are not looked at again */
-            if (lane == 0) xpipe_post(pipe + 1, kcov == 0xffffffffu ? 0u : kcov);
-            const uint32_t rel = p - rec.x;
-            const bool valid = (uint32_t)lane < lim;
-            const bool lit = rel < rec.z;
-            const uint32_t src = p - rec.w;
-            const bool far = !lit && (src < F || rec.w == 0u);                 /* offset 0: the byte that is there already */
-            uint32_t val = 0u, from = RESOLVED;
-            if (valid) {
-                if (lit) val = in[rec.y + rel];
-                else if (far) val = out[src];
-                else from = src;
-            }
-            pv[PD] = val; ps[PD] = from; plim[PD] = lim;
-            baseA += 64u;
-            inflight++;
-        }
-        /* ---------------- B: the oldest window on its way ---------------- */
-        if (plim[0] != 0u) {
-            K4_PHASE("x-copy-b");
-            uint32_t val = pv[0];
-            const uint32_t src = ps[0];
-            const bool valid = (uint32_t)lane < plim[0];
-            const bool inw = src != RESOLVED && src >= baseB;
-            if (src != RESOLVED && !inw) val = hist[src & (uint32_t)(XHIST - 1)];
-            if (ballot(inw)) {
-                /* sources inside the window: follow them to a lane that has its byte */
-                uint32_t ptr = inw ? src - baseB : (uint32_t)lane;
-                for (int it = 0; it < 6; it++) {
-                    const uint32_t nx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ptr << 2), (int)ptr);
-                    const bool same = nx == ptr;
-                    ptr = nx;
-                    if (!ballot(!same)) break;
-                }
-                val = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ptr << 2), (int)val);
-            }
-            if (valid) hist[(baseB + (uint32_t)lane) & (uint32_t)(XHIST - 1)] = (uint8_t)val;
-            baseB += plim[0];
-            inflight--;
-            lds_order();
-            while (baseB - F >= (uint32_t)XFLUSH) {
-                const uint4 v = *(const uint4 *)(hist + ((F + 16u * (uint32_t)lane) & (uint32_t)(XHIST - 1)));
-                U128u o;
-                o.v[0] = v.x; o.v[1] = v.y; o.v[2] = v.z; o.v[3] = v.w;
-                st128u(out + F + 16u * (uint32_t)lane, o);
-                F += (uint32_t)XFLUSH;
-            }
-        }
+    while (go) {
 #pragma unroll
-        for (int i = 0; i < PD; i++) { pv[i] = pv[i + 1]; ps[i] = ps[i + 1]; plim[i] = plim[i + 1]; }
-        plim[PD] = 0u; ps[PD] = RESOLVED;
+        for (int j = 0; j < NS; j++) {
+            if (!(more || inflight)) { go = false; break; }
+            const int sa = j, sb = (j + 1) % NS;
+            /* ---------------- A: records and sources of window [baseA, baseA + 64) ---------------- */
+            uint32_t lim = 0;
+            if (more) {
+                const unsigned long long tw = PROF ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
+                while (!done && avail < baseA + 64u) {
+                    const uint32_t d = pipe_load(pipe + 2);
+                    head = pipe_load(pipe + 0);
+                    avail = uni(qout[head & XQ_MASK]);
+                    if (PROF) n_poll++;
+                    if (d) {
+                        done = true;
+                        result = (int)uni(pipe[3]);
+                    } else if (avail < baseA + 64u) {
+                        if (inflight) break;                /* finish an older window meanwhile */
+                        if (++spin >= PIPE_SPIN_MAX) {
+                            dev_status_raise((uint32_t *)(uintptr_t)((unsigned long long)pipe[6] | ((unsigned long long)pipe[7] << 32)), (uint32_t)DEV_STATUS_PIPE_TIMEOUT);
+                            return PIPE_TIMEOUT;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                if (PROF) c_wait += (unsigned long long)__builtin_readcyclecounter() - tw;
+                if (done && result < 0) return result;      /* (what a failed block leaves in its slot is not defined) */
+                if (avail >= baseA + 64u) lim = 64u;
+                else if (done) { lim = avail - baseA; more = false; }
+            }
+            if (lim != 0u) {
+                K4_PHASE("x-copy-a");
+                spin = 0;
+                const uint32_t p = baseA + (uint32_t)lane;
+                if (lane < 16) ((uint32_t *)flags)[lane] = 0u;
+                lds_order();
+                const uint32_t ci = kcov + 1u + (uint32_t)lane;
+                const bool cv = (int32_t)(head - ci) > 0;
+                const uint32_t co = cv ? qout[ci & XQ_MASK] - baseA : 64u;
+                if (co < 64u) flags[co] = 1;
+                lds_order();
+                const unsigned long long S = ballot(flags[lane] != 0);
+                const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(S >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)S, 0u)) + (uint32_t)((S >> lane) & 1ull);
+                const uint4 rec = queue[(kcov + r) & XQ_MASK];
+                kcov += (uint32_t)__popcll(S);
+                lds_order();
+                /* the records below kcov are not looked at again */
+                if (lane == 0) xpipe_post(pipe + 1, kcov == 0xffffffffu ? 0u : kcov);
+                const uint32_t rel = p - rec.x;
+                const bool valid = (uint32_t)lane < lim;
+                const bool lit = rel < rec.z;
+                const uint32_t src = p - rec.w;
+                const bool far = !lit && (src < F || rec.w == 0u);             /* offset 0: the byte that is there already */
+                /* one load for the whole window: literals from the stream, old match sources from the output, the other lanes
+                 * a byte that is not used (the first of the output) */
+                const uint8_t *g = (valid && lit) ? in + (rec.y + rel) : out + ((valid && far) ? src : 0u);
+                pv[sa] = (uint32_t)*g;
+                ps[sa] = (valid && !lit && !far) ? src : RESOLVED;
+                plim[sa] = lim;
+                baseA += 64u;
+                inflight++;
+                if (PROF) n_win++;
+            } else if (PROF) n_idle++;
+            /* ---------------- B: the oldest window on its way ---------------- */
+            if (plim[sb] != 0u) {
+                K4_PHASE("x-copy-b");
+                uint32_t val = pv[sb];
+                const uint32_t src = ps[sb];
+                const bool valid = (uint32_t)lane < plim[sb];
+                const bool inw = src != RESOLVED && src >= baseB;
+                if (src != RESOLVED && !inw) val = hist[src & (uint32_t)(XHIST - 1)];
+                if (ballot(inw)) {
+                    /* sources inside the window: follow them to a lane that has its byte */
+                    uint32_t ptr = inw ? src - baseB : (uint32_t)lane;
+                    for (int it = 0; it < 6; it++) {
+                        const uint32_t nx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ptr << 2), (int)ptr);
+                        const bool same = nx == ptr;
+                        ptr = nx;
+                        if (!ballot(!same)) break;
+                    }
+                    val = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ptr << 2), (int)val);
+                    if (PROF) n_inw++;
+                }
+                if (valid) hist[(baseB + (uint32_t)lane) & (uint32_t)(XHIST - 1)] = (uint8_t)val;
+                baseB += plim[sb];
+                plim[sb] = 0u;
+                inflight--;
+                lds_order();
+                while (baseB - F >= (uint32_t)XFLUSH) {
+                    const uint4 v = *(const uint4 *)(hist + ((F + 16u * (uint32_t)lane) & (uint32_t)(XHIST - 1)));
+                    U128u o;
+                    o.v[0] = v.x; o.v[1] = v.y; o.v[2] = v.z; o.v[3] = v.w;
+                    st128u(out + F + 16u * (uint32_t)lane, o);
+                    F += (uint32_t)XFLUSH;
+                }
+            }
+        }
     }
     /* what is left in the ring: 16 bytes per lane, then the last bytes one by one */
     {
@@ -505,6 +542,9 @@ __device__ __forceinline__ int xcopy_block(const uint8_t *in, int src_size, uint
         }
         const uint32_t t0 = n & ~15u;
         if ((uint32_t)lane < (n & 15u)) out[F + t0 + (uint32_t)lane] = hist[(F + t0 + (uint32_t)lane) & (uint32_t)(XHIST - 1)];
+    }
+    if (PROF && pc && lane == 0) {
+        pc[0] = (unsigned long long)__builtin_readcyclecounter() - t_begin; pc[1] = c_wait; pc[2] = n_win; pc[3] = n_poll; pc[4] = n_inw; pc[5] = n_idle;
     }
     return result;
 }
@@ -547,6 +587,34 @@ __global__ __launch_bounds__(128 * XPAIRS_PER_WG) __attribute__((amdgpu_waves_pe
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[XPAIRS_PER_WG][X_PAIR_DWORDS];
     xdecode_kernel_body(a, lds);
+}
+
+/* diagnostic twin: 32 cycle / event counters per block, the parsing wave's in [0, 16), the copying wave's in [16, 32) (scripts/x_probe.py) */
+__global__ __launch_bounds__(128 * XPAIRS_PER_WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k4_decode_x_prof_kernel(BatchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[XPAIRS_PER_WG][X_PAIR_DWORDS];
+    const int lane = lane_id();
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t pair = wave >> 1, role = (wave ^ blockIdx.x) & 1u;
+    const long long b = (long long)blockIdx.x * XPAIRS_PER_WG + (long long)pair;
+    uint32_t *mine = lds[pair];
+    if (role == 0) {
+        pipe_init(mine + X_PIPE, a.status, lane);
+        if (lane == 0) mine[X_QOUT] = 0u;
+    }
+    __syncthreads();
+    if (b >= a.n) return;
+    const int src_len = a.srcLen[b];
+    const int cap = a.dstCap[b];
+    const uint8_t *in = a.src + a.srcOff[b];
+    uint8_t *out = a.dst + a.dstOff[b];
+    if (src_len <= 0) return;
+    if (role == 0) {
+        xparse_block<K4_X_WINDOWS, true>(in, src_len, cap < 0 ? 0 : cap, lane, mine, a.prof + 2 * PROF_STRIDE * b);
+    } else {
+        const int ret = xcopy_block<K4_X_DEPTH, true>(in, src_len, out, cap < 0 ? 0 : cap, lane, mine, a.prof + 2 * PROF_STRIDE * b + PROF_STRIDE);
+        if (lane == 0) a.outLen[b] = codec_decode_result(src_len, ret, a.flags);
+    }
 }
 
 }  // namespace k4
