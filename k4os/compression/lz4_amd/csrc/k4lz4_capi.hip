@@ -28,7 +28,6 @@
 
 #include "../../../../include/k4lz4.h"
 #include "k4lz4_decode.hpp"
-#include "k4lz4_decode2.hpp"
 #include "k4lz4_encode_fast.hpp"
 #include "k4lz4_parse.hpp"
 #include "k4lz4_pickle.hpp"
@@ -102,7 +101,6 @@ struct k4lz4_ctx {
     uint32_t *d_status = nullptr;   /* this context's status word: DEV_STATUS_* bits raised by its kernels (k4lz4_common.hpp) */
     int split_pct = -1;
     bool no_pair = false;
-    bool use_xdec = true;                 /* K4LZ4_NO_XDEC: plain decode batches of up to 16 blocks per CU through the first-generation pair kernel */
     int direct_span_pct = 200;            /* K4LZ4_DIRECT_SPAN_PCT: a registered source goes up as it lies while its span is at most this share of its blocks' bytes */
     bool no_direct = false;               /* K4LZ4_NO_DIRECT: registered host memory is staged like any other */
     int lds_floor_per_cu = 8;             /* K4LZ4_LDS_FLOOR: blocks per CU the LDS-table kernel gets at least */
@@ -679,23 +677,13 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
                                     dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, a);
             break;
         case KIND_DECODE:
-            if (a.prof && ctx->prof_pair && !ctx->prof_stamp && ctx->use_xdec) {
-                hipLaunchKernelGGL(k4::k4_decode_x_prof_kernel, dim3((unsigned)((cnt + k4::XPAIRS_PER_WG - 1) / k4::XPAIRS_PER_WG)),
-                                   dim3(128 * k4::XPAIRS_PER_WG), 0, stream, a);
-            }
-            else if (a.prof && ctx->prof_pair && !ctx->prof_stamp) {
+            if (a.prof && ctx->prof_pair && !ctx->prof_stamp) {
                 hipLaunchKernelGGL(k4::k4_decode_pair_prof_kernel, dim3((unsigned)((cnt + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
                                    dim3(128 * k4::DECODE_PAIRS_PER_WG), 0, stream, a);
             }
             else if (a.prof && !ctx->prof_stamp) hipLaunchKernelGGL(k4::k4_decode_prof_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
             else if (cnt > 24 * (int64_t)ctx->cu_count)   /* more blocks than can be resident (6 waves x 4 SIMDs per CU) */
                 hipLaunchKernelGGL(k4::k4_decode_dense_kernel, dim3(wg4), dim3(64 * k4::DECODE_WAVES_PER_WG), 0, stream, a);
-            else if (cnt <= 16 * (int64_t)ctx->cu_count && !ctx->no_pair && ctx->use_xdec && !a.dict && !(flags & K4LZ4_FLAG_PARTIAL)) {
-                /* two waves per block, second generation (k4lz4_decode2.hpp): window parser + byte-parallel copier; plain
-                 * LZ4_decompress_safe only */
-                hipLaunchKernelGGL(k4::k4_decode_x_kernel, dim3((unsigned)((cnt + k4::XPAIRS_PER_WG - 1) / k4::XPAIRS_PER_WG)),
-                                   dim3(128 * k4::XPAIRS_PER_WG), 0, stream, a);
-            }
             else if (cnt <= 16 * (int64_t)ctx->cu_count && !ctx->no_pair) {
                 /* at most half the chip's wave slots (8 per SIMD at 64 VGPRs) are needed: two waves per block, one
                  * parsing ahead of the one that copies */
@@ -1363,7 +1351,6 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->dlq, hipStreamNonBlocking);
     if (const char *pct = getenv("K4LZ4_SPLIT_PCT")) { const int v = atoi(pct); ctx->split_pct = v < 1 ? 1 : (v > 100 ? 100 : v); }
     ctx->no_pair = getenv("K4LZ4_NO_PAIR") != nullptr;
-    ctx->use_xdec = getenv("K4LZ4_NO_XDEC") == nullptr;
     ctx->prof_gtab = getenv("K4LZ4_PROF_GTAB") != nullptr;
     ctx->use_pace = getenv("K4LZ4_NO_PACE") == nullptr;
     if (const char *e = getenv("K4LZ4_PACE_MIN")) ctx->pace_min_per_cu = std::max(0, atoi(e));

@@ -498,33 +498,6 @@ struct StreamRing {
         }
     }
 
-    /* the same with the look-ahead as a parameter: [q, q + 4 AH) readable where the stream has it (AH <= 192 dwords, so that q's
-     * own dword stays in the ring); after a far jump the ring restarts AND is filled up to there (k4lz4_decode2.hpp) */
-    template <uint32_t AH>
-    __device__ __forceinline__ void ensure_ahead(uint32_t q, int lane)
-    {
-        static_assert(AH <= 192u, "ring of 256 dwords");
-        const uint32_t d = q >> 2;
-        if (d + 24u > rhi + 64u) {
-            wave_sync();
-            rhi = d & ~63u;
-            rlo = rhi;
-            ring[(rhi + (uint32_t)lane) & (RING_DWORDS - 1)] = load(rhi + (uint32_t)lane);
-            ring[(rhi + 64u + (uint32_t)lane) & (RING_DWORDS - 1)] = load(rhi + 64u + (uint32_t)lane);
-            rhi += 128u;
-            pf = load(rhi + (uint32_t)lane);
-            wave_sync();
-        }
-        while (rhi < d + AH && rhi < ndw + 64u) {
-            wave_sync();
-            ring[(rhi + (uint32_t)lane) & (RING_DWORDS - 1)] = pf;
-            rhi += 64u;
-            if (rhi - rlo > (uint32_t)RING_DWORDS) rlo = rhi - (uint32_t)RING_DWORDS;
-            pf = load(rhi + (uint32_t)lane);
-            wave_sync();
-        }
-    }
-
     /* encoder use: keep [qlo, q + 512) readable where the stream has it; after a far jump the ring
      * restarts at qlo.  Aligned byte positions. */
     __device__ __forceinline__ void ensure_from(uint32_t qlo, uint32_t q, int lane)

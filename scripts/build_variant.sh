@@ -9,7 +9,7 @@ import re
 txt=open('/tmp/w/bv_$NAME/remarks.txt').read()
 for b in re.split(r'(?=remark: [^\n]*Function Name)', txt):
     m=re.search(r'Function Name: (\S+)', b)
-    if not m or not re.search(r'encode_fast_kernel|encode_fast_gtab|decode_pair_kernel|decode_x|pickle_kernel|hc_parse_kernel', m[1]): continue
+    if not m or not re.search(r'encode_fast_kernel|encode_fast_gtab|decode_pair_kernel|pickle_kernel|hc_parse_kernel', m[1]): continue
     g=lambda k: (re.search(k+r': (\d+)', b) or [None,'?'])[1]
     print('$NAME %-44s SGPR %s VGPR %s scratch %s occ %s sspill %s'%(m[1][6:50], g('TotalSGPRs'), g(' VGPRs'), g(r'ScratchSize \[bytes/lane\]'), g(r'Occupancy \[waves/SIMD\]'), g('SGPRs Spill')))
 if 'error' in txt: print(txt[-3000:])

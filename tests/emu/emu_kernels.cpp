@@ -2,7 +2,6 @@
  * emulator and exposes them with the same batch shape as the C-ABI.  Test infrastructure only. */
 #include "hip/hip_runtime.h"
 #include "k4lz4_decode.hpp"
-#include "k4lz4_decode2.hpp"
 #include "k4lz4_encode_fast.hpp"
 #include "k4lz4_parse.hpp"
 #include "k4lz4_pickle.hpp"
@@ -36,19 +35,6 @@ int k4emu_decode_pair_batch(const uint8_t *src, const uint64_t *srcOff, const in
     if (n <= 0) return 0;
     unsigned grid = (unsigned)((n + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG);
     k4emu::launch_fn(dim3(grid), dim3(128 * k4::DECODE_PAIRS_PER_WG), [=] { k4::k4_decode_pair_kernel(a); }, threads);
-    return 0;
-}
-
-/* the second-generation pair decoder (k4lz4_decode2.hpp): window parser + byte-parallel copier */
-int k4emu_decode_x_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
-                         const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int flags, int threads)
-{
-    k4::BatchArgs a{};
-    a.src = src; a.srcOff = srcOff; a.srcLen = srcLen; a.dst = dst; a.dstOff = dstOff; a.dstCap = dstCap;
-    a.outLen = outLen; a.n = n; a.accel = 1; a.flags = flags;
-    if (n <= 0) return 0;
-    unsigned grid = (unsigned)((n + k4::XPAIRS_PER_WG - 1) / k4::XPAIRS_PER_WG);
-    k4emu::launch_fn(dim3(grid), dim3(128 * k4::XPAIRS_PER_WG), [=] { k4::k4_decode_x_kernel(a); }, threads);
     return 0;
 }
 

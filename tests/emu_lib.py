@@ -68,8 +68,6 @@ class Emu:
         self.lib.k4emu_decode_dict_batch.argtypes = b + [C.c_int, _u8p, C.c_void_p, C.c_void_p, C.c_int]
         self.lib.k4emu_decode_pair_batch.argtypes = b + [C.c_int, _u8p, C.c_void_p, C.c_void_p, C.c_int]
         self.pair = False      # True: decode_batch / decode_dict_batch run the two-waves-per-block kernel
-        self.lib.k4emu_decode_x_batch.argtypes = b + [C.c_int, C.c_int]
-        self.x = False         # True: decode_batch runs the second-generation pair kernel (k4lz4_decode2.hpp)
         self.lib.k4emu_xxh32_batch.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_uint32, C.c_int]
         self.lib.k4emu_allow_copy.argtypes = b + [C.c_int]
         self.lib.k4emu_decode_chain_batch.argtypes = [_u8p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _u8p,
@@ -88,11 +86,6 @@ class Emu:
 
     def decode_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, flags=0, threads=0):
         out = np.full(len(src_len), -12345, dtype=np.int32)
-        if self.x and not (flags & 32):
-            rc = self.lib.k4emu_decode_x_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
-                                               dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data, len(src_len), flags, threads)
-            assert rc == 0
-            return out
         if self.pair:
             rc = self.lib.k4emu_decode_pair_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst),
                                                   dst_off.ctypes.data, dst_cap.ctypes.data, out.ctypes.data, len(src_len),

@@ -686,25 +686,6 @@ def test_pair_kernel_passes_the_decoder_tests(case, emu_pair, oracle):
     case(emu_pair, oracle)
 
 
-@pytest.fixture()
-def emu_x(emu):
-    """decode routed to k4_decode_x_kernel (k4lz4_decode2.hpp: window parser + byte-parallel copier); the partial and the
-    dictionary arms stay with the first generation, as in the launcher"""
-    emu.x = True
-    yield emu
-    emu.x = False
-
-
-@pytest.mark.parametrize("case", [test_decode_matches_oracle_and_guards, test_decode_golden_issue64,
-                                  test_decode_malformed_parity_with_oracle, test_decode_special_cases,
-                                  test_decode_all_classes_various_sizes, test_decode_hostile_streams_random,
-                                  test_decode_random_stress],
-                         ids=lambda f: f.__name__)
-def test_window_parser_kernel_passes_the_decoder_tests(case, emu_x, oracle):
-    """every plain-decode test above, run once more through the second-generation pair kernel"""
-    case(emu_x, oracle)
-
-
 @pytest.mark.parametrize("mode", [0, 1], ids=["lane_copy32", "lane_move32_slack"])
 def test_lane_run_copies_every_length_and_alignment(emu, mode):
     """k4lz4_common.hpp LaneRun / lane_move32_slack: chunks plus an overlapping last word, no byte tails -- every length
@@ -753,9 +734,8 @@ def test_staged_batches_hold_long_and_overlapping_copies(emu, oracle):
     # a hand-made stream with an offset of 0: 8 literals, "match" of 6 bytes at offset 0, then ordinary sequences
     hostile = bytes([0x82]) + b"ABCDEFGH" + bytes([0, 0]) + bytes([0x21]) + b"ij" + bytes([8, 0]) + bytes([0xC0]) + b"123456789012"
     comp.append(np.frombuffer(hostile, np.uint8))
-    for pair in (False, True, "x"):
-        emu.pair = pair is True
-        emu.x = pair == "x"
+    for pair in (False, True):
+        emu.pair = pair
         src, soff, slen = pack(comp)
         caps = [b.size for b in blocks] + [64]
         dst, doff, dcap = arena(caps)
@@ -767,7 +747,6 @@ def test_staged_batches_hold_long_and_overlapping_copies(emu, oracle):
         got = dst[int(doff[-1]):int(doff[-1]) + n]
         assert got[:8].tobytes() == b"ABCDEFGH" and (got[8:14] == 0xCD).all() and got[14:].tobytes() == ref[14:n].tobytes()
     emu.pair = False
-    emu.x = False
     mask = np.ones(dst.size, bool)
     for i in range(len(caps)):
         mask[int(doff[i]):int(doff[i]) + caps[i]] = False
