@@ -114,6 +114,7 @@ struct k4lz4_ctx {
     uint8_t *d_parse = nullptr; size_t d_parse_cap = 0;       /* two-kernel fast encoder (k4lz4_parse.hpp): records, per-block counts, tables of the waves without an LDS table */
     bool use_parse = true;                /* K4LZ4_NO_PARSE: fast-level batches go to the one-kernel encoders as before */
     bool parse_queue = false;             /* K4LZ4_PARSE_QUEUE */
+    bool parse_persist = true;            /* K4LZ4_NO_PERSIST: batches beyond one residency in launches of one residency each (round 5) instead of one persistent launch */
     bool parse_inline_emit = true;        /* K4LZ4_NO_INLINE_EMIT: the blocks' bytes by k4_emit_kernel behind the parse instead of by the parsing waves themselves */
     bool parse_migrate = true;            /* K4LZ4_NO_MIGRATE: blocks whose table lives in memory stay there (k4lz4_parse.hpp, ParseCtl) */
     bool parse_pcost = false;             /* K4LZ4_PCOST: the parse's own cost estimate (k4_pcost_kernel) orders the blocks; measured: costs more than it gains */
@@ -384,25 +385,30 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
                  hipStream_t stream, const DictArgs *dd, const int32_t *hostLen)
 {
     int64_t chunk_max = 1 << 24;   /* blocks per launch (grid.x * blockDim.x must stay < 2^32) */
+#ifdef K4_PARSE_PROF
+    const bool parse_prof_ok = true;
+#else
+    const bool parse_prof_ok = false;
+#endif
     const bool encode_like = kind == KIND_ENCODE || kind == KIND_PICKLE;
     /* Fast-level LZ4Codec.Encode batches beyond what is resident at once (16 blocks per CU: 8 LDS-table + 8 global-table waves)
      * go in equal parts of at most that: a block takes its ~3.5 ms whatever the batch, so the rate is highest when every launch
      * is one full residency -- 8192 x 64 KiB in one launch 55 GiB/s (the LDS-table kernel runs two passes, the other one is long
      * done), as two launches of 4096 the bench batch's 63.  Not for batches that may be ragged (pickles, K4LZ4_FLAG_SEGMENTS):
      * those need their one cost-ordered launch. */
+    const bool parse_path = kind == KIND_ENCODE && level < K4LZ4_L03_HC && ctx->use_parse && ctx->accel == 1 && (!ctx->prof || parse_prof_ok || ctx->prof_stamp) &&
+                            !(flags & (FLAG_SEGMENTS_OK | K4LZ4_FLAG_SEGMENTS | K4LZ4_FLAG_NO_SPLIT));
+    /* round 6: the two-step encoder takes a batch beyond one residency in ONE persistent launch -- one workgroup of sixteen waves per
+     * CU, every wave takes the next block of the cost order when it is done with one (the waves with LDS tables from the expensive
+     * end, the others from the cheap end), records in per-wave slots -- instead of launches of one residency each with their own tail */
+    const bool parse_persistent = parse_path && ctx->parse_persist && ctx->parse_inline_emit && !ctx->prof && n > (int64_t)k4::PARSE_MAX_WAVES * (int64_t)ctx->cu_count &&
+                                  !(flags & K4LZ4_FLAG_NO_REORDER);
     if (kind == KIND_ENCODE && level < K4LZ4_L03_HC && !(flags & (FLAG_SEGMENTS_OK | K4LZ4_FLAG_SEGMENTS | K4LZ4_FLAG_NO_SPLIT)) &&
-        ctx->split_pct <= 0 && !ctx->prof && n > 16 * (int64_t)ctx->cu_count) {
+        ctx->split_pct <= 0 && !ctx->prof && n > 16 * (int64_t)ctx->cu_count && !parse_persistent) {
         const int64_t parts = (n + 16 * (int64_t)ctx->cu_count - 1) / (16 * (int64_t)ctx->cu_count);
         chunk_max = (n + parts - 1) / parts;
     }
-#ifdef K4_PARSE_PROF
-    const bool parse_prof_ok = true;
-#else
-    const bool parse_prof_ok = false;
-#endif
-    const bool parse_path = kind == KIND_ENCODE && level < K4LZ4_L03_HC && ctx->use_parse && ctx->accel == 1 && (!ctx->prof || parse_prof_ok || ctx->prof_stamp) &&
-                            !(flags & (FLAG_SEGMENTS_OK | K4LZ4_FLAG_SEGMENTS | K4LZ4_FLAG_NO_SPLIT));
-    if (parse_path) chunk_max = std::min<int64_t>(chunk_max, (int64_t)k4::PARSE_MAX_WAVES * (int64_t)ctx->cu_count);      /* (its scratch is 128 KiB per block) */
+    if (parse_path && !parse_persistent) chunk_max = std::min<int64_t>(chunk_max, (int64_t)k4::PARSE_MAX_WAVES * (int64_t)ctx->cu_count);      /* (one residency) */
     if (encode_like && level >= K4LZ4_L03_HC) {
         const int rc = launch_hc(ctx, kind == KIND_PICKLE, src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, stream, hostLen);
         if (rc != K4LZ4_OK || kind != KIND_ENCODE || !(flags & K4LZ4_FLAG_ALLOW_COPY)) return rc;
@@ -571,9 +577,12 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
         if (kind == KIND_ENCODE && parse_path) {
             const int64_t waves = std::max<int64_t>(1, std::min<int64_t>(ctx->parse_waves, (cnt + ctx->cu_count - 1) / ctx->cu_count));
             /* K4LZ4_PARSE_QUEUE: one workgroup per CU at most, every wave takes the next block of the cost order when it is done with one */
-            const bool queue = ctx->parse_queue && a.order && cnt > waves * (int64_t)ctx->cu_count;
+            const bool queue = (ctx->parse_queue || parse_persistent) && a.order && cnt > waves * (int64_t)ctx->cu_count;
             const int64_t nwg = queue ? (int64_t)ctx->cu_count : (cnt + waves - 1) / waves;
-            const size_t o_meta = (size_t)cnt * k4::PARSE_REC_STRIDE * sizeof(uint2), o_gtab = (o_meta + (size_t)cnt * 8 + 64 + 255) & ~(size_t)255;
+            /* records: a slot per wave of the launch where the parsing waves write their blocks out themselves, else one per block */
+            const bool slot_recs = ctx->parse_inline_emit;
+            const size_t rec_slots = slot_recs ? (size_t)nwg * (size_t)waves : (size_t)cnt;
+            const size_t o_meta = rec_slots * k4::PARSE_REC_STRIDE * sizeof(uint2), o_gtab = (o_meta + (size_t)cnt * 8 + 64 + 255) & ~(size_t)255;
             const size_t need = o_gtab + (waves > k4::PARSE_LDS_TABLES ? (size_t)nwg * k4::PARSE_MAX_WAVES * 16384 : 0);
             if (need > ctx->d_parse_cap) K4_HIP(ctx, hipStreamSynchronize(stream));
             const int rcp = grow(ctx, &ctx->d_parse, &ctx->d_parse_cap, need, false);
@@ -582,6 +591,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             pa.recs = (uint2 *)ctx->d_parse; pa.meta = (uint32_t *)(ctx->d_parse + o_meta); pa.gtab = (uint32_t *)(ctx->d_parse + o_gtab);
             pa.nwg = (uint32_t)nwg;
             pa.inline_emit = ctx->parse_inline_emit ? 1u : 0u;
+            pa.slot_recs = slot_recs ? 1u : 0u;
             pa.migrate = ctx->parse_migrate ? 1u : 0u;
             if (queue) {
                 pa.queue = pa.meta + 2 * cnt;
@@ -1373,6 +1383,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (const char *e = getenv("K4LZ4_STAGE_THREADS")) ctx->stage_threads = std::max(0, std::min(63, atoi(e) - 1));
     ctx->use_parse = getenv("K4LZ4_NO_PARSE") == nullptr;
     ctx->parse_queue = getenv("K4LZ4_PARSE_QUEUE") != nullptr;
+    ctx->parse_persist = getenv("K4LZ4_NO_PERSIST") == nullptr;
     ctx->parse_pcost = getenv("K4LZ4_PCOST") != nullptr;
     ctx->parse_migrate = getenv("K4LZ4_NO_MIGRATE") == nullptr;
     ctx->parse_inline_emit = getenv("K4LZ4_NO_INLINE_EMIT") == nullptr;

@@ -79,6 +79,44 @@ __device__ __forceinline__ uint64_t ld64u(const uint8_t *p) { return ((const U64
 __device__ __forceinline__ U128u ld128u(const uint8_t *p) { return *(const U128u *)p; }
 __device__ __forceinline__ void st128u(uint8_t *p, U128u v) { *(U128u *)p = v; }
 
+/* write-once / read-once data (the two-step encoder's records, the encoded bytes) with the non-temporal hint, so that they do not
+ * push the source lines the candidate fetches come back for out of the L2 and the Infinity Cache (K4_NT_RECS / K4_NT_OUT: A/B builds) */
+typedef uint64_t __attribute__((aligned(1))) k4_u64u;
+typedef uint32_t __attribute__((aligned(1))) k4_u32u;
+typedef uint16_t __attribute__((aligned(1))) k4_u16u;
+__device__ __forceinline__ void st64u_out(uint8_t *p, uint64_t v)
+{
+#if defined(K4_NT_OUT) && !defined(K4_HOST_EMU)
+    __builtin_nontemporal_store(v, (k4_u64u *)p);
+#else
+    ((U64u *)p)->v = v;
+#endif
+}
+__device__ __forceinline__ void st32u_out(uint8_t *p, uint32_t v)
+{
+#if defined(K4_NT_OUT) && !defined(K4_HOST_EMU)
+    __builtin_nontemporal_store(v, (k4_u32u *)p);
+#else
+    ((U32u *)p)->v = v;
+#endif
+}
+__device__ __forceinline__ void st16u_out(uint8_t *p, uint16_t v)
+{
+#if defined(K4_NT_OUT) && !defined(K4_HOST_EMU)
+    __builtin_nontemporal_store(v, (k4_u16u *)p);
+#else
+    ((U16u *)p)->v = v;
+#endif
+}
+__device__ __forceinline__ void st8_out(uint8_t *p, uint8_t v)
+{
+#if defined(K4_NT_OUT) && !defined(K4_HOST_EMU)
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
 /* Orders this wave's earlier LDS/global accesses (any lane) before its later ones (any lane).

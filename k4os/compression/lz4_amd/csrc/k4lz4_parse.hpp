@@ -49,6 +49,7 @@ namespace k4 {
  * the second byte on, and a match needs its bytes to have stood there before (the densest block the tests could build,
  * tests/adversarial_blocks.py, has 10 500).  The slot holds the paper bound plus a round's worth, so nothing hangs on that argument. */
 constexpr uint32_t PARSE_REC_STRIDE = 16448u;
+static_assert(PARSE_REC_STRIDE >= ((uint32_t)LIMIT_64K - 1u - 6u) / 4u + 1u + 62u, "a block below LIMIT_64K has at most (LIMIT_64K - 1 - 6) / 4 sequences; a round adds at most 64 / 4 + 1");
 constexpr uint32_t PARSE_MIN_LEN = 128u;             /* shorter blocks go to the other kernels (the clamped loads below want 16 readable bytes somewhere) */
 constexpr uint32_t PARSE_REST = 0xffffffffu;         /* meta[2 b]: this block is for k4_encode_fast_rest_kernel */
 constexpr int PARSE_MAX_WAVES = 16;                  /* waves (= blocks) per workgroup: one workgroup per CU */
@@ -66,6 +67,9 @@ struct ParseArgs {
     uint32_t migrate;       /* != 0: blocks without an LDS table move into one when a block of their workgroup is done with it (ParseCtl) */
     uint32_t inline_emit;   /* != 0: the wave that parsed a block writes it out as well (k4_emit_kernel is not launched): the blocks that are
                              * through early do that while the others still parse, only the last ones' bytes come on top of the launch */
+    uint32_t slot_recs;     /* != 0 (with inline_emit): a block's records are written out by the wave that made them, right behind its parse,
+                             * so `recs` holds one slot per WAVE of the launch (workgroup x waves per workgroup + wave) instead of one per block:
+                             * a launch's scratch is what is resident, whatever the number of blocks */
     uint32_t *queue;        /* nullptr, or three zeroed words: the launch has fewer waves than blocks and every wave takes the next block
                              * when it is done with one -- [0] tickets handed out (never more than there are blocks), [1] taken from the front
                              * of the order (the most expensive: by the waves with a table in LDS), [2] taken from its back (by the others) */
@@ -107,6 +111,25 @@ __device__ __forceinline__ uint32_t ext28(const uint32_t *x)
         acc = t + (t == 32u ? acc : 0u);
     }
     return acc >> 3;
+}
+
+/* a sequence record: written once by the parse, read once by the write-out */
+__device__ __forceinline__ void rec_store(uint2 *r, uint32_t x, uint32_t y)
+{
+#if defined(K4_NT_RECS) && !defined(K4_HOST_EMU)
+    __builtin_nontemporal_store((((unsigned long long)y) << 32) | x, (unsigned long long *)r);
+#else
+    *r = make_uint2(x, y);
+#endif
+}
+__device__ __forceinline__ uint2 rec_load(const uint2 *r)
+{
+#if defined(K4_NT_RECS) && !defined(K4_HOST_EMU)
+    const unsigned long long v = __builtin_nontemporal_load((const unsigned long long *)r);
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+#else
+    return *r;
+#endif
 }
 
 /* hop word: bits 0-6 lane after the match (64 and more: outside the sub-window, 127 = "127 or more"), and the reasons to
@@ -593,7 +616,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                 if (k >= KK) continue;
                 if (hits[k]) {
                     if (!DRY && ((hits[k] >> lane) & 1ull))
-                        recs[at + (uint32_t)__popcll(hits[k] & below_me)] = make_uint2(pos[k], (pos[k] - cpos[k]) | (ecode[k] << 16));
+                        rec_store(recs + at + (uint32_t)__popcll(hits[k] & below_me), pos[k], (pos[k] - cpos[k]) | (ecode[k] << 16));
                     at += (uint32_t)__popcll(hits[k]);
                 }
             }
@@ -786,7 +809,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         K4_PHASE("records");
         K4_TICC();
         if (hts) {
-            if (!DRY && mine) recs[nrec + (uint32_t)__popcll(hts & below_me)] = make_uint2(p, (p - cp) | (ec << 16));
+            if (!DRY && mine) rec_store(recs + nrec + (uint32_t)__popcll(hts & below_me), p, (p - cp) | (ec << 16));
             nrec += (uint32_t)__popcll(hts);
         }
         K4_TOCC(7);
@@ -885,7 +908,11 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
                 else t = 0xffffffffu;
             }
             t = uni(t);
-            if (t == 0xffffffffu) return;
+            if (t == 0xffffffffu) {
+                /* no block left for this wave: its LDS table is for a block of the workgroup that still parses with its table in memory */
+                if (p.migrate && in_lds && lane == 0) atomicOr(lds + PARSE_LDS_DWORDS - 1, 1u << wave);
+                return;
+            }
             idx = (long long)t;
         }
         if (idx >= a.n) return;
@@ -896,7 +923,7 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
             if (lane == 0) { meta[0] = PARSE_REST; meta[1] = 0u; }
         } else {
             const uint8_t *src = a.src + a.srcOff[b];
-            uint2 *recs = p.recs + (unsigned long long)b * PARSE_REC_STRIDE;
+            uint2 *recs = p.recs + (p.slot_recs ? (unsigned long long)blockIdx.x * waves + wave : (unsigned long long)b) * PARSE_REC_STRIDE;
             uint32_t n;
             unsigned long long *pc = nullptr;
 #ifdef K4_PARSE_PROF
@@ -913,7 +940,7 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
             } else {
                 uint32_t *gt = p.gtab + 4096ull * ((unsigned long long)blockIdx.x * PARSE_MAX_WAVES + wave);
                 ParseCtl ctl;
-                ctl.free_slots = p.queue ? nullptr : free_slots; ctl.claimed = -1; ctl.resume = false;
+                ctl.free_slots = free_slots; ctl.claimed = -1; ctl.resume = false;
                 n = parse_block<K, true>(src, (uint32_t)src_len, recs, (uint16_t *)gt, seen, lane, pc, nullptr, &ctl);
                 if (ctl.claimed >= 0) {
                     moved = true;
@@ -1038,12 +1065,12 @@ __device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, 
     const uint64_t olimit = (uint64_t)(dst_cap < 0 ? 0 : dst_cap);
     uint32_t op = 0u, emitted_to = 0u;
     uint2 rn = make_uint2(0u, 0u);
-    if ((uint32_t)lane < nseq) rn = recs[lane];
+    if ((uint32_t)lane < nseq) rn = rec_load(recs + lane);
     for (uint32_t base = 0u; base < nseq; base += 64u) {
         const uint32_t n = nseq - base < 64u ? nseq - base : 64u;
         const bool mine = (uint32_t)lane < n;
         const uint2 r = rn;
-        if (base + 64u + (uint32_t)lane < nseq) rn = recs[base + 64u + (uint32_t)lane];      /* the next 64, while these are written */
+        if (base + 64u + (uint32_t)lane < nseq) rn = rec_load(recs + base + 64u + (uint32_t)lane);      /* the next 64, while these are written */
         const uint32_t pos = r.x, cpos = r.x - (r.y & 0xffffu), code = r.y >> 16;
         const uint32_t end = mine ? pos + (uint32_t)MINMATCH + code : 0u;
         const uint32_t prev = (uint32_t)__shfl_up((int)end, 1);
@@ -1103,24 +1130,24 @@ __device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, 
             if (ballot(fail)) return 0;
         }
         if (mine) {
-            dst[o_tok] = (uint8_t)(((ll < (uint32_t)RUN_MASK ? ll : (uint32_t)RUN_MASK) << ML_BITS) |
-                                   (mc < (uint32_t)ML_MASK ? mc : (uint32_t)ML_MASK));
-            if (lx == 1u) dst[o_tok + 1u] = (uint8_t)(ll - RUN_MASK);
-            ((U16u *)(dst + o_off))->v = (uint16_t)(pos - cpos);   /* :299-304 */
-            if (mx == 1u) dst[o_mx] = (uint8_t)(mc - ML_MASK);
+            st8_out(dst + o_tok, (uint8_t)(((ll < (uint32_t)RUN_MASK ? ll : (uint32_t)RUN_MASK) << ML_BITS) |
+                                           (mc < (uint32_t)ML_MASK ? mc : (uint32_t)ML_MASK)));
+            if (lx == 1u) st8_out(dst + o_tok + 1u, (uint8_t)(ll - RUN_MASK));
+            st16u_out(dst + o_off, (uint16_t)(pos - cpos));   /* :299-304 */
+            if (mx == 1u) st8_out(dst + o_mx, (uint8_t)(mc - ML_MASK));
         }
         if (short_run && ll != 0u) {                  /* exactly ll bytes, from the pieces */
             uint8_t *d = dst + o_lit;
-            if (ll >= 8u) ((U64u *)d)->v = v0;
-            if (ll >= 16u) ((U64u *)(d + 8))->v = v1;
-            if (ll >= 24u) ((U64u *)(d + 16))->v = v2;
-            if (ll >= 32u) ((U64u *)(d + 24))->v = v3;
+            if (ll >= 8u) st64u_out(d, v0);
+            if (ll >= 16u) st64u_out(d + 8, v1);
+            if (ll >= 24u) st64u_out(d + 16, v2);
+            if (ll >= 32u) st64u_out(d + 24, v3);
             const uint32_t n8 = ll >> 3;
             uint64_t vt = n8 == 0u ? v0 : n8 == 1u ? v1 : n8 == 2u ? v2 : v3;
             d += 8u * n8;
-            if (ll & 4u) { ((U32u *)d)->v = (uint32_t)vt; vt >>= 32; d += 4; }
-            if (ll & 2u) { ((U16u *)d)->v = (uint16_t)vt; vt >>= 16; d += 2; }
-            if (ll & 1u) *d = (uint8_t)vt;
+            if (ll & 4u) { st32u_out(d, (uint32_t)vt); vt >>= 32; d += 4; }
+            if (ll & 2u) { st16u_out(d, (uint16_t)vt); vt >>= 16; d += 2; }
+            if (ll & 1u) st8_out(d, (uint8_t)vt);
         }
         unsigned long long big = ballot(mine && (lit0 > LANE_COPY_MAX || lx > 1u || mx > 1u));
         while (big) {

@@ -121,6 +121,7 @@ int k4emu_encode_parse_batch(const uint8_t *src, const uint64_t *srcOff, const i
     /* K + 16: the parsing waves write their blocks out themselves (ParseArgs::inline_emit) and k4_emit_kernel is not launched;
      * K + 32: fewer waves than blocks, every wave takes the next block of the order when it is done with one (ParseArgs::queue) */
     const bool inline_emit = (K & 16) != 0, use_queue = (K & 32) != 0, migrate = (K & 64) != 0;     /* K + 64: ParseArgs::migrate */
+    const bool slot_recs = (K & 128) != 0 && inline_emit;                                             /* K + 128: ParseArgs::slot_recs */
     K &= 15;
     if (n <= 0) return 0;
     k4::BatchArgs a{};
@@ -130,7 +131,11 @@ int k4emu_encode_parse_batch(const uint8_t *src, const uint64_t *srcOff, const i
     if (waves > k4::PARSE_MAX_WAVES) waves = k4::PARSE_MAX_WAVES;
     k4::ParseArgs p{};
     p.nwg = (uint32_t)((n + waves - 1) / waves);
-    std::vector<uint2> recs((size_t)n * k4::PARSE_REC_STRIDE);
+    if (use_queue && p.nwg > 2) p.nwg = 2;              /* two workgroups' waves share the whole batch */
+    /* filled with a mark: what lies behind a block's last record must still carry it afterwards (nothing is written that is not counted) */
+    const size_t rec_slots = slot_recs ? (size_t)p.nwg * waves : (size_t)n;
+    std::vector<uint2> recs(rec_slots * k4::PARSE_REC_STRIDE, uint2{0xA5A5A5A5u, 0x5A5A5A5Au});
+    p.slot_recs = slot_recs ? 1u : 0u;
     std::vector<uint32_t> meta((size_t)n * 2, 0x12345678u), gtab((size_t)p.nwg * k4::PARSE_MAX_WAVES * 4096u, 0xdeadbeefu);
     p.recs = recs.data(); p.meta = meta.data(); p.gtab = gtab.data();
     p.inline_emit = inline_emit ? 1u : 0u;
@@ -149,6 +154,14 @@ int k4emu_encode_parse_batch(const uint8_t *src, const uint64_t *srcOff, const i
     if (!inline_emit) k4emu::launch_fn(dim3((unsigned)((n + k4::EMIT_WAVES_PER_WG - 1) / k4::EMIT_WAVES_PER_WG)), dim3(64 * k4::EMIT_WAVES_PER_WG), [=] { k4::k4_emit_kernel(a, p); }, threads);
     k4emu::launch_fn(dim3((unsigned)((n + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG), [=] { k4::k4_encode_fast_rest_kernel(a, p); }, threads);
     if (nseq_out) for (long long i = 0; i < n; i++) nseq_out[i] = meta[(size_t)i * 2];
+    if (!slot_recs)                                     /* per-block slots: exactly the counted records were written */
+        for (long long i = 0; i < n; i++) {
+            const uint32_t m = meta[(size_t)i * 2];
+            if (m == k4::PARSE_REST) continue;
+            if (m > k4::PARSE_REC_STRIDE) return -2;
+            for (size_t r = m; r < k4::PARSE_REC_STRIDE; r++)
+                if (recs[(size_t)i * k4::PARSE_REC_STRIDE + r].x != 0xA5A5A5A5u || recs[(size_t)i * k4::PARSE_REC_STRIDE + r].y != 0x5A5A5A5Au) return -3;
+        }
     return 0;
 }
 

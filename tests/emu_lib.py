@@ -107,14 +107,14 @@ class Emu:
         assert rc == 0
         return out
 
-    def encode_parse_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, accel=1, flags=0, k=1, waves=16, order=None, threads=0, inline_emit=False, queue=False, migrate=False):
+    def encode_parse_batch(self, src, src_off, src_len, dst, dst_off, dst_cap, accel=1, flags=0, k=1, waves=16, order=None, threads=0, inline_emit=False, queue=False, migrate=False, slot_recs=False):
         """the two-kernel fast encoder (k4lz4_parse.hpp): parse with k sub-windows per round and `waves` blocks per workgroup
         (those beyond 9 keep their table in memory), emit, then the one-kernel encoder for the blocks the parse left alone.
         Returns (outLen, sequences per block -- 0xffffffff where the parse left the block alone)."""
         out = np.full(len(src_len), -12345, dtype=np.int32)
         nseq = np.zeros(len(src_len), dtype=np.uint32)
         rc = self.lib.k4emu_encode_parse_batch(self._p(src), src_off.ctypes.data, src_len.ctypes.data, self._p(dst), dst_off.ctypes.data,
-                                               dst_cap.ctypes.data, out.ctypes.data, len(src_len), accel, flags, k + (16 if inline_emit else 0) + (32 if queue else 0) + (64 if migrate else 0), waves,
+                                               dst_cap.ctypes.data, out.ctypes.data, len(src_len), accel, flags, k + (16 if inline_emit else 0) + (32 if queue else 0) + (64 if migrate else 0) + (128 if slot_recs else 0), waves,
                                                order.ctypes.data if order is not None else None, nseq.ctypes.data, threads)
         assert rc == 0
         return out, nseq

@@ -61,11 +61,15 @@ def test_encode_fast_matches_oracle(emu, oracle, variant):
     assert (dst[mask] == 0xCD).all()
 
 
-@pytest.mark.parametrize("k,waves,how", [(1, 1, ""), (1, 16, "inline+migrate"), (1, 12, "inline+queue"), (1, 11, "migrate"), (2, 16, ""), (2, 9, "inline"), (3, 12, "queue"), (4, 5, "")])
+@pytest.mark.parametrize("k,waves,how", [(1, 1, ""), (1, 16, "inline+migrate"), (1, 12, "inline+queue"), (1, 11, "migrate"), (2, 16, ""), (2, 9, "inline"), (3, 12, "queue"), (4, 5, ""),
+                                         (1, 16, "inline+migrate+slots"), (1, 16, "inline+queue+slots"), (1, 3, "inline+queue+slots"), (1, 16, "inline+queue+migrate+slots"), (1, 11, "inline+queue+migrate+slots")])
 def test_encode_parse_emit_matches_oracle(emu, oracle, k, waves, how):
     """the two-kernel fast encoder (k4lz4_parse.hpp: which sequences, then their bytes): k sub-windows of 64 positions per
     round, `waves` blocks per workgroup of which those beyond nine keep their table in memory; blocks it leaves alone
-    (under 128 bytes, 65 547 and more) come out of the one-kernel encoder behind it"""
+    (under 128 bytes, 65 547 and more) come out of the one-kernel encoder behind it.  "slots": the records in one slot per wave of
+    the launch instead of one per block (what the launcher does: the persistent launch of a batch beyond one residency reuses
+    them block after block).  The emulator's entry point also checks that nothing was written behind a block's last counted record
+    (the record slot is sized by PARSE_REC_STRIDE's static_assert: what is counted is all that is written)."""
     blocks = _fixture_blocks()
     blocks += [corpus.lorem(n) for n in (127, 128, 129, 140, 200, 65546, 65547)] + [corpus.repeated(0xAA, n) for n in (128, 129, 141)]
     blocks += [corpus.class_bytes(name, 65536, 21) for name in ("nci", "samba", "osdb", "xml", "x-ray", "sao")]
@@ -78,7 +82,7 @@ def test_encode_parse_emit_matches_oracle(emu, oracle, k, waves, how):
     src, soff, slen = pack(blocks)
     dst, doff, dcap = arena([oracle.compress_bound(b.size) for b in blocks])
     order = np.random.default_rng(k).permutation(len(blocks)).astype(np.uint32) if waves != 9 else None
-    out, nseq = emu.encode_parse_batch(src, soff, slen, dst, doff, dcap, k=k, waves=waves, order=order, inline_emit="inline" in how, queue="queue" in how, migrate="migrate" in how)
+    out, nseq = emu.encode_parse_batch(src, soff, slen, dst, doff, dcap, k=k, waves=waves, order=order, inline_emit="inline" in how, queue="queue" in how, migrate="migrate" in how, slot_recs="slots" in how)
     for i, b in enumerate(blocks):
         want = oracle.encode(b)
         if b.size == 0:

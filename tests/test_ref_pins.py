@@ -363,6 +363,57 @@ def test_pickle_whole_envelope_header_is_the_reference_header(ref, oracle):
             assert env[:off] == ref.pickle_header(block.size, enc_len, wm), (name, wm)
 
 
+def _enc_pair(ref, oracle, b, cap=None):
+    return oracle.compress_fast(b, cap=cap), ref.compress_fast(b, cap=cap)
+
+
+def test_adversarial_blocks_oracle_is_the_reference(ref, oracle):
+    """tests/adversarial_blocks.py -- the 99 block-end blocks around the search's 66th probe (LL64.fast.cs:156-172) and the densest
+    block the tests can build (10 500 sequences) -- are what the emulator and the GPU tests compare with the ORACLE; here the oracle is
+    compared with LL64 itself on them, return value, bytes and slack (round 5's review, thin spot (a))"""
+    import adversarial_blocks
+    hard = adversarial_blocks.search_limit_at_block_end() + [adversarial_blocks.dense_four_byte_matches(128, 65546, 128)]
+    for i, b in enumerate(hard):
+        a, w = _enc_pair(ref, oracle, b)
+        assert _same(a, w), i
+        n, back = ref.decompress_safe(w[1][:w[0]], b.size)
+        assert n == b.size and back[:n].tobytes() == b.tobytes()
+
+
+def test_block_end_stress_generator_oracle_is_the_reference(ref, oracle):
+    """tests/tools/emu_stress_block_end.py's generator, one round of 1 024 blocks with a fixed seed, through oracle and LL64"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import emu_stress_block_end
+    rng = np.random.default_rng(3)
+    blocks = [emu_stress_block_end.block(rng) for _ in range(1024)]
+    bad = _pool_map(lambda i: _same(*_enc_pair(ref, oracle, blocks[i])), range(len(blocks)))
+    assert all(bad), [i for i, ok in enumerate(bad) if not ok][:10]
+
+
+def test_gpu_stress_generator_oracle_is_the_reference(ref, oracle):
+    """tests/tools/gpu_stress_encode.py's generator (the adversarial generator of emu_stress_encode.py mixed with the corpus classes,
+    0 .. 100 000 bytes, ragged output limits), one round of 1 500 blocks with the seed the GPU suite uses: every block the
+    reference encodes successfully is the oracle's byte for byte, and the two agree on which blocks fail for want of room"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    from emu_stress_encode import gen
+    rng = np.random.default_rng(5)
+    blocks, caps = [], []
+    for i in range(1500):
+        n = int(rng.choice([rng.integers(0, 40), rng.integers(100, 400), rng.integers(300, 6000), rng.integers(6000, 65547), rng.integers(64000, 65547), 65536]))
+        if n == 0: blocks.append(np.zeros(0, np.uint8))
+        elif rng.random() < 0.5: blocks.append(gen(rng, n))
+        else: blocks.append(corpus.class_bytes(corpus.SILESIA_NAMES[int(rng.integers(0, 12))], n, int(rng.integers(0, 1 << 30))))
+    blocks.append(gen(rng, int(rng.integers(65547, 100000))))
+    for b in blocks:
+        bound = ref.compress_bound(b.size)
+        caps.append(bound if rng.random() < 0.7 else int(rng.integers(0, bound + 1)))
+    ok = _pool_map(lambda i: _same(*_enc_pair(ref, oracle, blocks[i], caps[i])), range(len(blocks)))
+    assert all(ok), [i for i, v in enumerate(ok) if not v][:10]
+    assert sum(1 for b, c in zip(blocks, caps) if ref.compress_fast(b, cap=c)[0] <= 0) > 20       # (the ragged limits do bite)
+
+
 def test_signcheck_is_clean():
     """`make -C oracle ref-signcheck`: the generated C++ under -Wsign-compare -Wsign-conversion.  C# widens mixed int / uint
     arithmetic to long where C++ converts to unsigned, so a translator change that introduced such a site would change results
