@@ -12,6 +12,9 @@ namespace K4os.Compression.LZ4
 		/// library's own figures for the box it was measured on.</summary>
 		public static double HostGiBs { get; set; } = 0;
 
+		/// <summary>Upper bound on the threads the managed fallback of a small batch may use (0: Environment.ProcessorCount).</summary>
+		public static int MaxHostThreads { get; set; } = 0;
+
 		/// <summary>Compresses n independent blocks. Block i is source[sourceOffsets[i] .. +sourceLengths[i]) and goes to
 		/// target[targetOffsets[i] .. +targetLengths[i]); encodedLengths[i] is what Encode(...) would return for it.</summary>
 		public static unsafe void EncodeBatch(
@@ -68,12 +71,22 @@ namespace K4os.Compression.LZ4
 			var meanBlock = (int) Math.Max(1, n > 0 ? total / n : 1);
 			if (n > 0 && n < LLNative.k4lz4_recommended_min_batch(level < LZ4Level.L03_HC ? 0 : 2, meanBlock, HostGiBs))
 			{
-				System.Threading.Tasks.Parallel.For(0, n, i =>
+				void One(int i)
 				{
 					var buf = new byte[MaximumOutputSize(blocks[i].Length)];
 					var k = ManagedEncode(blocks[i], buf, level);
 					result[i] = k <= 0 && blocks[i].Length > 0 ? null : buf.AsSpan(0, Math.Max(k, 0)).ToArray();
-				});
+				}
+				// one or two blocks: the caller's thread (what the serial loop did); more: at most one thread per block and never more than
+				// MaxHostThreads (default: the processor count -- HostGiBs is read as the rate of that many threads), and an exception
+				// inside the loop reaches the caller as itself, as from the serial loop and from the device path (ADVICE round 5)
+				if (n <= 2) { for (var i = 0; i < n; i++) One(i); return result; }
+				var options = new System.Threading.Tasks.ParallelOptions { MaxDegreeOfParallelism = Math.Max(1, Math.Min(n, MaxHostThreads > 0 ? MaxHostThreads : Environment.ProcessorCount)) };
+				try { System.Threading.Tasks.Parallel.For(0, n, options, One); }
+				catch (AggregateException e) when (e.InnerExceptions.Count == 1)
+				{
+					System.Runtime.ExceptionServices.ExceptionDispatchInfo.Capture(e.InnerExceptions[0]).Throw();
+				}
 				return result;
 			}
 			for (var first = 0; first < n;)

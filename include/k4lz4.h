@@ -226,7 +226,10 @@ K4LZ4_API int k4lz4_unpickle_sizes_device(k4lz4_ctx *ctx, const uint8_t *src, co
  * are identical to the normal kernels; timing is perturbed (each phase drains its memory traffic).
  * decode = 4 (encode) / 5 (decode): the ORDINARY kernels run and only record, per block, [8] start and [9] end on the
  * real-time counter, [10] HW_ID and -- encode -- [11] which kernel took the block (1 LDS table, 2 global table, 3 the
- * 28-known-bytes variant): when each block of a batch really starts and ends (scripts/stamp_probe.py). */
+ * 28-known-bytes variant; 4 / 5 / 6 the two-step encoder of k4lz4_parse.hpp: table in LDS, in memory, moved into LDS on the way):
+ * when each block of a batch really starts and ends (scripts/stamp_probe.py).
+ * NOTE: in a default build, decode = 0 (encode phases) instruments the ONE-KERNEL encoder of rounds 1-4, not the two-step encoder
+ * that LZ4Codec.Encode batches ship through; its phase probe is a build with -DK4_PARSE_PROF (scripts/parse_probe.py). */
 K4LZ4_API int k4lz4_profile_batch_device(k4lz4_ctx *ctx, int decode, const uint8_t *src, const uint64_t *srcOff,
                                          const int32_t *srcLen, uint8_t *dst, const uint64_t *dstOff,
                                          const int32_t *dstCap, int32_t *outLen, int64_t n, uint64_t *counters,

@@ -391,11 +391,11 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
     const bool parse_prof_ok = false;
 #endif
     const bool encode_like = kind == KIND_ENCODE || kind == KIND_PICKLE;
-    /* Fast-level LZ4Codec.Encode batches beyond what is resident at once (16 blocks per CU: 8 LDS-table + 8 global-table waves)
-     * go in equal parts of at most that: a block takes its ~3.5 ms whatever the batch, so the rate is highest when every launch
-     * is one full residency -- 8192 x 64 KiB in one launch 55 GiB/s (the LDS-table kernel runs two passes, the other one is long
-     * done), as two launches of 4096 the bench batch's 63.  Not for batches that may be ragged (pickles, K4LZ4_FLAG_SEGMENTS):
-     * those need their one cost-ordered launch. */
+    /* Fast-level LZ4Codec.Encode batches beyond what is resident at once (16 blocks per CU: the parse kernel's one workgroup per CU,
+     * nine waves with their table in LDS and seven that move into a table as one becomes free): one persistent launch (round 6,
+     * below); with K4LZ4_NO_PERSIST, or through the one-kernel encoders of rounds 1-4, equal parts of at most one residency each --
+     * a block takes its ~2-3 ms whatever the batch, so those launches are best full.  Not for batches that may be ragged (pickles,
+     * K4LZ4_FLAG_SEGMENTS): those need their one cost-ordered launch. */
     const bool parse_path = kind == KIND_ENCODE && level < K4LZ4_L03_HC && ctx->use_parse && ctx->accel == 1 && (!ctx->prof || parse_prof_ok || ctx->prof_stamp) &&
                             !(flags & (FLAG_SEGMENTS_OK | K4LZ4_FLAG_SEGMENTS | K4LZ4_FLAG_NO_SPLIT));
     /* round 6: the two-step encoder takes a batch beyond one residency in ONE persistent launch -- one workgroup of sixteen waves per
@@ -486,7 +486,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
         const bool hop2 = cnt <= (int64_t)ctx->hop2_max_per_cu * (int64_t)ctx->cu_count;
         a.prof = ctx->prof ? ctx->prof + k4::PROF_STRIDE * first : nullptr;
         a.status = ctx->d_status;
-        if ((kind == KIND_ENCODE || (K4_DEC_PACE && (kind == KIND_DECODE || kind == KIND_UNPICKLE))) && ctx->use_pace && ctx->d_pace && cnt > (int64_t)ctx->pace_min_per_cu * (int64_t)ctx->cu_count) {   /* k4lz4_common.hpp, Pace: more than two blocks per SIMD */
+        if (((kind == KIND_ENCODE && !parse_path) || (K4_DEC_PACE && (kind == KIND_DECODE || kind == KIND_UNPICKLE))) && ctx->use_pace && ctx->d_pace && cnt > (int64_t)ctx->pace_min_per_cu * (int64_t)ctx->cu_count) {   /* k4lz4_common.hpp, Pace: more than two blocks per SIMD */
             a.pace = ctx->d_pace;
             K4_HIP(ctx, hipMemsetAsync(a.pace, 0, k4::PACE_BYTES, stream));
         }
@@ -574,19 +574,32 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
          * sequences (one wavefront per block, 64 x K positions per round, 16 blocks per workgroup = per CU dealt from the cost
          * order, the nine most expensive of a workgroup with their table in LDS), then their bytes (a throughput kernel), then
          * whatever block the parse left alone (65 547 bytes and more, very short ones) by the one-kernel encoder. */
-        if (kind == KIND_ENCODE && parse_path) {
-            const int64_t waves = std::max<int64_t>(1, std::min<int64_t>(ctx->parse_waves, (cnt + ctx->cu_count - 1) / ctx->cu_count));
-            /* K4LZ4_PARSE_QUEUE: one workgroup per CU at most, every wave takes the next block of the cost order when it is done with one */
-            const bool queue = (ctx->parse_queue || parse_persistent) && a.order && cnt > waves * (int64_t)ctx->cu_count;
-            const int64_t nwg = queue ? (int64_t)ctx->cu_count : (cnt + waves - 1) / waves;
+        bool parse_here = kind == KIND_ENCODE && parse_path;
+        if (parse_here && hostLen) {             /* nothing for the parse kernel in this part (all blocks too short or byU32-sized): no scratch, no launch */
+            bool any = false;
+            for (int64_t i = 0; i < cnt && !any; i++) any = hostLen[first + i] >= (int32_t)k4::PARSE_MIN_LEN && hostLen[first + i] < k4::LIMIT_64K;
+            parse_here = any;
+        }
+        int64_t waves = 0, nwg = 0;
+        bool queue = false, slot_recs = false;
+        size_t o_meta = 0, o_gtab = 0;
+        if (parse_here) {
+            waves = std::max<int64_t>(1, std::min<int64_t>(ctx->parse_waves, (cnt + ctx->cu_count - 1) / ctx->cu_count));
+            /* K4LZ4_PARSE_QUEUE, and every batch beyond one residency: one workgroup per CU at most, every wave takes the next block of
+             * the cost order when it is done with one */
+            queue = (ctx->parse_queue || parse_persistent) && a.order && cnt > waves * (int64_t)ctx->cu_count;
+            nwg = queue ? (int64_t)ctx->cu_count : (cnt + waves - 1) / waves;
             /* records: a slot per wave of the launch where the parsing waves write their blocks out themselves, else one per block */
-            const bool slot_recs = ctx->parse_inline_emit;
+            slot_recs = ctx->parse_inline_emit;
             const size_t rec_slots = slot_recs ? (size_t)nwg * (size_t)waves : (size_t)cnt;
-            const size_t o_meta = rec_slots * k4::PARSE_REC_STRIDE * sizeof(uint2), o_gtab = (o_meta + (size_t)cnt * 8 + 64 + 255) & ~(size_t)255;
+            o_meta = rec_slots * k4::PARSE_REC_STRIDE * sizeof(uint2); o_gtab = (o_meta + (size_t)cnt * 8 + 64 + 255) & ~(size_t)255;
             const size_t need = o_gtab + (waves > k4::PARSE_LDS_TABLES ? (size_t)nwg * k4::PARSE_MAX_WAVES * 16384 : 0);
             if (need > ctx->d_parse_cap) K4_HIP(ctx, hipStreamSynchronize(stream));
             const int rcp = grow(ctx, &ctx->d_parse, &ctx->d_parse_cap, need, false);
-            if (rcp != K4LZ4_OK) return rcp;
+            /* (no room for the records: the one-kernel encoders below need next to none -- the same bytes, a third slower) */
+            if (rcp != K4LZ4_OK) { std::lock_guard<std::mutex> g(g_err_mu); ctx->error.clear(); parse_here = false; }
+        }
+        if (parse_here) {
             k4::ParseArgs pa{};
             pa.recs = (uint2 *)ctx->d_parse; pa.meta = (uint32_t *)(ctx->d_parse + o_meta); pa.gtab = (uint32_t *)(ctx->d_parse + o_gtab);
             pa.nwg = (uint32_t)nwg;
@@ -1226,7 +1239,9 @@ int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t
             if (he != hipSuccess) return finish(hip_fail(ctx, he, "hipEventRecord"));
         }
         DictArgs dpart = ddev;
-        rc = launch(ctx, kind, ctx->d_src, d_soff + b0, d_slen + b0, ctx->d_dst, d_doff + b0, d_cap + b0, d_out + b0, cnt, level, flags, st,
+        /* (the kernels' target is the context's staging buffer: a hostile stream's offset-0 matches are zeroed there instead of handing
+         * this caller what an earlier call left in it -- ADVICE round 5) */
+        rc = launch(ctx, kind, ctx->d_src, d_soff + b0, d_slen + b0, ctx->d_dst, d_doff + b0, d_cap + b0, d_out + b0, cnt, level, flags | k4::FLAG_ZERO_GAPS, st,
                     &dpart, srcLen + b0);
         if (rc != K4LZ4_OK) return finish(rc);
         he = hipMemcpyAsync(h_len + b0, d_out + b0, (size_t)cnt * 4, hipMemcpyDeviceToHost, st);
@@ -1452,6 +1467,8 @@ int64_t k4lz4_recommended_min_batch(int kind, int32_t blockBytes, double hostGiB
     static const double box_host_GiBs[3] = {32.0, 35.0, 2.2};
     const double host = hostGiBs > 0.0 ? hostGiBs : box_host_GiBs[kind];
     double floor_ms = floor_ms_64k[kind] * (double)blockBytes / 65536.0;
+    /* (fast encode of blocks of 65 547 bytes and more -- byU32 tables -- is the one-kernel encoder's: its floor is the older, higher one) */
+    if (kind == 0 && blockBytes >= k4::LIMIT_64K) floor_ms = 2.9 * (double)blockBytes / 65536.0;
     if (floor_ms < 0.05) floor_ms = 0.05;
     const double blocks = floor_ms * 1e-3 * host * 1073741824.0 / (double)blockBytes;
     return blocks < 1.0 ? 1 : (int64_t)(blocks + 0.999);
@@ -1726,10 +1743,24 @@ int k4lz4_xxh32_batch(k4lz4_ctx *ctx, const uint8_t *data, const uint64_t *off, 
     return K4LZ4_OK;
 }
 
+static int decode_chain_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *blkOff, const uint32_t *blkLen,
+                               const uint64_t *firstBlk, const uint32_t *nBlk, const int32_t *blockSize,
+                               const uint8_t *chained, uint8_t *dst, const uint64_t *dstOff, const uint64_t *dstCap,
+                               int64_t *outLen, int64_t nStreams, void *stream, bool staged);
+
 int k4lz4_decode_chain_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *blkOff, const uint32_t *blkLen,
                                     const uint64_t *firstBlk, const uint32_t *nBlk, const int32_t *blockSize,
                                     const uint8_t *chained, uint8_t *dst, const uint64_t *dstOff, const uint64_t *dstCap,
                                     int64_t *outLen, int64_t nStreams, void *stream)
+{
+    return decode_chain_device(ctx, src, blkOff, blkLen, firstBlk, nBlk, blockSize, chained, dst, dstOff, dstCap, outLen, nStreams, stream, false);
+}
+
+/* staged: the target is the context's staging buffer (the host-pointer entry point): offset-0 matches are zeroed there */
+static int decode_chain_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *blkOff, const uint32_t *blkLen,
+                               const uint64_t *firstBlk, const uint32_t *nBlk, const int32_t *blockSize,
+                               const uint8_t *chained, uint8_t *dst, const uint64_t *dstOff, const uint64_t *dstCap,
+                               int64_t *outLen, int64_t nStreams, void *stream, bool staged)
 {
     if (!ctx) return fail(nullptr, K4LZ4_E_ARG, "ctx is NULL");
     if (nStreams < 0 || (nStreams > 0 && (!src || !blkOff || !blkLen || !firstBlk || !nBlk || !blockSize || !chained || !dst ||
@@ -1737,7 +1768,7 @@ int k4lz4_decode_chain_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const ui
         return fail(ctx, K4LZ4_E_ARG, "bad argument");
     if (nStreams == 0) return K4LZ4_OK;
     K4_HIP(ctx, hipSetDevice(ctx->device));
-    k4::ChainArgs a{src, blkOff, blkLen, firstBlk, nBlk, blockSize, chained, dst, dstOff, dstCap, (long long *)outLen, nStreams, ctx->d_status};
+    k4::ChainArgs a{src, blkOff, blkLen, firstBlk, nBlk, blockSize, chained, dst, dstOff, dstCap, (long long *)outLen, nStreams, ctx->d_status, staged ? 1 : 0};
     const unsigned grid = (unsigned)((nStreams + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
     if (nStreams <= 16 * (int64_t)ctx->cu_count && !ctx->no_pair) {  /* room for two waves per stream */
         hipLaunchKernelGGL(k4::k4_decode_chain_pair_kernel, dim3((unsigned)((nStreams + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
@@ -1803,8 +1834,8 @@ int k4lz4_decode_chain_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t 
     K4_HIP(ctx, hipMemcpyAsync(d_nblk, nBlk, (size_t)nStreams * 4, hipMemcpyHostToDevice, st));
     K4_HIP(ctx, hipMemcpyAsync(d_bsize, blockSize, (size_t)nStreams * 4, hipMemcpyHostToDevice, st));
     K4_HIP(ctx, hipMemcpyAsync(d_chained, chained, (size_t)nStreams, hipMemcpyHostToDevice, st));
-    rc = k4lz4_decode_chain_batch_device(ctx, ctx->d_src, d_boff, d_blen, d_first, d_nblk, d_bsize, d_chained, ctx->d_dst, d_doff,
-                                         d_dcap, d_out, nStreams, st);
+    rc = decode_chain_device(ctx, ctx->d_src, d_boff, d_blen, d_first, d_nblk, d_bsize, d_chained, ctx->d_dst, d_doff,
+                             d_dcap, d_out, nStreams, st, true);
     if (rc != K4LZ4_OK) return rc;
     K4_HIP(ctx, hipMemcpyAsync(outLen, d_out, (size_t)nStreams * 8, hipMemcpyDeviceToHost, st));
     if (dtotal) K4_HIP(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_dst, (size_t)dtotal, hipMemcpyDeviceToHost, st));

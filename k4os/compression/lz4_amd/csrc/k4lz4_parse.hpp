@@ -660,9 +660,9 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
      * bytes inside the block, the search's 66-probe limit out of reach -- written for the number of instructions it takes: a wave
      * alone issues one instruction every five to six cycles whatever the instruction is, so a round costs what it counts.
      * Differences from the general form: the lanes inside matches come from a DPP max-scan instead of a shuffle, the round's puts are
-     * one store by every visited lane plus a read-back (a position is later than whatever its slot held, so the put that must stand
-     * is the largest: lanes that read back less than their own position store again), a lane that stops the chain for its group's
-     * sake has its candidate's bytes compared in vector code against one broadcast lane. */
+     * one store with ONE writer per slot (of the visited lanes of an equal-hash group the highest: the latest position is what a slot
+     * holds in the end; every lane carries its group's lane mask G), a lane that stops the chain for its group's sake has its
+     * candidate's bytes compared in vector code against one broadcast lane. */
     auto fast_round = [&](auto more_c) -> bool {
         constexpr bool MORE = decltype(more_c)::value;
         constexpr uint32_t KNOWN = MORE ? 28u : 12u;

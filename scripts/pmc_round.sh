@@ -20,6 +20,8 @@ run grbm GRBM_GUI_ACTIVE
 # the L2's requests to DRAM counted in 32-byte units: on the calibration kernels these two reproduce the known byte counts
 # exactly (1 GiB streamed = 33 554 768 x 32 B read, 33 554 432 x 32 B written; a scattered 16-byte read costs a 128-byte
 # line, a scattered 2-byte write a 32-byte sector), which FETCH_SIZE / WRITE_SIZE do not
+# the L2's own hit rate (round 6: the review asked for it beside the traffic): hits / (hits + misses), over all channels
+run l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run dramrd TCC_EA0_RDREQ_DRAM_32B_sum
 run dramwr TCC_EA0_WRREQ_WRITE_DRAM_32B_sum
 cal caldramrd TCC_EA0_RDREQ_DRAM_32B_sum

@@ -113,8 +113,14 @@ for k in c1:
 if issue:
     print("issue ports (x4 quad-cycles / 1024 SIMDs / the kernel's own cycles):",
           {k: (round(v["valu_busy"], 3), round(v["salu_busy"], 3), int(v["insts_total"])) for k, v in issue.items()})
+cl2, _ = counters_of("l2", {"TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"})
+l2 = {k: {"hit": v.get("TCC_HIT_sum", 0.0), "miss": v.get("TCC_MISS_sum", 0.0), "req": v.get("TCC_REQ_sum", 0.0),
+          "hit_rate": (v.get("TCC_HIT_sum", 0.0) / (v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0))) if v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0) else None}
+      for k, v in cl2.items()}
+if l2:
+    print("L2 (TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum), requests per launch):", {k: (None if v["hit_rate"] is None else round(v["hit_rate"], 3), int(v["req"])) for k, v in l2.items()})
 if out:
-    doc = {"source_sha": source_hash(), "counters": "32 B x (TCC_EA0_RDREQ_DRAM_32B_sum + TCC_EA0_WRREQ_WRITE_DRAM_32B_sum), separate passes",
+    doc = {"source_sha": source_hash(), "l2": l2, "counters": "32 B x (TCC_EA0_RDREQ_DRAM_32B_sum + TCC_EA0_WRREQ_WRITE_DRAM_32B_sum), separate passes",
            "calibration_vs_known_bytes": check,
            "read_bytes_per_launch": {k: int(32.0 * v) for k, v in rd.items()}, "write_bytes_per_launch": {k: int(32.0 * v) for k, v in wr.items()},
            "traffic_bytes_per_launch": out, "issue": issue}

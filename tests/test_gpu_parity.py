@@ -454,8 +454,7 @@ def test_streams_with_an_offset_of_zero_leave_the_target_as_it_was(oracle):
     ref, roff = make_arena(caps + 16, fill=0xCD)
     want = oracle.decode_batch(src, soff, slen, ref, roff, caps, threads=8)
     # on DEVICE buffers: "as it was" is what the target slot held.  (Through host pointers the target slot is the context's staging
-    # buffer and the caller gets what THAT held: the one place where a host-pointer call and the reference can differ -- in bytes
-    # the reference itself leaves undefined -- see DESIGN.md 8.)
+    # buffer: there these bytes are zeroed -- the next test.)
     dc = DeviceCodec(0)
     sb = DeviceBatch.from_host(src, soff, slen, dc.device)
     db = DeviceBatch(torch.full((ref.size,), 0xCD, dtype=torch.uint8, device=dc.device), torch.from_numpy(roff.view(np.int64)).to(dc.device),
@@ -469,6 +468,41 @@ def test_streams_with_an_offset_of_zero_leave_the_target_as_it_was(oracle):
             a, b = int(doff[i]), int(roff[i])
             assert np.array_equal(dst[a:a + want[i]], ref[b:b + want[i]]), i          # the bytes left alone included
             assert (dst[a + caps[i]:a + caps[i] + 16] == 0xCD).all(), i
+
+
+def test_offset_zero_through_host_pointers_never_returns_another_calls_bytes(oracle):
+    """a host-pointer decode runs on the context's staging buffer, which holds what earlier calls left there; the
+    bytes an offset-0 match "copies onto themselves" (LL64.dec.cs:408-418) are therefore ZEROED on this path (the reference leaves
+    them what the caller's buffer held -- undefined bytes either way, but never another caller's data).  The staging buffer is first
+    filled with a recognisable pattern by an ordinary decode through the same context; return values and every defined byte are
+    the oracle's, the offset-0 bytes are 0."""
+    rng = np.random.default_rng(78)
+    marker = np.full(400000, 0xEE, np.uint8)
+    streams, sizes = [], []
+    for i in range(120):
+        b = corpus.class_bytes(corpus.SILESIA_NAMES[i % 12], int(rng.integers(200, 20000)), i)
+        streams.append(_zero_one_offset(oracle.encode(b), rng))
+        sizes.append(b.size)
+    # plus the hand-made one of the emulator test: 8 literals, a "match" of 6 bytes at offset 0, then ordinary sequences
+    streams.append(bytes([0x82]) + b"ABCDEFGH" + bytes([0, 0]) + bytes([0x21]) + b"ij" + bytes([8, 0]) + bytes([0xC0]) + b"123456789012")
+    sizes.append(33)
+    src, soff, slen = pack_blocks([np.frombuffer(x, np.uint8) for x in streams])
+    caps = np.array(sizes, np.int32)
+    ref, roff = make_arena(caps + 16, fill=0x00)            # the oracle leaves the bytes as they are: a zeroed target is what the host path gives
+    want = oracle.decode_batch(src, soff, slen, ref, roff, caps, threads=8)
+    for attempt in range(2):                                 # (second time: the staging buffer holds the first attempt's output)
+        LZ4Codec.DecodeBatchPacked(*pack_blocks([np.frombuffer(LZ4Codec.Encode(marker), np.uint8)]), *make_arena(np.array([marker.size], np.int32)), np.array([marker.size], np.int32))
+        dst, doff = make_arena(caps + 16, fill=0xCD)
+        got = LZ4Codec.DecodeBatchPacked(src, soff, slen, dst, doff, caps, flags=FLAG_RAW_RETURN)
+        assert np.array_equal(got, want)
+        assert (want > 0).sum() > 60
+        for i in range(len(streams)):
+            if want[i] > 0:
+                a, b = int(doff[i]), int(roff[i])
+                assert np.array_equal(dst[a:a + want[i]], ref[b:b + want[i]]), (attempt, i)
+                assert (dst[a + want[i]:a + caps[i] + 16] == 0xCD).all(), (attempt, i)
+    a = int(doff[-1])
+    assert got[-1] == 33 and dst[a:a + 8].tobytes() == b"ABCDEFGH" and (dst[a + 8:a + 14] == 0).all()
 
 
 def test_randomised_ragged_batches_through_the_default_fast_encoder(oracle):
