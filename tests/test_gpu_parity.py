@@ -491,7 +491,8 @@ def test_offset_zero_through_host_pointers_never_returns_another_calls_bytes(ora
     ref, roff = make_arena(caps + 16, fill=0x00)            # the oracle leaves the bytes as they are: a zeroed target is what the host path gives
     want = oracle.decode_batch(src, soff, slen, ref, roff, caps, threads=8)
     for attempt in range(2):                                 # (second time: the staging buffer holds the first attempt's output)
-        LZ4Codec.DecodeBatchPacked(*pack_blocks([np.frombuffer(LZ4Codec.Encode(marker), np.uint8)]), *make_arena(np.array([marker.size], np.int32)), np.array([marker.size], np.int32))
+        back = LZ4Codec.DecodeBatchPacked(*pack_blocks([np.frombuffer(oracle.encode(marker), np.uint8)]), *make_arena(np.array([marker.size], np.int32)), np.array([marker.size], np.int32))
+        assert back[0] == marker.size
         dst, doff = make_arena(caps + 16, fill=0xCD)
         got = LZ4Codec.DecodeBatchPacked(src, soff, slen, dst, doff, caps, flags=FLAG_RAW_RETURN)
         assert np.array_equal(got, want)
@@ -512,7 +513,48 @@ def test_randomised_ragged_batches_through_the_default_fast_encoder(oracle):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
     import gpu_stress_encode
     assert gpu_stress_encode.run(2, 5, 1500, oracle) == 0          # (seed 5 holds the block that found the 66th-probe corner, round 5)
+    assert gpu_stress_encode.run(2, 6, 3000, oracle) == 0          # round 6: two more rounds of 3 000 blocks, another seed ...
+    assert gpu_stress_encode.run(1, 7, 3000, oracle, device=True) == 0   # ... and one on device buffers (no host staging in between)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_batches_beyond_one_residency_through_the_persistent_launch(oracle):
+    """round 6: more blocks than one residency of the parse kernel (16 per CU) go through ONE persistent launch -- every wave takes
+    the next block of the cost order when it is done with one, the records live in per-wave slots that are reused block after
+    block, a wave that finds the queue empty frees its LDS table for a block that still parses with its table in memory.  9 400
+    ragged blocks (many more than are resident), ragged output limits: the oracle's bytes, lengths and failures, and the same
+    from launches of one residency each (K4LZ4_NO_PERSIST)."""
+    import os
+    from k4os.compression.lz4_amd import _native
+    import adversarial_blocks
+    rng = np.random.default_rng(61)
+    blocks = [b[:int(rng.integers(130, 8193))] for b in corpus.silesia_like_blocks(9000, 8192, seed=8)]
+    blocks += [b for b in corpus.silesia_like_blocks(300, 65536, seed=9)]
+    blocks += adversarial_blocks.search_limit_at_block_end() + [adversarial_blocks.dense_four_byte_matches(128, 65546, 128)]
+    blocks += [corpus.lorem(n) for n in (0, 1, 13, 127, 128, 65546, 65547, 70000)]
+    order = rng.permutation(len(blocks))
+    blocks = [blocks[i] for i in order]
+    caps = np.array([LZ4Codec.MaximumOutputSize(b.size) if rng.random() < 0.85 else int(rng.integers(0, LZ4Codec.MaximumOutputSize(b.size) + 1)) for b in blocks], np.int32)
+    src, soff, slen = pack_blocks(blocks)
+    ref_dst, ref_off = make_arena(caps + 16, fill=0xCD)
+    want = oracle.encode_batch(src, soff, slen, ref_dst, ref_off, caps, threads=32)
+    for env in ({}, {"K4LZ4_NO_PERSIST": "1"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ctx = _native.Context(-1)
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+        for rep in range(2):                     # (the second call reuses the slots the first one filled)
+            dst, doff = make_arena(caps + 16, fill=0xCD)
+            out = LZ4Codec.EncodeBatchPacked(src, soff, slen, dst, doff, caps, ctx=ctx)
+            assert np.array_equal(out, want), (env, rep, np.nonzero(out != want)[0][:5])
+            for i in np.nonzero(want > 0)[0]:
+                a = dst[int(doff[i]):int(doff[i]) + caps[i] + 16]; b = ref_dst[int(ref_off[i]):int(ref_off[i]) + caps[i] + 16]
+                assert np.array_equal(a[:want[i]], b[:want[i]]) and (a[want[i]:] == 0xCD).all(), (env, rep, int(i))
+        ctx.close()
 
 
 def test_fast_encoder_paths_give_identical_bytes(oracle):
