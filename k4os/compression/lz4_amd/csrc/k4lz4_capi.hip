@@ -114,6 +114,7 @@ struct k4lz4_ctx {
     uint8_t *d_parse = nullptr; size_t d_parse_cap = 0;       /* two-kernel fast encoder (k4lz4_parse.hpp): records, per-block counts, tables of the waves without an LDS table */
     bool use_parse = true;                /* K4LZ4_NO_PARSE: fast-level batches go to the one-kernel encoders as before */
     bool parse_queue = false;             /* K4LZ4_PARSE_QUEUE */
+    bool hc_records = true;               /* K4LZ4_NO_HC_RECORDS: level 3 writes its sequences out inside the parse loop (rounds 1-5) */
     bool parse_persist = true;            /* K4LZ4_NO_PERSIST: batches beyond one residency in launches of one residency each (round 5) instead of one persistent launch */
     bool parse_inline_emit = true;        /* K4LZ4_NO_INLINE_EMIT: the blocks' bytes by k4_emit_kernel behind the parse instead of by the parsing waves themselves */
     bool parse_migrate = true;            /* K4LZ4_NO_MIGRATE: blocks whose table lives in memory stay there (k4lz4_parse.hpp, ParseCtl) */
@@ -330,11 +331,20 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
         }
         if (optimal) hipLaunchKernelGGL(k4::k4_hc_parse_opt_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
         else {
+            /* level 3 on blocks of at most 64 KiB: the parse writes 8-byte sequence records (the fast encoder's scratch, a slot per
+             * block) and the same wave turns them into bytes afterwards; without room for them LZ4HC_encodeSequence stays in the loop */
+            if (level <= K4LZ4_L03_HC && tail[1] <= 65536 && ctx->hc_records) {
+                const size_t need = (size_t)cnt * k4::PARSE_REC_STRIDE * sizeof(uint2);
+                if (need > ctx->d_parse_cap) K4_HIP(ctx, hipStreamSynchronize(stream));
+                if (grow(ctx, &ctx->d_parse, &ctx->d_parse_cap, need, false) == K4LZ4_OK) h.recs = (uint2 *)ctx->d_parse;
+                else { std::lock_guard<std::mutex> g(g_err_mu); ctx->error.clear(); }
+            }
             if (ctx->use_pace && ctx->d_pace && cnt > 8 * (int64_t)ctx->cu_count) {
                 h.pace = ctx->d_pace;
                 K4_HIP(ctx, hipMemsetAsync(h.pace, 0, k4::PACE_BYTES, stream));
             }
-            hipLaunchKernelGGL(k4::k4_hc_parse_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
+            if (h.recs) hipLaunchKernelGGL(k4::k4_hc_parse_rec_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
+            else hipLaunchKernelGGL(k4::k4_hc_parse_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
         }
         if (pickle) hipLaunchKernelGGL(k4::k4_pickle_finish_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a, d_enclen);
         K4_HIP(ctx, hipGetLastError());
@@ -1399,6 +1409,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     ctx->use_parse = getenv("K4LZ4_NO_PARSE") == nullptr;
     ctx->parse_queue = getenv("K4LZ4_PARSE_QUEUE") != nullptr;
     ctx->parse_persist = getenv("K4LZ4_NO_PERSIST") == nullptr;
+    ctx->hc_records = getenv("K4LZ4_NO_HC_RECORDS") == nullptr;
     ctx->parse_pcost = getenv("K4LZ4_PCOST") != nullptr;
     ctx->parse_migrate = getenv("K4LZ4_NO_MIGRATE") == nullptr;
     ctx->parse_inline_emit = getenv("K4LZ4_NO_INLINE_EMIT") == nullptr;

@@ -72,6 +72,10 @@ struct HcArgs {
     uint32_t *status;              /* the context's status word (k4lz4_common.hpp), or nullptr */
     uint32_t *pace;                /* the parse kernel's late-blocks-first slots (k4lz4_common.hpp, Pace), zeroed; or nullptr */
     unsigned int blockBase;        /* chain kernels: workgroup 0 is block blockBase (the two of them share a launch chunk) */
+    uint2 *recs;                   /* round 6, k4_hc_parse_kernel at level 3 on blocks of at most 64 KiB: PARSE_REC_STRIDE sequence records per block
+                                    * (k4lz4_parse.hpp: x = where the match starts, y = offset | (length - MINMATCH) << 16) -- the parse only DECIDES,
+                                    * the block's bytes are written from the records afterwards (emit_block<true>); nullptr: LZ4HC_encodeSequence
+                                    * inside the parse loop as before */
 };
 
 /* a launch sized from a reservation (k4lz4_ctx_reserve_hc) whose batch turned out bigger: nothing is touched, every block
@@ -930,11 +934,24 @@ __device__ __forceinline__ int hc_nb_searches(int level)
 }
 
 /* LZ4HC_compress_hashChain (LL64.high.cs:512-800) for one block; returns bytes written, 0 = overflow */
-template <bool L3>
+/* REC: the sequences go into `recs` as 8-byte records and the bytes are written afterwards (emit_block<true>, k4lz4_parse.hpp) --
+ * LZ4HC_encodeSequence (LL64.high.cs:435-510) is a pure function of (anchor, start, match, length) and the source, and inside this
+ * serial loop it was 28 % of the kernel (wave-wide copies and fills with their own trips to memory, 22 more VGPRs, 59 more SGPR
+ * spills: profiles/r6_hc_ab.txt).  Only where a match length fits the record: blocks of at most 64 KiB. */
+template <bool L3, bool REC = false>
 __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap, int level,
                                               const uint32_t *cand, const uint2 *flen, const uint2 *blen, int lane,
-                                              uint32_t *pace = nullptr, uint32_t *pace_mine = nullptr)
+                                              uint32_t *pace = nullptr, uint32_t *pace_mine = nullptr, uint2 *recs = nullptr)
 {
+    uint32_t nrec = 0;
+/* one sequence: literals [anchor, ip), a match of ML bytes at REF; the cursor and the anchor move behind it */
+#define K4_HC_EMIT(ML, REF, PFA, PFB) \
+    do { \
+        if (REC) { \
+            if (lane == 0) recs[nrec] = make_uint2(ip, (ip - (REF)) | ((uint32_t)((ML) - MINMATCH) << 16)); \
+            nrec++; ip += (uint32_t)(ML); anchor = ip; \
+        } else if (!hc_encode_sequence(src, dst, ip, op, anchor, (ML), (REF), limited, oend, lane, (PFA), (PFB))) return 0; \
+    } while (0)
 #define K4_HC_SEARCH(P, LOW, LONGEST, MPOS, SPOS) \
     (L3 ? hc_search_l3(src, cand, hc_get_rec(win, cand, flen, blen, (P)), (P), (LOW), matchlimit, (LONGEST), (MPOS), (SPOS), lane) \
         : hc_search(src, cand, (P), (LOW), matchlimit, (LONGEST), (MPOS), (SPOS), max_attempts, lane, prev, pattern_analysis))
@@ -983,8 +1000,10 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
                  * are skipped a window at a time, and the record of the first position that can is
                  * already in registers */
                 const uint32_t pos = win.base + (uint32_t)lane;
-                if (anchor + (uint32_t)lane < U) pf_byte = src[anchor + (uint32_t)lane];
-                pf_anchor = anchor;
+                if (!REC) {
+                    if (anchor + (uint32_t)lane < U) pf_byte = src[anchor + (uint32_t)lane];
+                    pf_anchor = anchor;
+                }
                 const unsigned long long hm = __ballot(pos >= ip && pos <= mflimit && (win.f.x | win.f.y) != 0u);
                 if (!hm) { ip = win.base + 64u; continue; }
                 const int fz = ctz64(hm);
@@ -1011,7 +1030,7 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
                         ml2 = ml;
                     }
                     if (ml2 == ml) {                           /* no better match: encode ML1 */
-                        if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane, pf_anchor, pf_byte)) return 0;
+                        K4_HC_EMIT(ml, ref, pf_anchor, pf_byte);
                         break;
                     }
                     if (start0 < ip) {
@@ -1039,9 +1058,9 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
                 }
                 if (ml3 == ml2) {                              /* no better match: encode ML1 and ML2 */
                     if (start2 < ip + (uint32_t)ml) ml = (int)(start2 - ip);
-                    if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane, pf_anchor, pf_byte)) return 0;
+                    K4_HC_EMIT(ml, ref, pf_anchor, pf_byte);
                     ip = start2;
-                    if (!hc_encode_sequence(src, dst, ip, op, anchor, ml2, ref2, limited, oend, lane)) return 0;
+                    K4_HC_EMIT(ml2, ref2, HC_NONE, (uint8_t)0);
                     break;
                 }
                 if (start3 < ip + (uint32_t)ml + 3u) {         /* not enough space for match 2: remove it */
@@ -1051,7 +1070,7 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
                             start2 += (uint32_t)correction; ref2 += (uint32_t)correction; ml2 -= correction;
                             if (ml2 < MINMATCH) { start2 = start3; ref2 = ref3; ml2 = ml3; }
                         }
-                        if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane, pf_anchor, pf_byte)) return 0;
+                        K4_HC_EMIT(ml, ref, pf_anchor, pf_byte);
                         ip = start3; ref = ref3; ml = ml3;
                         start0 = start2; ref0 = ref2; ml0 = ml2;
                         go_search2 = true;
@@ -1071,13 +1090,17 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
                         ml = (int)(start2 - ip);
                     }
                 }
-                if (!hc_encode_sequence(src, dst, ip, op, anchor, ml, ref, limited, oend, lane, pf_anchor, pf_byte)) return 0;
+                K4_HC_EMIT(ml, ref, pf_anchor, pf_byte);
                 ip = start2; ref = ref2; ml = ml2;             /* ML2 becomes ML1, ML3 becomes ML2 */
                 start2 = start3; ref2 = ref3; ml2 = ml3;
                 /* goto _Search3 */
             }
           } while (L3 && ip <= mflimit && ip - win.base < 64u);
         }
+    }
+    if (REC) {
+        wave_sync();                 /* the records are this wave's own stores: in order with the loads that follow */
+        return emit_block<true>(src, U, dst, dst_cap, recs, nrec, lane);
     }
     /* _last_literals (:751-787) */
     {
@@ -1100,6 +1123,7 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
     }
     return (int)op;
 #undef K4_HC_SEARCH
+#undef K4_HC_EMIT
 }
 
 __global__ __launch_bounds__(64) void k4_hc_parse_kernel(HcArgs a)
@@ -1126,6 +1150,34 @@ __global__ __launch_bounds__(64) void k4_hc_parse_kernel(HcArgs a)
         int r = ret;
         if (!(a.flags & FLAG_RAW_RETURN)) r = src_len <= 0 ? 0 : (ret <= 0 ? -1 : ret);   /* LZ4Codec.cs:45-51 */
         else if (!hc_scratch_ok(a)) r = HC_NO_SCRATCH;      /* "not encoded", which 0 would not say to the pickle envelope (raw fallback) */
+        a.outLen[b] = r;
+    }
+}
+
+/* level 3 on blocks of at most 64 KiB, sequences as records and the bytes behind the parse (HcArgs::recs): a kernel of its own so
+ * that its registers are this form's and not the maximum over the three forms of k4_hc_parse_kernel */
+__global__ __launch_bounds__(64) void k4_hc_parse_rec_kernel(HcArgs a)
+{
+    __shared__ uint32_t pace_mine[4];
+    const int lane = lane_id();
+    if (K4_HC_PACE) Pace::begin(a.pace, pace_mine, lane);
+    const long long b = (long long)blockIdx.x;
+    const int src_len = a.srcLen[b];
+    const int cap = a.dstCap[b];
+    int ret = 0;
+    if ((src_len > 0 || (a.flags & FLAG_RAW_RETURN)) && hc_scratch_ok(a)) {
+        const uint32_t *prev = (const uint32_t *)(a.work + a.workOff[b]);
+        const uint32_t al = ((uint32_t)(src_len > 0 ? src_len : 0) + 3u) & ~3u;
+        const uint32_t *cand = prev + al;
+        const uint2 *flen = (const uint2 *)(cand + 4u * al);
+        const uint2 *blen = flen + al;
+        ret = hc_parse_block<true, true>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.level, cand, flen, blen, lane, a.pace, pace_mine,
+                                         a.recs + (unsigned long long)b * PARSE_REC_STRIDE);
+    }
+    if (lane == 0) {
+        int r = ret;
+        if (!(a.flags & FLAG_RAW_RETURN)) r = src_len <= 0 ? 0 : (ret <= 0 ? -1 : ret);   /* LZ4Codec.cs:45-51 */
+        else if (!hc_scratch_ok(a)) r = HC_NO_SCRATCH;
         a.outLen[b] = r;
     }
 }

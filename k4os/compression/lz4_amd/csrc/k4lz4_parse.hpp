@@ -884,6 +884,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 
+template <bool HC = false>
 __device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, uint8_t *dst, const int dst_cap, const uint2 *recs, const uint32_t nseq, const int lane);
 
 template <int K>
@@ -1059,6 +1060,10 @@ __global__ __launch_bounds__(256) void k4_porder_kernel(BatchArgs a)
  */
 constexpr int EMIT_WAVES_PER_WG = 4;
 
+/* HC: the records of the hash-chain parse (k4lz4_encode_hc.hpp, round 6) -- LZ4HC_encodeSequence (LL64.high.cs:435-510) writes the same
+ * format from the same four numbers; what differs is that its match starts are final (no backward extension here: LZ4HC_countBack
+ * ran inside the search) and its second output-limit test (:484: op + length / 255 + (1 + LASTLITERALS) > oend, against :346-350) */
+template <bool HC>
 __device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, uint8_t *dst, const int dst_cap, const uint2 *recs, const uint32_t nseq, const int lane)
 {
     const bool limited = dst_cap < compress_bound((int)U);         /* :524 */
@@ -1076,7 +1081,7 @@ __device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, 
         const uint32_t prev = (uint32_t)__shfl_up((int)end, 1);
         const uint32_t ls = lane == 0 ? emitted_to : prev;
         const uint32_t lit0 = mine ? pos - ls : 0u;
-        const uint32_t maxback = lit0 < cpos ? lit0 : cpos;                /* 0 right after a match */
+        const uint32_t maxback = HC ? 0u : (lit0 < cpos ? lit0 : cpos);    /* 0 right after a match */
         /* everything this pass needs from the source, asked for together -- the four bytes before position and candidate for the
          * backward extension, and the literal run in 8-byte pieces (a piece that holds a literal lies inside the block: a match
          * and the last literals follow) -- so that a pass waits for memory once */
@@ -1126,7 +1131,7 @@ __device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, 
         const uint32_t o_lit = o_tok + 1u + lx, o_off = o_lit + ll, o_mx = o_off + 2u;
         if (limited) {                                      /* :251-255, :346-350 */
             const bool fail = mine && ((uint64_t)o_tok + 1u + ll + (2 + 1 + LASTLITERALS) + ll / 255u > olimit ||
-                                       (uint64_t)o_mx + (1 + LASTLITERALS) + (mc + 240u) / 255u > olimit);
+                                       (uint64_t)o_mx + (1 + LASTLITERALS) + (HC ? mc / 255u : (mc + 240u) / 255u) > olimit);
             if (ballot(fail)) return 0;
         }
         if (mine) {

@@ -210,7 +210,12 @@ int k4emu_encode_hc_batch(const uint8_t *src, const uint64_t *srcOff, const int3
         const unsigned gy = (unsigned)((off[(size_t)n + 1] + k4::HC_CAND_POS_PER_WG - 1) / k4::HC_CAND_POS_PER_WG);
         k4emu::launch_fn(dim3((unsigned)n, gy), dim3(256), [=] { k4::k4_hc_cand_kernel(a); }, threads);
     }
+    /* flags bit 30 (the emulator's own): level 3 with sequence records (HcArgs::recs), as the launcher runs blocks of at most 64 KiB */
+    std::vector<uint2> recs;
+    if ((flags & (1 << 30)) && level <= 3 && off[(size_t)n + 1] <= 65536) { recs.resize((size_t)n * k4::PARSE_REC_STRIDE); a.recs = recs.data(); }
+    a.flags = flags & ~(1 << 30);
     if (level >= 10) k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_hc_parse_opt_kernel(a); }, threads);
+    else if (a.recs) k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_hc_parse_rec_kernel(a); }, threads);
     else k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_hc_parse_kernel(a); }, threads);
     return 0;
 }

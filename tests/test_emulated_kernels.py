@@ -481,6 +481,37 @@ def test_encode_hc_matches_oracle(emu, oracle, level):
     assert (dst[mask] == 0xCD).all()
 
 
+def test_encode_hc_level3_from_sequence_records(emu, oracle):
+    """round 6: at level 3, on blocks of at most 64 KiB, k4_hc_parse_kernel only decides -- 8-byte sequence records -- and the bytes are
+    written from the records afterwards (emit_block<true>: LZ4HC_encodeSequence's format and ITS output-limit tests,
+    LL64.high.cs:435-510).  The oracle's bytes at full capacity, at exact fit, one byte short and far too small."""
+    rng = np.random.default_rng(44)
+    blocks = [corpus.class_bytes(name, int(rng.integers(2000, 65537)), 7) for name in corpus.SILESIA_NAMES]
+    blocks += [corpus.class_bytes(name, 65536, 9) for name in ("dickens", "xml", "nci", "sao")]
+    blocks += [corpus.lorem(n) for n in (1, 12, 13, 14, 1000, 65536)] + [corpus.repeated(0xAA, n) for n in (13, 33, 1000, 65536)]
+    blocks += [corpus.random_bytes(5000, 5), np.tile(np.frombuffer(b"abcdabcdabcdabcd" * 4 + b"xyz", np.uint8), 300)]
+    blocks += [np.concatenate([np.zeros(20000, np.uint8), corpus.random_bytes(100, 1), np.zeros(20000, np.uint8)])]
+    import adversarial_blocks
+    blocks.append(adversarial_blocks.dense_four_byte_matches(128, 65536, 128))
+    full = [oracle.compress_hc(b, 3) for b in blocks]
+    cases = []
+    for b, (r, w) in zip(blocks, full):
+        for cap in (oracle.compress_bound(b.size), r, r - 1, max(r // 2, 0), 0):
+            cases.append((b, cap))
+    src, soff, slen = pack([b for b, _ in cases])
+    dst, doff, dcap = arena([c for _, c in cases])
+    out = emu.encode_hc_batch(src, soff, slen, dst, doff, dcap, level=3, flags=FLAG_RAW | (1 << 30))
+    for i, (b, cap) in enumerate(cases):
+        r, w = oracle.compress_hc(b, 3, cap=cap)
+        assert out[i] == r, (i, b.size, cap, out[i], r)
+        if r > 0:
+            assert dst[int(doff[i]):int(doff[i]) + r].tobytes() == w[:r].tobytes(), (i, b.size, cap)
+    mask = np.ones(dst.size, bool)                         # nothing outside a slot, nothing behind a successful block's bytes
+    for i, (b, cap) in enumerate(cases):                   # (what a failed call leaves INSIDE its slot is no contract)
+        mask[int(doff[i]):int(doff[i]) + (int(out[i]) if out[i] > 0 else cap)] = False
+    assert (dst[mask] == 0xCD).all()
+
+
 def test_encode_hc_limited_output(emu, oracle):
     blocks, caps, wants = [], [], []
     for name in ("dickens", "xml", "x-ray"):
