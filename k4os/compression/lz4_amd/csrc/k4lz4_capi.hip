@@ -310,15 +310,17 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
                 K4_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
                 K4_HIP(ctx, hipMemsetAsync(ctx->d_hc_hash + ((size_t)n_lds << (k4::HC_HASH_LOG + 2)), 0, (size_t)n_mem << (k4::HC_HASH_LOG + 2), ctx->aux));
                 k4::HcArgs hm = h;
-                hm.blockBase = (unsigned)n_lds;
-                hipLaunchKernelGGL(k4::k4_hc_chain_kernel, dim3((unsigned)n_mem), dim3(64), 0, ctx->aux, hm);
+                hm.blockBase = (unsigned)n_lds; hm.nChain = n_mem;
+                hipLaunchKernelGGL(k4::k4_hc_chain_kernel, dim3((unsigned)((n_mem + k4::HC_CHAIN_WAVES_PER_WG - 1) / k4::HC_CHAIN_WAVES_PER_WG)), dim3(64 * k4::HC_CHAIN_WAVES_PER_WG), 0, ctx->aux, hm);
                 K4_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
             }
-            hipLaunchKernelGGL(k4::k4_hc_chain_lds_kernel, dim3((unsigned)n_lds), dim3(64), 0, stream, h);
+            h.nChain = n_lds;
+            hipLaunchKernelGGL(k4::k4_hc_chain_lds_kernel, dim3((unsigned)((n_lds + k4::HC_CHAIN_LDS_WAVES_PER_WG - 1) / k4::HC_CHAIN_LDS_WAVES_PER_WG)), dim3(64 * k4::HC_CHAIN_LDS_WAVES_PER_WG), 0, stream, h);
             if (n_mem > 0) K4_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_join, 0));
         } else {
             K4_HIP(ctx, hipMemsetAsync(ctx->d_hc_hash, 0, (size_t)cnt << (k4::HC_HASH_LOG + 2), stream));
-            hipLaunchKernelGGL(k4::k4_hc_chain_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
+            h.nChain = cnt;
+            hipLaunchKernelGGL(k4::k4_hc_chain_kernel, dim3((unsigned)((cnt + k4::HC_CHAIN_WAVES_PER_WG - 1) / k4::HC_CHAIN_WAVES_PER_WG)), dim3(64 * k4::HC_CHAIN_WAVES_PER_WG), 0, stream, h);
         }
         const bool optimal = level >= K4LZ4_L10_OPT;              /* clTable (LL64.high.cs:1124-1138): lz4opt strategy */
         if (tail[1] >= 13 && !optimal) {
@@ -329,6 +331,7 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
                 hipLaunchKernelGGL(k4::k4_hc_cand_kernel, dim3((unsigned)cnt, std::min(65535u, gy - y0)), dim3(256), 0, stream, hy);
             }
         }
+        const hipStream_t pstream = stream;
         if (optimal) hipLaunchKernelGGL(k4::k4_hc_parse_opt_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
         else {
             /* level 3 on blocks of at most 64 KiB: the parse writes 8-byte sequence records (the fast encoder's scratch, a slot per
@@ -341,10 +344,10 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
             }
             if (ctx->use_pace && ctx->d_pace && cnt > 8 * (int64_t)ctx->cu_count) {
                 h.pace = ctx->d_pace;
-                K4_HIP(ctx, hipMemsetAsync(h.pace, 0, k4::PACE_BYTES, stream));
+                K4_HIP(ctx, hipMemsetAsync(h.pace, 0, k4::PACE_BYTES, pstream));
             }
-            if (h.recs) hipLaunchKernelGGL(k4::k4_hc_parse_rec_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
-            else hipLaunchKernelGGL(k4::k4_hc_parse_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, h);
+            if (h.recs) hipLaunchKernelGGL(k4::k4_hc_parse_rec_kernel, dim3((unsigned)((cnt + k4::HC_REC_WAVES_PER_WG - 1) / k4::HC_REC_WAVES_PER_WG)), dim3(64 * k4::HC_REC_WAVES_PER_WG), 0, pstream, h);
+            else hipLaunchKernelGGL(k4::k4_hc_parse_kernel, dim3((unsigned)((cnt + k4::HC_PARSE_WAVES_PER_WG - 1) / k4::HC_PARSE_WAVES_PER_WG)), dim3(64 * k4::HC_PARSE_WAVES_PER_WG), 0, pstream, h);
         }
         if (pickle) hipLaunchKernelGGL(k4::k4_pickle_finish_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a, d_enclen);
         K4_HIP(ctx, hipGetLastError());

@@ -72,6 +72,7 @@ struct HcArgs {
     uint32_t *status;              /* the context's status word (k4lz4_common.hpp), or nullptr */
     uint32_t *pace;                /* the parse kernel's late-blocks-first slots (k4lz4_common.hpp, Pace), zeroed; or nullptr */
     unsigned int blockBase;        /* chain kernels: workgroup 0 is block blockBase (the two of them share a launch chunk) */
+    long long nChain;              /* ... and this many blocks from there on are this kernel's */
     uint2 *recs;                   /* round 6, k4_hc_parse_kernel at level 3 on blocks of at most 64 KiB: PARSE_REC_STRIDE sequence records per block
                                     * (k4lz4_parse.hpp: x = where the match starts, y = offset | (length - MINMATCH) << 16) -- the parse only DECIDES,
                                     * the block's bytes are written from the records afterwards (emit_block<true>); nullptr: LZ4HC_encodeSequence
@@ -182,11 +183,25 @@ __device__ __forceinline__ void hc_chain_block(const uint8_t *src, uint32_t U, T
     }
 }
 
-__global__ __launch_bounds__(64) void k4_hc_chain_kernel(HcArgs a)
+/* blocks per workgroup of the two chain kernels (round 6, measured with the parse kernels' change of shape, gpurun_out/r6j: the
+ * table-in-memory kernel is the same with one or four waves per workgroup, 4.0 - 4.2 ms; the LDS-table kernel with two waves and
+ * two 68 KiB tables per workgroup is SLOWER than with two one-wave workgroups per CU, 6.3 - 6.7 against 5.7 ms) */
+#ifndef K4_HC_CHAIN_WAVES
+#define K4_HC_CHAIN_WAVES 4
+#endif
+#ifndef K4_HC_CHAIN_LDS_WAVES
+#define K4_HC_CHAIN_LDS_WAVES 1
+#endif
+constexpr int HC_CHAIN_WAVES_PER_WG = K4_HC_CHAIN_WAVES, HC_CHAIN_LDS_WAVES_PER_WG = K4_HC_CHAIN_LDS_WAVES;
+__global__ __launch_bounds__(64 * HC_CHAIN_WAVES_PER_WG) void k4_hc_chain_kernel(HcArgs a)
 {
-    __shared__ uint32_t seen[(1u << HC_HASH_LOG) / 32u];
+    __shared__ uint32_t seen_all[HC_CHAIN_WAVES_PER_WG][(1u << HC_HASH_LOG) / 32u];
     const int lane = lane_id();
-    const long long b = (long long)blockIdx.x + (long long)a.blockBase;
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    uint32_t *seen = seen_all[wave];
+    const long long slot = (long long)blockIdx.x * HC_CHAIN_WAVES_PER_WG + (long long)wave;
+    if (slot >= a.nChain) return;
+    const long long b = slot + (long long)a.blockBase;
     const int len = a.srcLen[b];
     if (len < MFLIMIT + 1 || !hc_scratch_ok(a)) return;    /* no search happens (LL64.high.cs:549) */
     for (uint32_t k = (uint32_t)lane; k < (1u << HC_HASH_LOG) / 32u; k += 64u) seen[k] = 0u;
@@ -195,12 +210,17 @@ __global__ __launch_bounds__(64) void k4_hc_chain_kernel(HcArgs a)
 }
 
 /* every block of the launch is at most 64 KiB long (the host knows the longest): tables in LDS, no table memory touched */
-__global__ __launch_bounds__(64) void k4_hc_chain_lds_kernel(HcArgs a)
+__global__ __launch_bounds__(64 * HC_CHAIN_LDS_WAVES_PER_WG) void k4_hc_chain_lds_kernel(HcArgs a)
 {
-    __shared__ uint32_t seen[(1u << HC_HASH_LOG) / 32u];
-    __shared__ uint16_t tab[1u << HC_HASH_LOG];
+    __shared__ uint32_t seen_all[HC_CHAIN_LDS_WAVES_PER_WG][(1u << HC_HASH_LOG) / 32u];
+    __shared__ uint16_t tab_all[HC_CHAIN_LDS_WAVES_PER_WG][1u << HC_HASH_LOG];
     const int lane = lane_id();
-    const long long b = (long long)blockIdx.x + (long long)a.blockBase;
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    uint32_t *seen = seen_all[wave];
+    uint16_t *tab = tab_all[wave];
+    const long long slot = (long long)blockIdx.x * HC_CHAIN_LDS_WAVES_PER_WG + (long long)wave;
+    if (slot >= a.nChain) return;                          /* (this kernel's share of the launch chunk: blocks blockBase .. blockBase + nChain) */
+    const long long b = slot + (long long)a.blockBase;
     const int len = a.srcLen[b];
     if (len < MFLIMIT + 1 || len > 65536 || !hc_scratch_ok(a)) return;
     for (uint32_t k = (uint32_t)lane; k < (1u << HC_HASH_LOG) / 32u; k += 64u) seen[k] = 0u;
@@ -1126,13 +1146,19 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
 #undef K4_HC_EMIT
 }
 
-__global__ __launch_bounds__(64) void k4_hc_parse_kernel(HcArgs a)
+/* four blocks per workgroup (round 6: one-wave workgroups were placed so that the same 4096 blocks took 15.2 ms instead of 8.9 --
+ * profiles/r6_hc_ab.txt) */
+constexpr int HC_PARSE_WAVES_PER_WG = 4;
+__global__ __launch_bounds__(64 * HC_PARSE_WAVES_PER_WG) void k4_hc_parse_kernel(HcArgs a)
 {
-    __shared__ uint32_t pace_mine[4];
+    __shared__ uint32_t pace_all[HC_PARSE_WAVES_PER_WG][4];
     const int lane = lane_id();
-    if (K4_HC_PACE) Pace::begin(a.pace, pace_mine, lane);
-    const long long b = (long long)blockIdx.x;
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    uint32_t *pace_mine = pace_all[wave];
+    const long long b = (long long)blockIdx.x * HC_PARSE_WAVES_PER_WG + (long long)wave;
+    if (b >= a.n) return;
     const int src_len = a.srcLen[b];
+    if (K4_HC_PACE) Pace::begin(a.pace, pace_mine, lane);
     const int cap = a.dstCap[b];
     int ret = 0;
     if ((src_len > 0 || (a.flags & FLAG_RAW_RETURN)) && hc_scratch_ok(a)) {
@@ -1156,13 +1182,17 @@ __global__ __launch_bounds__(64) void k4_hc_parse_kernel(HcArgs a)
 
 /* level 3 on blocks of at most 64 KiB, sequences as records and the bytes behind the parse (HcArgs::recs): a kernel of its own so
  * that its registers are this form's and not the maximum over the three forms of k4_hc_parse_kernel */
-__global__ __launch_bounds__(64) void k4_hc_parse_rec_kernel(HcArgs a)
+constexpr int HC_REC_WAVES_PER_WG = HC_PARSE_WAVES_PER_WG;
+__global__ __launch_bounds__(64 * HC_REC_WAVES_PER_WG) void k4_hc_parse_rec_kernel(HcArgs a)
 {
-    __shared__ uint32_t pace_mine[4];
+    __shared__ uint32_t pace_all[HC_REC_WAVES_PER_WG][4];
     const int lane = lane_id();
-    if (K4_HC_PACE) Pace::begin(a.pace, pace_mine, lane);
-    const long long b = (long long)blockIdx.x;
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    uint32_t *pace_mine = pace_all[wave];
+    const long long b = (long long)blockIdx.x * HC_REC_WAVES_PER_WG + (long long)wave;
+    if (b >= a.n) return;
     const int src_len = a.srcLen[b];
+    if (K4_HC_PACE) Pace::begin(a.pace, pace_mine, lane);
     const int cap = a.dstCap[b];
     int ret = 0;
     if ((src_len > 0 || (a.flags & FLAG_RAW_RETURN)) && hc_scratch_ok(a)) {

@@ -204,8 +204,9 @@ int k4emu_encode_hc_batch(const uint8_t *src, const uint64_t *srcOff, const int3
     std::vector<uint8_t> work((size_t)off[(size_t)n] + 64);
     a.hash = hash.data();
     a.work = work.data();
-    if (off[(size_t)n + 1] <= 65536) k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_hc_chain_lds_kernel(a); }, threads);   /* as the launcher chooses */
-    else k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_hc_chain_kernel(a); }, threads);
+    a.nChain = n;
+    if (off[(size_t)n + 1] <= 65536) k4emu::launch_fn(dim3((unsigned)((n + k4::HC_CHAIN_LDS_WAVES_PER_WG - 1) / k4::HC_CHAIN_LDS_WAVES_PER_WG)), dim3(64 * k4::HC_CHAIN_LDS_WAVES_PER_WG), [=] { k4::k4_hc_chain_lds_kernel(a); }, threads);   /* as the launcher chooses */
+    else k4emu::launch_fn(dim3((unsigned)((n + k4::HC_CHAIN_WAVES_PER_WG - 1) / k4::HC_CHAIN_WAVES_PER_WG)), dim3(64 * k4::HC_CHAIN_WAVES_PER_WG), [=] { k4::k4_hc_chain_kernel(a); }, threads);
     if (off[(size_t)n + 1] >= 13 && level < 10) {
         const unsigned gy = (unsigned)((off[(size_t)n + 1] + k4::HC_CAND_POS_PER_WG - 1) / k4::HC_CAND_POS_PER_WG);
         k4emu::launch_fn(dim3((unsigned)n, gy), dim3(256), [=] { k4::k4_hc_cand_kernel(a); }, threads);
@@ -215,8 +216,8 @@ int k4emu_encode_hc_batch(const uint8_t *src, const uint64_t *srcOff, const int3
     if ((flags & (1 << 30)) && level <= 3 && off[(size_t)n + 1] <= 65536) { recs.resize((size_t)n * k4::PARSE_REC_STRIDE); a.recs = recs.data(); }
     a.flags = flags & ~(1 << 30);
     if (level >= 10) k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_hc_parse_opt_kernel(a); }, threads);
-    else if (a.recs) k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_hc_parse_rec_kernel(a); }, threads);
-    else k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_hc_parse_kernel(a); }, threads);
+    else if (a.recs) k4emu::launch_fn(dim3((unsigned)((n + k4::HC_REC_WAVES_PER_WG - 1) / k4::HC_REC_WAVES_PER_WG)), dim3(64 * k4::HC_REC_WAVES_PER_WG), [=] { k4::k4_hc_parse_rec_kernel(a); }, threads);
+    else k4emu::launch_fn(dim3((unsigned)((n + k4::HC_PARSE_WAVES_PER_WG - 1) / k4::HC_PARSE_WAVES_PER_WG)), dim3(64 * k4::HC_PARSE_WAVES_PER_WG), [=] { k4::k4_hc_parse_kernel(a); }, threads);
     return 0;
 }
 
