@@ -115,6 +115,7 @@ struct k4lz4_ctx {
     bool use_parse = true;                /* K4LZ4_NO_PARSE: fast-level batches go to the one-kernel encoders as before */
     bool parse_queue = false;             /* K4LZ4_PARSE_QUEUE */
     bool hc_records = true;               /* K4LZ4_NO_HC_RECORDS: level 3 writes its sequences out inside the parse loop (rounds 1-5) */
+    bool parse_big = true;                /* K4LZ4_NO_PARSE_BIG: blocks of 65 547 bytes and more stay with the one-kernel encoder (round 5) */
     bool parse_persist = true;            /* K4LZ4_NO_PERSIST: batches beyond one residency in launches of one residency each (round 5) instead of one persistent launch */
     bool parse_inline_emit = true;        /* K4LZ4_NO_INLINE_EMIT: the blocks' bytes by k4_emit_kernel behind the parse instead of by the parsing waves themselves */
     bool parse_migrate = true;            /* K4LZ4_NO_MIGRATE: blocks whose table lives in memory stay there (k4lz4_parse.hpp, ParseCtl) */
@@ -588,10 +589,18 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
          * order, the nine most expensive of a workgroup with their table in LDS), then their bytes (a throughput kernel), then
          * whatever block the parse left alone (65 547 bytes and more, very short ones) by the one-kernel encoder. */
         bool parse_here = kind == KIND_ENCODE && parse_path;
-        if (parse_here && hostLen) {             /* nothing for the parse kernel in this part (all blocks too short or byU32-sized): no scratch, no launch */
-            bool any = false;
-            for (int64_t i = 0; i < cnt && !any; i++) any = hostLen[first + i] >= (int32_t)k4::PARSE_MIN_LEN && hostLen[first + i] < k4::LIMIT_64K;
-            parse_here = any;
+        /* blocks of 65 547 bytes and more (byU32 tables) go through k4_parse_big_kernel behind the first launch -- where the parsing
+         * waves write their blocks out themselves (a big block has more sequences than a record slot holds) */
+        const bool big_ok = ctx->parse_big && ctx->parse_inline_emit;
+        bool any_small = true, any_big = big_ok;
+        if (parse_here && hostLen) {             /* nothing for the parse kernels in this part (all blocks too short): no scratch, no launch */
+            any_small = false; any_big = false;
+            for (int64_t i = 0; i < cnt && !(any_small && (any_big || !big_ok)); i++) {
+                const int32_t len = hostLen[first + i];
+                if (len >= (int32_t)k4::PARSE_MIN_LEN && len < k4::LIMIT_64K) any_small = true;
+                else if (len >= k4::LIMIT_64K && big_ok) any_big = true;
+            }
+            parse_here = any_small || any_big;
         }
         int64_t waves = 0, nwg = 0;
         bool queue = false, slot_recs = false;
@@ -619,17 +628,24 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             pa.inline_emit = ctx->parse_inline_emit ? 1u : 0u;
             pa.slot_recs = slot_recs ? 1u : 0u;
             pa.migrate = ctx->parse_migrate ? 1u : 0u;
+            pa.big = any_big ? 1u : 0u;
             if (queue) {
                 pa.queue = pa.meta + 2 * cnt;
-                K4_HIP(ctx, hipMemsetAsync(pa.queue, 0, 16, stream));
+                K4_HIP(ctx, hipMemsetAsync(pa.queue, 0, 32, stream));
             }
+            /* (the first launch also says whose every block is -- PARSE_BIG / PARSE_REST --, so it runs even without a block of its own) */
             hipLaunchKernelGGL(k4::k4_parse_kernel, dim3((unsigned)nwg), dim3((unsigned)(64 * waves)), 0, stream, a, pa);
+            if (any_big) {
+                k4::ParseArgs pb = pa;
+                if (queue) pb.queue = pa.queue + 4;
+                hipLaunchKernelGGL(k4::k4_parse_big_kernel, dim3((unsigned)nwg), dim3((unsigned)(64 * waves)), 0, stream, a, pb);
+            }
             if (!pa.inline_emit)
                 hipLaunchKernelGGL(k4::k4_emit_kernel, dim3((unsigned)((cnt + k4::EMIT_WAVES_PER_WG - 1) / k4::EMIT_WAVES_PER_WG)), dim3(64 * k4::EMIT_WAVES_PER_WG), 0, stream, a, pa);
             bool rest = true;          /* (where the host knows the lengths it knows whether there is anything left) */
             if (hostLen) {
                 rest = false;
-                for (int64_t i = 0; i < cnt && !rest; i++) rest = hostLen[first + i] < (int32_t)k4::PARSE_MIN_LEN || hostLen[first + i] >= k4::LIMIT_64K;
+                for (int64_t i = 0; i < cnt && !rest; i++) rest = hostLen[first + i] < (int32_t)k4::PARSE_MIN_LEN || (hostLen[first + i] >= k4::LIMIT_64K && !any_big);
             }
             if (rest)
                 hipLaunchKernelGGL(k4::k4_encode_fast_rest_kernel, dim3((unsigned)((cnt + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, a, pa);
@@ -1412,6 +1428,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     ctx->use_parse = getenv("K4LZ4_NO_PARSE") == nullptr;
     ctx->parse_queue = getenv("K4LZ4_PARSE_QUEUE") != nullptr;
     ctx->parse_persist = getenv("K4LZ4_NO_PERSIST") == nullptr;
+    ctx->parse_big = getenv("K4LZ4_NO_PARSE_BIG") == nullptr;
     ctx->hc_records = getenv("K4LZ4_NO_HC_RECORDS") == nullptr;
     ctx->parse_pcost = getenv("K4LZ4_PCOST") != nullptr;
     ctx->parse_migrate = getenv("K4LZ4_NO_MIGRATE") == nullptr;

@@ -52,6 +52,7 @@ constexpr uint32_t PARSE_REC_STRIDE = 16448u;
 static_assert(PARSE_REC_STRIDE >= ((uint32_t)LIMIT_64K - 1u - 6u) / 4u + 1u + 62u, "a block below LIMIT_64K has at most (LIMIT_64K - 1 - 6) / 4 sequences; a round adds at most 64 / 4 + 1");
 constexpr uint32_t PARSE_MIN_LEN = 128u;             /* shorter blocks go to the other kernels (the clamped loads below want 16 readable bytes somewhere) */
 constexpr uint32_t PARSE_REST = 0xffffffffu;         /* meta[2 b]: this block is for k4_encode_fast_rest_kernel */
+constexpr uint32_t PARSE_BIG = 0xfffffffeu;          /* ... for k4_parse_big_kernel (65 547 bytes and more: byU32 table), which then writes its count */
 constexpr int PARSE_MAX_WAVES = 16;                  /* waves (= blocks) per workgroup: one workgroup per CU */
 constexpr int PARSE_LDS_TABLES = 9;                  /* of which so many have their table in LDS (9 x 16 KiB + 16 x 512 B of 160 KiB) */
 constexpr int PARSE_SEEN_DWORDS = 128;               /* one bit per two hash values */
@@ -67,6 +68,7 @@ struct ParseArgs {
     uint32_t migrate;       /* != 0: blocks without an LDS table move into one when a block of their workgroup is done with it (ParseCtl) */
     uint32_t inline_emit;   /* != 0: the wave that parsed a block writes it out as well (k4_emit_kernel is not launched): the blocks that are
                              * through early do that while the others still parse, only the last ones' bytes come on top of the launch */
+    uint32_t big;           /* != 0: k4_parse_big_kernel follows this launch and takes the blocks of 65 547 bytes and more (needs inline_emit) */
     uint32_t slot_recs;     /* != 0 (with inline_emit): a block's records are written out by the wave that made them, right behind its parse,
                              * so `recs` holds one slot per WAVE of the launch (workgroup x waves per workgroup + wave) instead of one per block:
                              * a launch's scratch is what is resident, whatever the number of blocks */
@@ -144,6 +146,7 @@ constexpr uint32_t HOP_LONG = 0x100u, HOP_LAZY = 0x200u, HOP_END = 0x400u, HOP_I
  * table (LDS, or global memory with GT), `seen`: PARSE_SEEN_DWORDS dwords of LDS.  Returns the number of records written.
  */
 struct ParseStats { uint32_t rounds, slow, groups, lazies, longs; };
+constexpr int PARSE_FLUSH = -2;      /* ParseCtl::claimed: the record slot is nearly full -- write the records out, then resume */
 
 /* A block whose table lives in memory may move into an LDS table that another block of its workgroup has finished with: the
  * waves with LDS tables set their bit in *free_slots when their parse is through; a wave without one looks at the word every 16
@@ -151,16 +154,29 @@ struct ParseStats { uint32_t rounds, slow, groups, lazies, longs; };
  * the slot and calls parse_block's LDS form with `resume`.  The encoder's state between two rounds is just these words. */
 struct ParseCtl {
     uint32_t *free_slots;       /* LDS word of the workgroup, or nullptr */
-    int claimed;                /* out: the slot claimed (parse_block returned early), else -1 */
+    uint32_t rec_cap;           /* in: 0, or the records the block's slot holds -- parse_block returns with claimed = PARSE_FLUSH once a round may overrun it */
+    int claimed;                /* out: the slot claimed (parse_block returned early), PARSE_FLUSH, else -1 */
     bool resume;                /* in: go on from the state below (the table is in place) */
     uint32_t c, sbase, sj, nrec, long_seen, long_rounds;
     bool test, more;
 };      /* what a DRY run counts (the cost estimate's input) */
 
-template <int K, bool GT, bool DRY = false>
-__device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32_t U, uint2 *recs, uint16_t *tab, uint32_t *seen, const int lane, unsigned long long *pc = nullptr,
+/* TT: the table and hash of the block (k4lz4_encode_fast.hpp, FastTable): 1 = byU16 + hash4 (blocks below LIMIT_64K: the case this file
+ * was written for), 0 = byU32 + hash5 (LL64.fast.cs:526-544: 65 547 bytes and more), 2 = byU32 + hash4 (LL32: LZ4Codec.Enforce32).  What
+ * changes with a byU32 table (round 6): a candidate more than 65 535 bytes back is no match (LL64.fast.cs:219-224; it is still put over),
+ * one bit of `seen` per hash value, hash5 reads five bytes, and a match length no longer fits the record's 16 bits -- 0xffff there says
+ * "this or more", counted again where the record is written out.  The record slot of a block holds PARSE_REC_STRIDE records: a longer
+ * block returns to its caller when the slot is nearly full (ParseCtl::flush, like a table migration), has them written out and goes on. */
+template <int K, bool GT, bool DRY = false, int TT = 1>
+__device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32_t U, uint2 *recs, void *tabv, uint32_t *seen, const int lane, unsigned long long *pc = nullptr,
                                                 ParseStats *stats = nullptr, ParseCtl *ctl = nullptr)
 {
+    typedef FastTable<TT> Table;
+    static_assert(TT == 1 || K == 1, "byU32 tables: one sub-window per round");
+    constexpr bool U32 = TT != 1;
+    Table tab;
+    tab.t = (decltype(tab.t))tabv;
+    constexpr uint32_t SEEN_SHIFT = TT == 1 ? 1u : 0u;          /* hash value -> bit of `seen` */
     ParseStats st = {0u, 0u, 0u, 0u, 0u};
 #define K4_ST(field, v) do { if (DRY) st.field += (v); } while (0)
 #ifdef K4_PARSE_PROF
@@ -202,7 +218,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
     const unsigned long long me = 1ull << lane, below_me = me - 1ull;
 
     const bool resumed = ctl && ctl->resume;
-    if (!resumed) for (int k = lane; k < 1024; k += 64) ((uint4 *)tab)[k] = make_uint4(0u, 0u, 0u, 0u);     /* LZ4_initStream; put(hash(0), 0) stores a 0 (:119-122) */
+    if (!resumed) for (int k = lane; k < 1024; k += 64) ((uint4 *)tabv)[k] = make_uint4(0u, 0u, 0u, 0u);     /* LZ4_initStream; put(hash(0), 0) stores a 0 (:119-122) */
     for (int k = lane; k < PARSE_SEEN_DWORDS; k += 64) seen[k] = 0u;
     wave_sync();
 
@@ -222,7 +238,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
     bool tent[K];
     /* the next round's source bytes */
     U128u pw[K];
-    uint32_t pre2 = 0u;
+    uint32_t pre2 = 0u, pre2b = 0u;
     /* Blocks whose matches often run past the 12 bytes a round knows behind every probe (:326-329 then costs a trip to memory in the
      * middle of the chain, ~1500 cycles under load) switch to rounds that know 28: 16 more bytes of every probe and candidate, about
      * 25 more instructions per round.  Decided every 32 rounds from what the rounds before met. */
@@ -255,6 +271,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
             asm("" : "+v"(o2));
 #endif
             pre2 = ld32u(src + o2);
+            if (TT == 0) pre2b = ld32u(src + o2 + 4u);
 #ifdef K4_PARSE_AHEAD
             /* the lines two rounds on: asked for now (after the loads this round's successor waits for, so that its wait does not
              * include them), looked at never -- the asm below only keeps the compiler from dropping the load */
@@ -311,7 +328,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         uint32_t cand[K];
         bool flagged[K];
         uint32_t hE2 = 0xffffffffu;
-        if (test) hE2 = FastTable<1>::hash_of(pre2, 0u);         /* the put of c - 2 (:394): made with the round's other puts, seen by its look-ups */
+        if (test) hE2 = Table::hash_of(pre2, pre2b);         /* the put of c - 2 (:394): made with the round's other puts, seen by its look-ups */
 #pragma unroll
         for (int k = 0; k < K; k++) {
             if (k >= KK) { val[k] = false; h[k] = 0u; pos[k] = 0u; hop[k] = 0u; cpos[k] = 0u; ecode[k] = 0u; seq[k] = n0[k] = n1[k] = n2[k] = 0u; cand[k] = 0u; flagged[k] = false; continue; }
@@ -328,12 +345,12 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
             uint32_t w0 = pw[k].v[0], w1 = pw[k].v[1], w2 = pw[k].v[2], w3 = pw[k].v[3];
             if (!plain) shift16(w0, w1, w2, w3, p < U - 16u ? 0u : p - (U - 16u));
             seq[k] = w0; n0[k] = w1; n1[k] = w2; n2[k] = w3;
-            h[k] = FastTable<1>::hash_of(w0, 0u);
+            h[k] = Table::hash_of(w0, w1);
             uint32_t cd = 0u;
             bool fl = false;
             if (val[k]) {
-                cd = tab[h[k]];
-                const uint32_t bit = h[k] >> 1;
+                cd = tab.get(h[k]);
+                const uint32_t bit = h[k] >> SEEN_SHIFT;
                 fl = ((atomicOr(&seen[bit >> 5], 1u << (bit & 31u)) >> (bit & 31u)) & 1u) != 0u;
             }
             if (h[k] == hE2) cd = c0 - 2u;
@@ -352,7 +369,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         /* (every lane has recorded its hash by now: wipe the words this round touched) */
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < K; k++) if (k < KK && val[k]) seen[h[k] >> 6] = 0u;
+        for (int k = 0; k < K; k++) if (k < KK && val[k]) seen[h[k] >> (5u + SEEN_SHIFT)] = 0u;
 
         /* lanes that share a hash: Dm = those with an earlier lane of the round in their group, Gall = all of them */
         K4_PT(1);
@@ -396,7 +413,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
             if (k >= KK) { hmx[k] = 0ull; hits[k] = 0ull; vis[k] = 0ull; qent[k] = 64u; tent[k] = false; continue; }
             uint32_t v0 = cw[k].v[0], v1 = cw[k].v[1], v2 = cw[k].v[2], v3 = cw[k].v[3];
             if (!plain) shift16(v0, v1, v2, v3, cand[k] < U - 16u ? 0u : cand[k] - (U - 16u));
-            const bool hit = val[k] && v0 == seq[k];
+            const bool hit = val[k] && v0 == seq[k] && (!U32 || pos[k] - cand[k] <= (uint32_t)DISTANCE_MAX);      /* LL64.fast.cs:219-224 */
             uint32_t e = ext12(v1 ^ n0[k], v2 ^ n1[k], v3 ^ n2[k]);
             uint32_t word;
             if (plain) {
@@ -616,7 +633,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                 if (k >= KK) continue;
                 if (hits[k]) {
                     if (!DRY && ((hits[k] >> lane) & 1ull))
-                        rec_store(recs + at + (uint32_t)__popcll(hits[k] & below_me), pos[k], (pos[k] - cpos[k]) | (ecode[k] << 16));
+                        rec_store(recs + at + (uint32_t)__popcll(hits[k] & below_me), pos[k], (pos[k] - cpos[k]) | ((U32 && ecode[k] > 0xffffu ? 0xffffu : ecode[k]) << 16));
                     at += (uint32_t)__popcll(hits[k]);
                 }
             }
@@ -633,12 +650,12 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
             for (int k = 0; k < K; k++) printf("   k=%d qent=%u tent=%d hmx=%016llx hits=%016llx vis=%016llx Dm=%016llx Gall=%016llx\n", k, qent[k], (int)tent[k], hmx[k], hits[k], vis[k], Dm[k], Gall[k]);
         }
 #endif
-        if (hE2 != 0xffffffffu && lane == 0) tab[hE2] = (uint16_t)(c0 - 2u);
+        if (hE2 != 0xffffffffu && lane == 0) tab.put(hE2, c0 - 2u);
         if (GT) wave_sync(); else __builtin_amdgcn_wave_barrier();      /* a lane of the round may put the same slot: it comes second */
 #pragma unroll
         for (int k = 0; k < K; k++) {
             if (k >= KK) continue;
-            if ((vis[k] & ~Gall[k]) >> lane & 1ull) tab[h[k]] = (uint16_t)pos[k];
+            if ((vis[k] & ~Gall[k]) >> lane & 1ull) tab.put(h[k], pos[k]);
         }
 #pragma unroll
         for (int k = 0; k < K; k++) {
@@ -648,7 +665,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                 const int j = ctz64(g);
                 g &= g - 1ull;
                 if (GT) wave_sync(); else __builtin_amdgcn_wave_barrier();
-                if (lane == j) tab[h[k]] = (uint16_t)pos[k];
+                if (lane == j) tab.put(h[k], pos[k]);
             }
         }
         if (GT) wave_sync(); else lds_sync();       /* (never a wait for the records' stores or the next round's loads) */
@@ -675,13 +692,13 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         K4_PHASE("front");
         const uint32_t p = c0 + (uint32_t)lane;
         const uint32_t w0 = pw[0].v[0], w1 = pw[0].v[1], w2 = pw[0].v[2], w3 = pw[0].v[3];
-        const uint32_t hh = FastTable<1>::hash_of(w0, 0u);
-        uint32_t cd = tab[hh];
-        const uint32_t bit = hh >> 1;
+        const uint32_t hh = Table::hash_of(w0, w1);
+        uint32_t cd = tab.get(hh);
+        const uint32_t bit = hh >> SEEN_SHIFT;
         const bool flg = ((atomicOr(&seen[bit >> 5], 1u << (bit & 31u)) >> (bit & 31u)) & 1u) != 0u;
         uint32_t hE2 = 0xffffffffu;
         if (test) {
-            hE2 = FastTable<1>::hash_of(pre2, 0u);
+            hE2 = Table::hash_of(pre2, pre2b);
             if (hh == hE2) cd = c0 - 2u;
         }
         K4_PT(0);
@@ -689,7 +706,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         U128u cw2 = {{0u, 0u, 0u, 0u}};
         if (MORE) cw2 = ld128u(src + cd + 16u);
         __builtin_amdgcn_wave_barrier();
-        seen[hh >> 6] = 0u;
+        seen[hh >> (5u + SEEN_SHIFT)] = 0u;
         /* groups */
         K4_PT(1);
         K4_PHASE("groups");
@@ -708,7 +725,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
             }
         }
         K4_PHASE("words");
-        const bool hit = cw.v[0] == w0;
+        const bool hit = cw.v[0] == w0 && (!U32 || p - cd <= (uint32_t)DISTANCE_MAX);      /* LL64.fast.cs:219-224 */
         uint32_t e;
         if (MORE) {
             const uint32_t x[7] = {cw.v[1] ^ w1, cw.v[2] ^ w2, cw.v[3] ^ w3, cw2.v[0] ^ pw2.v[0], cw2.v[1] ^ pw2.v[1], cw2.v[2] ^ pw2.v[2], cw2.v[3] ^ pw2.v[3]};
@@ -809,7 +826,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         K4_PHASE("records");
         K4_TICC();
         if (hts) {
-            if (!DRY && mine) rec_store(recs + nrec + (uint32_t)__popcll(hts & below_me), p, (p - cp) | (ec << 16));
+            if (!DRY && mine) rec_store(recs + nrec + (uint32_t)__popcll(hts & below_me), p, (p - cp) | ((U32 && ec > 0xffffu ? 0xffffu : ec) << 16));
             nrec += (uint32_t)__popcll(hts);
         }
         K4_TOCC(7);
@@ -833,13 +850,20 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         K4_PHASE("commit");
         /* one writer per slot: of the visited lanes of a group the highest (the latest position is what a slot holds in the end); the
          * put of c0 - 2 (:394) came before all of them and stands only where none of them has its hash */
-        if (hE2 != 0xffffffffu && (ballot(hh == hE2) & vm) == 0ull && lane == 0) tab[hE2] = (uint16_t)(c0 - 2u);
-        if (((vm >> lane) & 1ull) && (G & vm & ~(below_me | me)) == 0ull) tab[hh] = (uint16_t)p;
+        if (hE2 != 0xffffffffu && (ballot(hh == hE2) & vm) == 0ull && lane == 0) tab.put(hE2, c0 - 2u);
+        if (((vm >> lane) & 1ull) && (G & vm & ~(below_me | me)) == 0ull) tab.put(hh, p);
         if (GT) wave_sync(); else lds_sync();       /* (never a wait for the records' stores or the next round's loads) */
         K4_PT(5);
         return true;
     };
+    const uint32_t rec_cap = ctl ? ctl->rec_cap : 0u;
     for (;;) {
+        if (U32 && rec_cap && nrec + 64u * (uint32_t)K + 2u > rec_cap) {
+            ctl->c = c; ctl->sbase = sbase; ctl->sj = sj; ctl->nrec = nrec; ctl->test = test; ctl->more = more;
+            ctl->long_seen = long_seen; ctl->long_rounds = long_rounds;
+            ctl->claimed = PARSE_FLUSH;
+            return nrec;
+        }
         if (GT && ctl && ctl->free_slots && (++mig_tick & 15u) == 0u) {
             const uint32_t fs = uni(*(volatile uint32_t *)ctl->free_slots);
             if (fs) {
@@ -884,12 +908,23 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 
-template <bool HC = false>
-__device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, uint8_t *dst, const int dst_cap, const uint2 *recs, const uint32_t nseq, const int lane);
+/* where a block's write-out stands between two calls (a block longer than its record slot is written out a slot-full at a time) */
+struct EmitState { uint32_t op, emitted_to; };
+template <bool HC = false, bool BIG = false>
+__device__ __forceinline__ bool emit_records(const uint8_t *src, const uint32_t U, uint8_t *dst, const int dst_cap, const uint2 *recs, const uint32_t nseq, const int lane, EmitState &st);
+__device__ __forceinline__ int emit_tail(const uint8_t *src, const uint32_t U, uint8_t *dst, const int dst_cap, const int lane, const EmitState &st);
+template <bool HC = false, bool BIG = false>
+__device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, uint8_t *dst, const int dst_cap, const uint2 *recs, const uint32_t nseq, const int lane)
+{
+    EmitState st = {0u, 0u};
+    if (!emit_records<HC, BIG>(src, U, dst, dst_cap, recs, nseq, lane, st)) return 0;
+    return emit_tail(src, U, dst, dst_cap, lane, st);
+}
 
-template <int K>
+template <int K, int TT = 1>
 __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const ParseArgs &p, uint32_t *lds)
 {
+    constexpr bool U32 = TT != 1;
     const int lane = lane_id();
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t waves = blockDim.x >> 6;
@@ -920,8 +955,12 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
         const long long b = a.order ? (long long)uni(a.order[idx]) : idx;
         const int src_len = a.srcLen[b];
         uint32_t *meta = p.meta + 2ull * (unsigned long long)b;
-        if (src_len < (int)PARSE_MIN_LEN || src_len >= LIMIT_64K || a.accel != 1) {
-            if (lane == 0) { meta[0] = PARSE_REST; meta[1] = 0u; }
+        /* whose block: this launch's (byU16: 128 .. 65 546 bytes; the byU32 launch behind it: 65 547 and more), the byU32 launch's
+         * (marked PARSE_BIG by the first one when there is going to be one), or the one-kernel encoder's (PARSE_REST) */
+        const bool big = src_len >= LIMIT_64K && a.accel == 1;
+        const bool mine = a.accel == 1 && (U32 ? big : (src_len >= (int)PARSE_MIN_LEN && src_len < LIMIT_64K));
+        if (!mine) {
+            if (!U32 && lane == 0) { meta[0] = (big && p.big) ? PARSE_BIG : PARSE_REST; meta[1] = 0u; }
         } else {
             const uint8_t *src = a.src + a.srcOff[b];
             uint2 *recs = p.recs + (p.slot_recs ? (unsigned long long)blockIdx.x * waves + wave : (unsigned long long)b) * PARSE_REC_STRIDE;
@@ -935,25 +974,47 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
 #ifndef K4_PARSE_PROF
             if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 8, lane);
 #endif
-            if (in_lds) {
-                n = parse_block<K, false>(src, (uint32_t)src_len, recs, (uint16_t *)(lds + 4096u * wave), seen, lane, pc);
-                if (free_slots && !p.queue && lane == 0) atomicOr(free_slots, 1u << wave);        /* this wave's table is free now */
-            } else {
-                uint32_t *gt = p.gtab + 4096ull * ((unsigned long long)blockIdx.x * PARSE_MAX_WAVES + wave);
-                ParseCtl ctl;
-                ctl.free_slots = free_slots; ctl.claimed = -1; ctl.resume = false;
-                n = parse_block<K, true>(src, (uint32_t)src_len, recs, (uint16_t *)gt, seen, lane, pc, nullptr, &ctl);
-                if (ctl.claimed >= 0) {
+            /* One call of parse_block is the whole block unless it comes back early: with a claim on an LDS table that has become free
+             * (the table moves, the LDS form goes on), or -- byU32 blocks, which may hold more sequences than a record slot -- with a
+             * slot-full of records to be written out before it goes on (PARSE_FLUSH). */
+            const int cap = a.dstCap[b];
+            uint8_t *dst = a.dst + a.dstOff[b];
+            EmitState est = {0u, 0u};
+            bool room = true;
+            uint32_t *gt = p.gtab + 4096ull * ((unsigned long long)blockIdx.x * PARSE_MAX_WAVES + wave);
+            uint32_t *table = in_lds ? lds + 4096u * wave : gt;
+            bool table_in_lds = in_lds;
+            int my_slot = -1;                    /* an LDS table this wave moved into (to be given back) */
+            ParseCtl ctl = {};
+            ctl.free_slots = in_lds ? nullptr : free_slots; ctl.claimed = -1; ctl.resume = false;
+            ctl.rec_cap = U32 ? PARSE_REC_STRIDE : 0u;
+            for (;;) {
+                if (table_in_lds) n = parse_block<K, false, false, TT>(src, (uint32_t)src_len, recs, table, seen, lane, pc, nullptr, (U32 || ctl.resume) ? &ctl : nullptr);
+                else n = parse_block<K, true, false, TT>(src, (uint32_t)src_len, recs, table, seen, lane, pc, nullptr, &ctl);
+                if (U32 && ctl.claimed == PARSE_FLUSH) {
+                    wave_sync();                 /* the records are this wave's own stores: in order with the loads that follow */
+                    if (room && !emit_records<false, true>(src, (uint32_t)src_len, dst, cap < 0 ? 0 : cap, recs, n, lane, est)) room = false;
+                    wave_sync();
+                    if (!room) { n = 0u; break; }            /* the output does not fit (:251-255, :346-350): the block fails, no need to go on */
+                    ctl.nrec = 0u; ctl.resume = true; ctl.claimed = -1;
+                    continue;
+                }
+                if (ctl.claimed >= 0) {          /* a table of the workgroup has become free: move in */
                     moved = true;
                     uint32_t *slot = lds + 4096u * (uint32_t)ctl.claimed;
 #pragma unroll 4
                     for (int k = lane; k < 1024; k += 64) ((uint4 *)slot)[k] = ((const uint4 *)gt)[k];
                     wave_sync();
-                    ctl.resume = true; ctl.free_slots = nullptr;
-                    const int sl = ctl.claimed;
-                    n = parse_block<K, false>(src, (uint32_t)src_len, recs, (uint16_t *)slot, seen, lane, pc, nullptr, &ctl);
-                    if (lane == 0) atomicOr(free_slots, 1u << sl);                                /* ... and free again for the next one */
+                    my_slot = ctl.claimed;
+                    table = slot; table_in_lds = true;
+                    ctl.resume = true; ctl.free_slots = nullptr; ctl.claimed = -1;
+                    continue;
                 }
+                break;
+            }
+            if (free_slots && lane == 0) {
+                if (my_slot >= 0) atomicOr(free_slots, 1u << my_slot);                 /* ... and free again for the next one */
+                else if (in_lds && !p.queue) atomicOr(free_slots, 1u << wave);          /* this wave's table is free now */
             }
 #ifdef K4_PARSE_PROF
             if (a.prof) { if (lane == 0) { pc[9] = __builtin_amdgcn_s_memrealtime(); pc[15] = in_lds ? 1u : 2u; } }
@@ -966,8 +1027,9 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
 #endif
             if (p.inline_emit) {
                 wave_sync();                 /* the records are this wave's own stores: in order with the loads that follow */
-                const int cap = a.dstCap[b];
-                const int ret = emit_block(src, (uint32_t)src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, recs, n, lane);
+                int ret = 0;
+                if (room && emit_records<false, U32>(src, (uint32_t)src_len, dst, cap < 0 ? 0 : cap, recs, n, lane, est))
+                    ret = emit_tail(src, (uint32_t)src_len, dst, cap < 0 ? 0 : cap, lane, est);
                 if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
             }
 #ifndef K4_PARSE_PROF
@@ -983,6 +1045,15 @@ __global__ __launch_bounds__(64 * PARSE_MAX_WAVES) void k4_parse_kernel(BatchArg
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[PARSE_LDS_DWORDS];
     parse_kernel_body<K4_PARSE_K>(a, p, lds);
+}
+
+/* The same for the blocks of 65 547 bytes and more (round 6): byU32 table, hash5 (LL64.fast.cs:526-544) or -- LZ4Codec.Enforce32 --
+ * hash4 (x32/LL32.tools.cs:141-148); a kernel of its own so that k4_parse_kernel stays the code the bench batch was tuned on. */
+__global__ __launch_bounds__(64 * PARSE_MAX_WAVES) void k4_parse_big_kernel(BatchArgs a, ParseArgs p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[PARSE_LDS_DWORDS];
+    if (a.flags & FLAG_X32) parse_kernel_body<1, 2>(a, p, lds);
+    else parse_kernel_body<1, 0>(a, p, lds);
 }
 
 /* ------------------------------------------------------------------------------------------------------------------ */
@@ -1063,12 +1134,13 @@ constexpr int EMIT_WAVES_PER_WG = 4;
 /* HC: the records of the hash-chain parse (k4lz4_encode_hc.hpp, round 6) -- LZ4HC_encodeSequence (LL64.high.cs:435-510) writes the same
  * format from the same four numbers; what differs is that its match starts are final (no backward extension here: LZ4HC_countBack
  * ran inside the search) and its second output-limit test (:484: op + length / 255 + (1 + LASTLITERALS) > oend, against :346-350) */
-template <bool HC>
-__device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, uint8_t *dst, const int dst_cap, const uint2 *recs, const uint32_t nseq, const int lane)
+/* BIG: records of a byU32 block -- a match length code of 0xffff says "this or more" and is counted again here (LL64.fast.cs:326-329) */
+template <bool HC, bool BIG>
+__device__ __forceinline__ bool emit_records(const uint8_t *src, const uint32_t U, uint8_t *dst, const int dst_cap, const uint2 *recs, const uint32_t nseq, const int lane, EmitState &st)
 {
     const bool limited = dst_cap < compress_bound((int)U);         /* :524 */
     const uint64_t olimit = (uint64_t)(dst_cap < 0 ? 0 : dst_cap);
-    uint32_t op = 0u, emitted_to = 0u;
+    uint32_t op = st.op, emitted_to = st.emitted_to;
     uint2 rn = make_uint2(0u, 0u);
     if ((uint32_t)lane < nseq) rn = rec_load(recs + lane);
     for (uint32_t base = 0u; base < nseq; base += 64u) {
@@ -1076,7 +1148,18 @@ __device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, 
         const bool mine = (uint32_t)lane < n;
         const uint2 r = rn;
         if (base + 64u + (uint32_t)lane < nseq) rn = rec_load(recs + base + 64u + (uint32_t)lane);      /* the next 64, while these are written */
-        const uint32_t pos = r.x, cpos = r.x - (r.y & 0xffffu), code = r.y >> 16;
+        const uint32_t pos = r.x, cpos = r.x - (r.y & 0xffffu);
+        uint32_t code = r.y >> 16;
+        if (BIG) {
+            unsigned long long lng = ballot(mine && code == 0xffffu);
+            while (lng) {
+                const int g = ctz64(lng);
+                lng &= lng - 1ull;
+                const uint32_t gp = readlane_u32(pos, g), gc = readlane_u32(cpos, g);
+                const uint32_t full = wave_count(src + gp + (uint32_t)MINMATCH, src + gc + (uint32_t)MINMATCH, (U - (uint32_t)LASTLITERALS) - (gp + (uint32_t)MINMATCH), lane);
+                if (lane == g) code = full;
+            }
+        }
         const uint32_t end = mine ? pos + (uint32_t)MINMATCH + code : 0u;
         const uint32_t prev = (uint32_t)__shfl_up((int)end, 1);
         const uint32_t ls = lane == 0 ? emitted_to : prev;
@@ -1132,7 +1215,7 @@ __device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, 
         if (limited) {                                      /* :251-255, :346-350 */
             const bool fail = mine && ((uint64_t)o_tok + 1u + ll + (2 + 1 + LASTLITERALS) + ll / 255u > olimit ||
                                        (uint64_t)o_mx + (1 + LASTLITERALS) + (HC ? mc / 255u : (mc + 240u) / 255u) > olimit);
-            if (ballot(fail)) return 0;
+            if (ballot(fail)) return false;
         }
         if (mine) {
             st8_out(dst + o_tok, (uint8_t)(((ll < (uint32_t)RUN_MASK ? ll : (uint32_t)RUN_MASK) << ML_BITS) |
@@ -1167,7 +1250,17 @@ __device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, 
         op += total;
         emitted_to = readlane_u32(end, (int)n - 1);
     }
-    /* ---- _last_literals (:469-503) ---- */
+    st.op = op; st.emitted_to = emitted_to;
+    return true;
+}
+
+/* ---- _last_literals (:469-503; LZ4HC's :751-787 are the same bytes and the same test) ---- */
+__device__ __forceinline__ int emit_tail(const uint8_t *src, const uint32_t U, uint8_t *dst, const int dst_cap, const int lane, const EmitState &st)
+{
+    const bool limited = dst_cap < compress_bound((int)U);
+    const uint64_t olimit = (uint64_t)(dst_cap < 0 ? 0 : dst_cap);
+    uint32_t op = st.op;
+    const uint32_t emitted_to = st.emitted_to;
     const uint32_t last_run = U - emitted_to;
     if (limited && (uint64_t)op + last_run + 1u + (last_run + 255u - RUN_MASK) / 255u > olimit) return 0;
     if (last_run >= (uint32_t)RUN_MASK) {
@@ -1189,7 +1282,7 @@ __global__ __launch_bounds__(64 * EMIT_WAVES_PER_WG) void k4_emit_kernel(BatchAr
     const long long b = (long long)blockIdx.x * EMIT_WAVES_PER_WG + (long long)uni(threadIdx.x >> 6);
     if (b >= a.n) return;
     const uint32_t nseq = uni(p.meta[2ull * (unsigned long long)b]);
-    if (nseq == PARSE_REST) return;
+    if (nseq == PARSE_REST || nseq == PARSE_BIG) return;
     const int src_len = a.srcLen[b];
     const int cap = a.dstCap[b];
     const int ret = emit_block(a.src + a.srcOff[b], (uint32_t)src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap,

@@ -113,6 +113,10 @@ template <int K> static void emu_parse_launch(const k4::BatchArgs &a, const k4::
         k4::parse_kernel_body<K>(a, p, lds);
     }, threads);
 }
+static void emu_parse_big_launch(const k4::BatchArgs &a, const k4::ParseArgs &p, unsigned waves, int threads)
+{
+    k4emu::launch_fn(dim3(p.nwg), dim3(64 * waves), [=] { k4::k4_parse_big_kernel(a, p); }, threads);
+}
 extern "C" {
 int k4emu_encode_parse_batch(const uint8_t *src, const uint64_t *srcOff, const int32_t *srcLen, uint8_t *dst,
                              const uint64_t *dstOff, const int32_t *dstCap, int32_t *outLen, long long n, int accel, int flags,
@@ -140,7 +144,8 @@ int k4emu_encode_parse_batch(const uint8_t *src, const uint64_t *srcOff, const i
     p.recs = recs.data(); p.meta = meta.data(); p.gtab = gtab.data();
     p.inline_emit = inline_emit ? 1u : 0u;
     p.migrate = migrate ? 1u : 0u;
-    std::vector<uint32_t> q(4, 0u);
+    std::vector<uint32_t> q(8, 0u);
+    p.big = inline_emit ? 1u : 0u;                      /* blocks of 65 547 bytes and more: k4_parse_big_kernel behind the first launch */
     std::vector<uint32_t> ident;
     if (use_queue) {
         p.queue = q.data();
@@ -151,13 +156,18 @@ int k4emu_encode_parse_batch(const uint8_t *src, const uint64_t *srcOff, const i
     else if (K == 2) emu_parse_launch<2>(a, p, (unsigned)waves, threads);
     else if (K == 3) emu_parse_launch<3>(a, p, (unsigned)waves, threads);
     else emu_parse_launch<4>(a, p, (unsigned)waves, threads);
+    if (p.big) {
+        k4::ParseArgs pb = p;
+        if (use_queue) pb.queue = q.data() + 4;
+        emu_parse_big_launch(a, pb, (unsigned)waves, threads);
+    }
     if (!inline_emit) k4emu::launch_fn(dim3((unsigned)((n + k4::EMIT_WAVES_PER_WG - 1) / k4::EMIT_WAVES_PER_WG)), dim3(64 * k4::EMIT_WAVES_PER_WG), [=] { k4::k4_emit_kernel(a, p); }, threads);
     k4emu::launch_fn(dim3((unsigned)((n + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG), [=] { k4::k4_encode_fast_rest_kernel(a, p); }, threads);
     if (nseq_out) for (long long i = 0; i < n; i++) nseq_out[i] = meta[(size_t)i * 2];
     if (!slot_recs)                                     /* per-block slots: exactly the counted records were written */
         for (long long i = 0; i < n; i++) {
             const uint32_t m = meta[(size_t)i * 2];
-            if (m == k4::PARSE_REST) continue;
+            if (m == k4::PARSE_REST || m == k4::PARSE_BIG || srcLen[i] >= k4::LIMIT_64K) continue;
             if (m > k4::PARSE_REC_STRIDE) return -2;
             for (size_t r = m; r < k4::PARSE_REC_STRIDE; r++)
                 if (recs[(size_t)i * k4::PARSE_REC_STRIDE + r].x != 0xA5A5A5A5u || recs[(size_t)i * k4::PARSE_REC_STRIDE + r].y != 0x5A5A5A5Au) return -3;

@@ -90,13 +90,51 @@ def test_encode_parse_emit_matches_oracle(emu, oracle, k, waves, how):
             continue
         got = dst[int(doff[i]):int(doff[i]) + max(int(out[i]), 0)].tobytes()
         assert out[i] == len(want) and got == want, f"block {i} ({b.size} B)"
-        assert (nseq[i] == 0xFFFFFFFF) == (b.size < 128 or b.size >= 65547), f"block {i} ({b.size} B): who encoded it"
-        if nseq[i] != 0xFFFFFFFF:
+        # (65 547 bytes and more: k4_parse_big_kernel where the parsing waves write out themselves, else the one-kernel encoder)
+        assert (nseq[i] == 0xFFFFFFFF) == (b.size < 128 or (b.size >= 65547 and "inline" not in how)), f"block {i} ({b.size} B): who encoded it"
+        if nseq[i] != 0xFFFFFFFF and b.size < 65547:
             assert nseq[i] == oracle.count_sequences(np.frombuffer(want, np.uint8)) - 1, f"block {i}: sequences"
     mask = np.ones(dst.size, bool)
     for i in range(len(blocks)):
         mask[int(doff[i]):int(doff[i]) + max(int(out[i]), 0)] = False
     assert (dst[mask] == 0xCD).all()
+
+
+@pytest.mark.parametrize("waves,how,x32", [(16, "inline+migrate+slots", False), (5, "inline+queue+slots", False), (12, "inline+slots", True), (16, "inline+queue+migrate+slots", True)])
+def test_encode_parse_big_blocks_matches_oracle(emu, oracle, waves, how, x32):
+    """round 6: blocks of 65 547 bytes and more -- byU32 table, hash5 (LL64.fast.cs:526-544), or hash4 with LZ4Codec.Enforce32
+    (x32/LL32.tools.cs:141-148) -- through k4_parse_big_kernel: candidates more than 65 535 bytes back are no matches
+    (LL64.fast.cs:219-224), match lengths beyond the record's 16 bits are counted again at the write-out, and a block with more
+    sequences than its record slot holds is written out a slot-full at a time (the dense block below: ~21 000 sequences against
+    16 448 records).  Full and ragged output limits; small blocks in the same batch keep their kernel."""
+    rng = np.random.default_rng(12)
+    sizes = [65547, 65548, 70000, 100000, 131072, 200000, 262144 + 77, 400000]
+    blocks = [corpus.class_bytes(corpus.SILESIA_NAMES[(3 * i) % 12], n, 31 + i) for i, n in enumerate(sizes)]
+    blocks.append(np.concatenate([corpus.lorem(3000), corpus.repeated(0x55, 150000), corpus.lorem(2000)]))             # a match of 150 000 bytes: length code beyond 16 bits
+    blocks.append(np.concatenate([corpus.class_bytes("xml", 40000, 2), rng.integers(0, 256, 80000, dtype=np.uint8), corpus.class_bytes("xml", 40000, 2)]))   # the same text 120 000 bytes on: too far
+    blocks.append(np.concatenate([rng.integers(0, 256, 70000, dtype=np.uint8), corpus.lorem(5000)]))                  # the step grows and grows, then matches again
+    import adversarial_blocks
+    blocks.append(np.tile(adversarial_blocks.dense_four_byte_matches(128, 65536, 128)[:43000], 2))                      # more sequences than a record slot
+    blocks += [corpus.lorem(n) for n in (100, 5000, 65546)] + [corpus.class_bytes("mr", 40000, 3)]                      # the other kernel's
+    caps = []
+    for b in blocks:
+        bound = oracle.compress_bound(b.size)
+        caps.append(bound)
+    blocks2, caps2 = list(blocks), list(caps)
+    for b in blocks[:6]:                                    # the same blocks with output limits: exact fit, one byte short, half
+        r, _ = (oracle.compress_fast_x32 if x32 else oracle.compress_fast)(b)
+        for c in (r, r - 1, r // 2):
+            blocks2.append(b); caps2.append(c)
+    src, soff, slen = pack(blocks2)
+    dst, doff, dcap = arena(caps2)
+    out, nseq = emu.encode_parse_batch(src, soff, slen, dst, doff, dcap, flags=FLAG_RAW | (128 if x32 else 0), k=1, waves=waves, inline_emit=True, queue="queue" in how, migrate="migrate" in how, slot_recs=True, threads=8)
+    for i, (b, cap) in enumerate(zip(blocks2, caps2)):
+        r, w = (oracle.compress_fast_x32 if x32 else oracle.compress_fast)(b, cap)
+        assert out[i] == max(r, 0), (i, b.size, cap, out[i], r)
+        if r > 0:
+            assert dst[int(doff[i]):int(doff[i]) + r].tobytes() == w[:r].tobytes(), (i, b.size, cap)
+            assert (dst[int(doff[i]) + r:int(doff[i]) + cap + 16] == 0xCD).all(), (i, b.size, cap)
+        assert (nseq[i] == 0xFFFFFFFF) == (b.size < 128)      # nothing of 128 bytes and more is the one-kernel encoder's
 
 
 def test_encode_parse_block_ends_randomised(emu, oracle):
