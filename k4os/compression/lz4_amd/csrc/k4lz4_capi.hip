@@ -115,6 +115,7 @@ struct k4lz4_ctx {
     bool use_parse = true;                /* K4LZ4_NO_PARSE: fast-level batches go to the one-kernel encoders as before */
     bool parse_queue = false;             /* K4LZ4_PARSE_QUEUE */
     bool hc_records = true;               /* K4LZ4_NO_HC_RECORDS: level 3 writes its sequences out inside the parse loop (rounds 1-5) */
+    bool parse_seg = true;                /* K4LZ4_NO_PARSE_SEG: ragged batches (pickles, K4LZ4_FLAG_SEGMENTS) through the one-kernel encoders and their *_seg twins (rounds 3-5) */
     bool parse_big = true;                /* K4LZ4_NO_PARSE_BIG: blocks of 65 547 bytes and more stay with the one-kernel encoder (round 5) */
     bool parse_persist = true;            /* K4LZ4_NO_PERSIST: batches beyond one residency in launches of one residency each (round 5) instead of one persistent launch */
     bool parse_inline_emit = true;        /* K4LZ4_NO_INLINE_EMIT: the blocks' bytes by k4_emit_kernel behind the parse instead of by the parsing waves themselves */
@@ -415,6 +416,11 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
     /* round 6: the two-step encoder takes a batch beyond one residency in ONE persistent launch -- one workgroup of sixteen waves per
      * CU, every wave takes the next block of the cost order when it is done with one (the waves with LDS tables from the expensive
      * end, the others from the cheap end), records in per-wave slots -- instead of launches of one residency each with their own tail */
+    /* round 6: ragged batches -- pickles, K4LZ4_FLAG_SEGMENTS -- through the two-step encoder as well: the blocks below 65 547 bytes by
+     * k4_parse_kernel, the others (and the later segments of the cut ones) by k4_parse_seg_kernel, the join as before */
+    const bool parse_seg_path = kind == KIND_ENCODE && level < K4LZ4_L03_HC && ctx->use_parse && ctx->parse_big && ctx->parse_seg && ctx->parse_inline_emit &&
+                                ctx->accel == 1 && !ctx->prof && (flags & (FLAG_SEGMENTS_OK | K4LZ4_FLAG_SEGMENTS)) != 0 &&
+                                !(flags & (K4LZ4_FLAG_NO_SPLIT | K4LZ4_FLAG_NO_REORDER | K4LZ4_FLAG_ALLOW_COPY));
     const bool parse_persistent = parse_path && ctx->parse_persist && ctx->parse_inline_emit && !ctx->prof && n > (int64_t)k4::PARSE_MAX_WAVES * (int64_t)ctx->cu_count &&
                                   !(flags & K4LZ4_FLAG_NO_REORDER);
     if (kind == KIND_ENCODE && level < K4LZ4_L03_HC && !(flags & (FLAG_SEGMENTS_OK | K4LZ4_FLAG_SEGMENTS | K4LZ4_FLAG_NO_SPLIT)) &&
@@ -588,7 +594,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
          * sequences (one wavefront per block, 64 x K positions per round, 16 blocks per workgroup = per CU dealt from the cost
          * order, the nine most expensive of a workgroup with their table in LDS), then their bytes (a throughput kernel), then
          * whatever block the parse left alone (65 547 bytes and more, very short ones) by the one-kernel encoder. */
-        bool parse_here = kind == KIND_ENCODE && parse_path;
+        bool parse_here = kind == KIND_ENCODE && (parse_path || (parse_seg_path && (a.order || cnt == 1)));
         /* blocks of 65 547 bytes and more (byU32 tables) go through k4_parse_big_kernel behind the first launch -- where the parsing
          * waves write their blocks out themselves (a big block has more sequences than a record slot holds) */
         const bool big_ok = ctx->parse_big && ctx->parse_inline_emit;
@@ -602,20 +608,23 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             }
             parse_here = any_small || any_big;
         }
-        int64_t waves = 0, nwg = 0;
+        int64_t waves = 0, nwg = 0, nwg_seg = 0;
+        const bool seg_two_step = seg && parse_here && parse_seg_path;      /* (seg: the plan has been made above) */
         bool queue = false, slot_recs = false;
         size_t o_meta = 0, o_gtab = 0;
         if (parse_here) {
             waves = std::max<int64_t>(1, std::min<int64_t>(ctx->parse_waves, (cnt + ctx->cu_count - 1) / ctx->cu_count));
             /* K4LZ4_PARSE_QUEUE, and every batch beyond one residency: one workgroup per CU at most, every wave takes the next block of
              * the cost order when it is done with one */
-            queue = (ctx->parse_queue || parse_persistent) && a.order && cnt > waves * (int64_t)ctx->cu_count;
+            queue = (ctx->parse_queue || parse_persistent || parse_seg_path) && a.order && cnt > waves * (int64_t)ctx->cu_count;
             nwg = queue ? (int64_t)ctx->cu_count : (cnt + waves - 1) / waves;
+            /* the segments' launch: always sixteen waves per workgroup, one workgroup per CU at most, everything from its queue */
+            if (seg_two_step) nwg_seg = std::min<int64_t>(ctx->cu_count, (cnt + (int64_t)sg.max_items + k4::PARSE_MAX_WAVES - 1) / k4::PARSE_MAX_WAVES);
             /* records: a slot per wave of the launch where the parsing waves write their blocks out themselves, else one per block */
             slot_recs = ctx->parse_inline_emit;
-            const size_t rec_slots = slot_recs ? (size_t)nwg * (size_t)waves : (size_t)cnt;
+            const size_t rec_slots = slot_recs ? std::max((size_t)nwg * (size_t)waves, (size_t)nwg_seg * k4::PARSE_MAX_WAVES) : (size_t)cnt;
             o_meta = rec_slots * k4::PARSE_REC_STRIDE * sizeof(uint2); o_gtab = (o_meta + (size_t)cnt * 8 + 64 + 255) & ~(size_t)255;
-            const size_t need = o_gtab + (waves > k4::PARSE_LDS_TABLES ? (size_t)nwg * k4::PARSE_MAX_WAVES * 16384 : 0);
+            const size_t need = o_gtab + std::max(waves > k4::PARSE_LDS_TABLES ? (size_t)nwg * k4::PARSE_MAX_WAVES * 16384 : 0, (size_t)nwg_seg * k4::PARSE_MAX_WAVES * 16384);
             if (need > ctx->d_parse_cap) K4_HIP(ctx, hipStreamSynchronize(stream));
             const int rcp = grow(ctx, &ctx->d_parse, &ctx->d_parse_cap, need, false);
             /* (no room for the records: the one-kernel encoders below need next to none -- the same bytes, a third slower) */
@@ -629,13 +638,18 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             pa.slot_recs = slot_recs ? 1u : 0u;
             pa.migrate = ctx->parse_migrate ? 1u : 0u;
             pa.big = any_big ? 1u : 0u;
-            if (queue) {
-                pa.queue = pa.meta + 2 * cnt;
-                K4_HIP(ctx, hipMemsetAsync(pa.queue, 0, 32, stream));
+            if (queue || seg_two_step) {
+                K4_HIP(ctx, hipMemsetAsync(pa.meta + 2 * cnt, 0, 32, stream));
+                if (queue) pa.queue = pa.meta + 2 * cnt;
             }
             /* (the first launch also says whose every block is -- PARSE_BIG / PARSE_REST --, so it runs even without a block of its own) */
             hipLaunchKernelGGL(k4::k4_parse_kernel, dim3((unsigned)nwg), dim3((unsigned)(64 * waves)), 0, stream, a, pa);
-            if (any_big) {
+            if (seg_two_step) {
+                k4::ParseArgs pb = pa;
+                pb.queue = pa.meta + 2 * cnt + 4;
+                pb.nwg = (uint32_t)nwg_seg;
+                hipLaunchKernelGGL(k4::k4_parse_seg_kernel, dim3((unsigned)nwg_seg), dim3(64 * k4::PARSE_MAX_WAVES), 0, stream, a, pb, sg);
+            } else if (any_big) {
                 k4::ParseArgs pb = pa;
                 if (queue) pb.queue = pa.queue + 4;
                 hipLaunchKernelGGL(k4::k4_parse_big_kernel, dim3((unsigned)nwg), dim3((unsigned)(64 * waves)), 0, stream, a, pb);
@@ -649,6 +663,8 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             }
             if (rest)
                 hipLaunchKernelGGL(k4::k4_encode_fast_rest_kernel, dim3((unsigned)((cnt + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG), 0, stream, a, pa);
+            if (seg_two_step)            /* the cut blocks' pieces: joined, or encoded again (k4lz4_segments.hpp) */
+                hipLaunchKernelGGL(k4::k4_seg_join_kernel, dim3((unsigned)std::min<int64_t>(k4::SEG_MAX_BLOCKS, cnt)), dim3(64), 0, stream, a, sg);
             if (flags & K4LZ4_FLAG_ALLOW_COPY)
                 hipLaunchKernelGGL(k4::k4_allow_copy_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, stream, a);
             K4_HIP(ctx, hipGetLastError());
@@ -1429,6 +1445,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     ctx->parse_queue = getenv("K4LZ4_PARSE_QUEUE") != nullptr;
     ctx->parse_persist = getenv("K4LZ4_NO_PERSIST") == nullptr;
     ctx->parse_big = getenv("K4LZ4_NO_PARSE_BIG") == nullptr;
+    ctx->parse_seg = getenv("K4LZ4_NO_PARSE_SEG") == nullptr;
     ctx->hc_records = getenv("K4LZ4_NO_HC_RECORDS") == nullptr;
     ctx->parse_pcost = getenv("K4LZ4_PCOST") != nullptr;
     ctx->parse_migrate = getenv("K4LZ4_NO_MIGRATE") == nullptr;

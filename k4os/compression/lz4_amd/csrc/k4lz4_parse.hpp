@@ -159,6 +159,8 @@ struct ParseCtl {
     bool resume;                /* in: go on from the state below (the table is in place) */
     uint32_t c, sbase, sj, nrec, long_seen, long_rounds;
     bool test, more;
+    uint32_t cut_pos;           /* segments (SegRun): where the run's next cut lies, whether it is still warming up; */
+    bool dry, stopped;          /* out: parse_block returned because the run stopped at its boundary (sr->state says how), not at the block's end */
 };      /* what a DRY run counts (the cost estimate's input) */
 
 /* TT: the table and hash of the block (k4lz4_encode_fast.hpp, FastTable): 1 = byU16 + hash4 (blocks below LIMIT_64K: the case this file
@@ -167,10 +169,17 @@ struct ParseCtl {
  * one bit of `seen` per hash value, hash5 reads five bytes, and a match length no longer fits the record's 16 bits -- 0xffff there says
  * "this or more", counted again where the record is written out.  The record slot of a block holds PARSE_REC_STRIDE records: a longer
  * block returns to its caller when the slot is nearly full (ParseCtl::flush, like a table migration), has them written out and goes on. */
-template <int K, bool GT, bool DRY = false, int TT = 1>
+/* SEG (byU32 blocks only): the block is one of several runs over a big block (k4lz4_encode_fast.hpp, SegRun; k4lz4_segments.hpp says who
+ * gets what).  The run starts at sr->begin as a fresh encoder would; a warm run (emit_from != 0) writes no record before its CUT -- its
+ * first match end at or behind emit_from --, where it publishes cut and table and goes on as the block's encoder; every run stops at
+ * its first match end at or behind stop_at, and says whether the next run's published cut and table are that very state.  A round
+ * may end at any match end (a match that runs out of the window does just that), which is all the rounds need for it: hop words of
+ * matches that end at or behind the next such position carry HOP_END, and the chain's exits look at where the match ended. */
+template <int K, bool GT, bool DRY = false, int TT = 1, bool SEG = false>
 __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32_t U, uint2 *recs, void *tabv, uint32_t *seen, const int lane, unsigned long long *pc = nullptr,
-                                                ParseStats *stats = nullptr, ParseCtl *ctl = nullptr)
+                                                ParseStats *stats = nullptr, ParseCtl *ctl = nullptr, SegRun *sr = nullptr)
 {
+    static_assert(!SEG || (TT != 1 && K == 1 && !DRY), "segments: byU32 blocks, one sub-window per round");
     typedef FastTable<TT> Table;
     static_assert(TT == 1 || K == 1, "byU32 tables: one sub-window per round");
     constexpr bool U32 = TT != 1;
@@ -222,8 +231,22 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
     for (int k = lane; k < PARSE_SEEN_DWORDS; k += 64) seen[k] = 0u;
     wave_sync();
 
-    uint32_t c = 1u;              /* position of lane 0 of the round */
-    uint32_t sbase = 1u;          /* first probe of the running search (:466: the position behind a match + 1) */
+    /* segments: the next match end at or behind cut_pos ends its round and is looked at (handle_cut); a warm run counts no records */
+    uint32_t cut_pos = 0xffffffffu;
+    bool dry = false, cut_hit = false;
+    uint32_t seg_begin = 0u;
+    if (SEG) {
+        const uint32_t ef = uni(sr->emit_from), sa = uni(sr->stop_at);
+        seg_begin = uni(sr->begin);
+        dry = ef != 0u;
+        cut_pos = ef ? ef : sa;
+    }
+    if (SEG && !resumed && seg_begin != 0u) {                 /* the run's first position, inserted unsearched (:119-122) */
+        if (lane == 0) tab.put(Table::hash(src + seg_begin), seg_begin);
+        wave_sync();
+    }
+    uint32_t c = seg_begin + 1u;              /* position of lane 0 of the round */
+    uint32_t sbase = seg_begin + 1u;          /* first probe of the running search (:466: the position behind a match + 1) */
     bool test = false;            /* c is the position right behind a match (:393-463) */
     uint32_t sj = 0u;             /* != 0: the search has used up its 66 contiguous probes; next probe is number sj (0-based) */
     uint32_t nrec = 0u;
@@ -290,6 +313,8 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
     if (resumed) {
         c = uni(ctl->c); sbase = uni(ctl->sbase); sj = uni(ctl->sj); nrec = uni(ctl->nrec); test = ctl->test; more = ctl->more;
         long_seen = uni(ctl->long_seen); long_rounds = uni(ctl->long_rounds);
+        if (SEG) { cut_pos = uni(ctl->cut_pos); dry = uni(ctl->dry ? 1u : 0u) != 0u; }      /* (uni(): a loop that leaves on a condition the compiler takes for per-lane makes
+                                                                                             * everything it carries per-lane -- and the scalar chain's operands are carried) */
     }
     prepare();
     (void)ahead;
@@ -418,12 +443,13 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
             uint32_t word;
             if (plain) {
                 word = ((uint32_t)lane + (uint32_t)MINMATCH + e) | (e == 12u ? HOP_LONG : 0u);
+                if (SEG && pos[k] + (uint32_t)MINMATCH + e >= cut_pos) word |= HOP_END;
             } else {
                 const uint32_t fwd_max = matchlimit - (pos[k] + (uint32_t)MINMATCH);       /* (of no consequence where the lane is no probe) */
                 const bool lng = e == 12u && fwd_max > 12u && fwd_max < 0x80000000u;
                 if (e > fwd_max) e = fwd_max;
                 const uint32_t qn = strided ? 127u : (uint32_t)lane + (uint32_t)MINMATCH + e;
-                word = qn | (lng ? HOP_LONG : 0u) | (pos[k] + (uint32_t)MINMATCH + e >= mfl1 ? HOP_END : 0u) | (val[k] ? 0u : HOP_INVALID);
+                word = qn | (lng ? HOP_LONG : 0u) | (pos[k] + (uint32_t)MINMATCH + e >= (SEG && cut_pos < mfl1 ? cut_pos : mfl1) ? HOP_END : 0u) | (val[k] ? 0u : HOP_INVALID);
             }
             const bool lazy = ((Dm[k] >> lane) & 1ull) != 0ull;
             if (lazy) word |= HOP_LAZY | (hit ? 0u : HOP_TABMISS);
@@ -569,6 +595,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                     sbase = e_end + 1u;
                     limited = false;
                     if (e_end >= mfl1) { outcome = 2; upto_last = (uint32_t)f + 1u; done = true; return; }      /* :391 */
+                    if (SEG && e_end >= cut_pos) { cut_hit = true; outcome = 1; upto_last = (uint32_t)f + 1u; done = true; return; }
                     const uint32_t nq = e_end - w0;
                     if (strided || nq >= 128u || (nq >= 64u && k + 1 >= KK)) { outcome = 1; upto_last = (uint32_t)f + 1u; done = true; return; }
                     if (nq >= 64u) { q = nq - 64u; etest = true; return; }
@@ -631,7 +658,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 if (k >= KK) continue;
-                if (hits[k]) {
+                if (hits[k] && !(SEG && dry)) {
                     if (!DRY && ((hits[k] >> lane) & 1ull))
                         rec_store(recs + at + (uint32_t)__popcll(hits[k] & below_me), pos[k], (pos[k] - cpos[k]) | ((U32 && ecode[k] > 0xffffu ? 0xffffu : ecode[k]) << 16));
                     at += (uint32_t)__popcll(hits[k]);
@@ -732,6 +759,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
             e = ext28(x);
         } else e = ext12(cw.v[1] ^ w1, cw.v[2] ^ w2, cw.v[3] ^ w3);
         uint32_t word = ((uint32_t)lane + (uint32_t)MINMATCH + e) | (e == KNOWN ? HOP_LONG : 0u);
+        if (SEG && p + (uint32_t)MINMATCH + e >= cut_pos) word |= HOP_END;
         if ((D0 >> lane) & 1ull) word |= HOP_LAZY | (hit ? 0u : HOP_TABMISS);
         uint32_t ec = e, cp = cd;
         unsigned long long hm = ballot(hit) | D0;
@@ -799,6 +827,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                 long_seen++;
                 if (e_end >= mfl1) { anchor = e_end; outcome = 2; upto = (uint32_t)f + 1u; break; }      /* :391 */
             }
+            if (SEG && e_end >= cut_pos) { cut_hit = true; anchor = e_end; outcome = 1; upto = (uint32_t)f + 1u; break; }
             const uint32_t nq = e_end - c0;
             if (nq >= 64u) { anchor = e_end; outcome = 1; upto = (uint32_t)f + 1u; break; }
             q = nq;
@@ -825,7 +854,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         K4_TOCB(6);
         K4_PHASE("records");
         K4_TICC();
-        if (hts) {
+        if (hts && !(SEG && dry)) {
             if (!DRY && mine) rec_store(recs + nrec + (uint32_t)__popcll(hts & below_me), p, (p - cp) | ((U32 && ec > 0xffffu ? 0xffffu : ec) << 16));
             nrec += (uint32_t)__popcll(hts);
         }
@@ -856,11 +885,75 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         K4_PT(5);
         return true;
     };
+    /* a round has ended at a match end at or behind cut_pos (c is that match end, the round's puts are made): the table holds every
+     * visited position before it -- and position c - 2, which the reference puts right behind a match (:394) and this encoder with the
+     * round that follows: here, so that both runs hold it whichever way their windows fell (the round that follows puts it once more).
+     * Returns true when the run is over (sr->state says how). */
+    auto handle_cut = [&]() -> bool {
+        const uint32_t cut = c;
+        if (lane == 0) tab.put(Table::hash(src + cut - 2u), cut - 2u);
+        wave_sync();
+        if (dry) {
+            /* the warm run has reached its cut: publish it with the table, count records from here on */
+            uint32_t *pub = sr->snap_pub;
+#pragma unroll 2
+            for (int k = lane; k < 4096; k += 64) pub[16 + k] = tab.get((uint32_t)k);
+            wave_sync();
+            agent_publish(pub, cut + 1u);            /* (all lanes, the same word: see the end of this function) */
+            dry = false;
+            nrec = 0u;
+            sr->cut = cut;
+            cut_pos = uni(sr->stop_at);
+            return false;
+        }
+        /* the true run has reached a match end behind the next segment's boundary: is that segment's run in step here? */
+        uint32_t theirs = 0u;
+        const uint32_t spin_max = uni(sr->spin_max) ? uni(sr->spin_max) : SEG_SPIN_MAX;
+        for (uint32_t spin = 0; spin < spin_max; spin++) {
+            theirs = uni(agent_peek(sr->snap_chk));
+            if (theirs != 0u) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        bool same = theirs == cut + 1u;
+        if (same) {
+            agent_acquire();
+            bool differ = false;
+#pragma unroll 2
+            for (int k = lane; k < 4096; k += 64) {
+                const uint32_t mine = tab.get((uint32_t)k), other = sr->snap_chk[16 + k];
+                differ = differ || (mine != other && !(cut - mine > (uint32_t)DISTANCE_MAX && cut - other > (uint32_t)DISTANCE_MAX));
+            }
+            same = ballot(differ) == 0ull;
+        }
+        sr->stop = cut;
+        if (!same && (theirs == 0u || !sr->fix)) { sr->state = 3u; return true; }        /* gave up waiting: nothing to offer */
+        if (!same) {               /* this run's records stand if IT began in step; its table is left for a run that goes on from here */
+            uint32_t *fix = sr->fix;
+#pragma unroll 2
+            for (int k = lane; k < 4096; k += 64) fix[k] = tab.get((uint32_t)k);
+            wave_sync();
+        }
+        sr->state = same ? 1u : 4u;
+        return true;
+    };
+    if (ctl) ctl->stopped = false;
     const uint32_t rec_cap = ctl ? ctl->rec_cap : 0u;
     for (;;) {
+        if (SEG) {
+            /* (what the rounds and handle_cut leave in these is the same in every lane; uni() says so to the compiler -- a value it
+             * takes for per-lane, carried around this loop, would make the scalar chains' operands per-lane with it) */
+            cut_hit = uni(cut_hit ? 1u : 0u) != 0u;
+            if (cut_hit) {
+                cut_hit = false;
+                if (handle_cut()) { ctl->stopped = true; return nrec; }
+            }
+            cut_pos = uni(cut_pos); nrec = uni(nrec); dry = uni(dry ? 1u : 0u) != 0u;
+            c = uni(c); sbase = uni(sbase);
+        }
         if (U32 && rec_cap && nrec + 64u * (uint32_t)K + 2u > rec_cap) {
             ctl->c = c; ctl->sbase = sbase; ctl->sj = sj; ctl->nrec = nrec; ctl->test = test; ctl->more = more;
             ctl->long_seen = long_seen; ctl->long_rounds = long_rounds;
+            if (SEG) { ctl->cut_pos = cut_pos; ctl->dry = dry; }
             ctl->claimed = PARSE_FLUSH;
             return nrec;
         }
@@ -873,6 +966,7 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
                 if (uni(old) & (1u << sl)) {
                     ctl->c = c; ctl->sbase = sbase; ctl->sj = sj; ctl->nrec = nrec; ctl->test = test; ctl->more = more;
                     ctl->long_seen = long_seen; ctl->long_rounds = long_rounds;
+                    if (SEG) { ctl->cut_pos = cut_pos; ctl->dry = dry; }
                     ctl->claimed = (int)sl;
                     wave_sync();             /* the table's last puts are in memory before anybody copies it */
                     return nrec;
@@ -903,6 +997,18 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
 #endif
     if (DRY && stats) *stats = st;
 #undef K4_ST
+    if (SEG) {
+        if (uni(dry ? 1u : 0u) != 0u) {           /* a warm run that never found its cut: nothing to offer */
+            /* (every lane stores the same word: a fence inside `if (lane == 0)` at this place makes the compiler move scalar values that
+             * the chains' assembly produced into vector registers -- "illegal VGPR to SGPR copy") */
+            agent_publish(sr->snap_pub, SEG_NONE);
+            sr->state = 3u;
+            ctl->stopped = true;
+            nrec = 0u;
+        } else {
+            sr->stop = U; sr->state = 2u;
+        }
+    }
     return nrec;
 }
 
@@ -919,6 +1025,95 @@ __device__ __forceinline__ int emit_block(const uint8_t *src, const uint32_t U, 
     EmitState st = {0u, 0u};
     if (!emit_records<HC, BIG>(src, U, dst, dst_cap, recs, nseq, lane, st)) return 0;
     return emit_tail(src, U, dst, dst_cap, lane, st);
+}
+
+/* One block (or, SEG, one run over a big block: `sr`) by the calling wave: parse, the records written out by the same wave -- a slot-full
+ * at a time where the block has more sequences than its record slot holds --, the table in LDS (`in_lds`: the wave's own slot) or in
+ * memory until a table of the workgroup becomes free.  Returns what the encoder call returns (bytes written to dst, 0: no room); for a
+ * run that stopped at its boundary (sr->state 1 / 4) that is the piece without last literals.  *nrec_out: records of the last parse call
+ * (the whole block's where it fits its slot). */
+template <int K, int TT, bool SEG>
+__device__ __forceinline__ int parse_one(const BatchArgs &a, const ParseArgs &p, uint32_t *lds, uint32_t *seen, const bool in_lds, const uint32_t wave, const uint32_t waves,
+                                         const int lane, const long long b, const uint8_t *src, const int src_len, uint8_t *dst, const int cap, SegRun *sr, uint32_t *nrec_out)
+{
+    constexpr bool U32 = TT != 1;
+    uint2 *recs = p.recs + (p.slot_recs ? (unsigned long long)blockIdx.x * waves + wave : (unsigned long long)b) * PARSE_REC_STRIDE;
+    uint32_t n;
+    unsigned long long *pc = nullptr;
+#ifdef K4_PARSE_PROF
+    if (a.prof) { pc = a.prof + PROF_STRIDE * b; prof_place<true>(pc, 8, lane); }
+#endif
+    uint32_t *free_slots = p.migrate ? lds + PARSE_LDS_DWORDS - 1 : nullptr;
+    bool moved = false;
+#ifndef K4_PARSE_PROF
+    if (a.prof && !SEG) prof_place<true>(a.prof + PROF_STRIDE * b, 8, lane);
+#endif
+    /* One call of parse_block is the whole block unless it comes back early: with a claim on an LDS table that has become free
+     * (the table moves, the LDS form goes on), or -- byU32 blocks, which may hold more sequences than a record slot -- with a
+     * slot-full of records to be written out before it goes on (PARSE_FLUSH). */
+    EmitState est = {0u, 0u};
+    bool room = true, started = false;
+    auto write_out = [&](uint32_t cnt) {         /* the records so far; a warm run's output begins at its cut */
+        if (SEG && !started) { est.emitted_to = uni(sr->cut); started = true; }
+        wave_sync();                             /* the records are this wave's own stores: in order with the loads that follow */
+        if (room && !emit_records<false, U32>(src, (uint32_t)src_len, dst, cap < 0 ? 0 : cap, recs, cnt, lane, est)) room = false;
+        wave_sync();
+    };
+    uint32_t *gt = p.gtab + 4096ull * ((unsigned long long)blockIdx.x * PARSE_MAX_WAVES + wave);
+    uint32_t *table = in_lds ? lds + 4096u * wave : gt;
+    bool table_in_lds = in_lds;
+    int my_slot = -1;                            /* an LDS table this wave moved into (to be given back) */
+    ParseCtl ctl = {};
+    ctl.free_slots = in_lds ? nullptr : free_slots; ctl.claimed = -1; ctl.resume = false;
+    ctl.rec_cap = U32 ? PARSE_REC_STRIDE : 0u;
+    for (;;) {
+        if (table_in_lds) n = parse_block<K, false, false, TT, SEG>(src, (uint32_t)src_len, recs, table, seen, lane, pc, nullptr, (U32 || ctl.resume) ? &ctl : nullptr, sr);
+        else n = parse_block<K, true, false, TT, SEG>(src, (uint32_t)src_len, recs, table, seen, lane, pc, nullptr, &ctl, sr);
+        if (U32 && ctl.claimed == PARSE_FLUSH) {
+            if (p.inline_emit) write_out(n);
+            if (!room) { n = 0u; break; }            /* the output does not fit (:251-255, :346-350): the block fails, no need to go on */
+            ctl.nrec = 0u; ctl.resume = true; ctl.claimed = -1;
+            continue;
+        }
+        if (ctl.claimed >= 0) {                  /* a table of the workgroup has become free: move in */
+            moved = true;
+            uint32_t *slot = lds + 4096u * (uint32_t)ctl.claimed;
+#pragma unroll 4
+            for (int k = lane; k < 1024; k += 64) ((uint4 *)slot)[k] = ((const uint4 *)gt)[k];
+            wave_sync();
+            my_slot = ctl.claimed;
+            table = slot; table_in_lds = true;
+            ctl.resume = true; ctl.free_slots = nullptr; ctl.claimed = -1;
+            continue;
+        }
+        break;
+    }
+    if (free_slots && lane == 0) {
+        if (my_slot >= 0) atomicOr(free_slots, 1u << my_slot);                 /* ... and free again for the next one */
+        else if (in_lds && !p.queue) atomicOr(free_slots, 1u << wave);          /* this wave's table is free now */
+    }
+#ifdef K4_PARSE_PROF
+    if (a.prof) { if (lane == 0) { pc[9] = __builtin_amdgcn_s_memrealtime(); pc[15] = in_lds ? 1u : 2u; } }
+#endif
+    *nrec_out = n;
+#ifndef K4_PARSE_PROF
+    /* k4lz4_profile_batch_device mode 4 (stamps only): [12] when the parse was through, [9] when the block was written, [11]
+     * where its table lived (4 LDS, 5 memory, 6 memory first and an LDS table from some round on) */
+    if (a.prof && !SEG) { prof_place<true>(a.prof + PROF_STRIDE * b, 12, lane); if (lane == 0) a.prof[PROF_STRIDE * b + 11] = in_lds ? 4u : (moved ? 6u : 5u); }
+#endif
+    int ret = 0;
+    if (p.inline_emit) {
+        const bool stopped = SEG && ctl.stopped;                  /* the run ended at its boundary: a piece, no last literals */
+        if (!(SEG && stopped && uni(sr->state) == 3u)) {
+            if (room) write_out(n);
+            if (room) ret = stopped ? (int)est.op : emit_tail(src, (uint32_t)src_len, dst, cap < 0 ? 0 : cap, lane, est);
+        }
+    }
+#ifndef K4_PARSE_PROF
+    if (a.prof && !SEG) prof_place<true>(a.prof + PROF_STRIDE * b, 9, lane);
+#endif
+    (void)moved;
+    return ret;
 }
 
 template <int K, int TT = 1>
@@ -962,79 +1157,12 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
         if (!mine) {
             if (!U32 && lane == 0) { meta[0] = (big && p.big) ? PARSE_BIG : PARSE_REST; meta[1] = 0u; }
         } else {
-            const uint8_t *src = a.src + a.srcOff[b];
-            uint2 *recs = p.recs + (p.slot_recs ? (unsigned long long)blockIdx.x * waves + wave : (unsigned long long)b) * PARSE_REC_STRIDE;
-            uint32_t n;
-            unsigned long long *pc = nullptr;
-#ifdef K4_PARSE_PROF
-            if (a.prof) { pc = a.prof + PROF_STRIDE * b; prof_place<true>(pc, 8, lane); }
-#endif
-            uint32_t *free_slots = p.migrate ? lds + PARSE_LDS_DWORDS - 1 : nullptr;
-            bool moved = false;
-#ifndef K4_PARSE_PROF
-            if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 8, lane);
-#endif
-            /* One call of parse_block is the whole block unless it comes back early: with a claim on an LDS table that has become free
-             * (the table moves, the LDS form goes on), or -- byU32 blocks, which may hold more sequences than a record slot -- with a
-             * slot-full of records to be written out before it goes on (PARSE_FLUSH). */
-            const int cap = a.dstCap[b];
-            uint8_t *dst = a.dst + a.dstOff[b];
-            EmitState est = {0u, 0u};
-            bool room = true;
-            uint32_t *gt = p.gtab + 4096ull * ((unsigned long long)blockIdx.x * PARSE_MAX_WAVES + wave);
-            uint32_t *table = in_lds ? lds + 4096u * wave : gt;
-            bool table_in_lds = in_lds;
-            int my_slot = -1;                    /* an LDS table this wave moved into (to be given back) */
-            ParseCtl ctl = {};
-            ctl.free_slots = in_lds ? nullptr : free_slots; ctl.claimed = -1; ctl.resume = false;
-            ctl.rec_cap = U32 ? PARSE_REC_STRIDE : 0u;
-            for (;;) {
-                if (table_in_lds) n = parse_block<K, false, false, TT>(src, (uint32_t)src_len, recs, table, seen, lane, pc, nullptr, (U32 || ctl.resume) ? &ctl : nullptr);
-                else n = parse_block<K, true, false, TT>(src, (uint32_t)src_len, recs, table, seen, lane, pc, nullptr, &ctl);
-                if (U32 && ctl.claimed == PARSE_FLUSH) {
-                    wave_sync();                 /* the records are this wave's own stores: in order with the loads that follow */
-                    if (room && !emit_records<false, true>(src, (uint32_t)src_len, dst, cap < 0 ? 0 : cap, recs, n, lane, est)) room = false;
-                    wave_sync();
-                    if (!room) { n = 0u; break; }            /* the output does not fit (:251-255, :346-350): the block fails, no need to go on */
-                    ctl.nrec = 0u; ctl.resume = true; ctl.claimed = -1;
-                    continue;
-                }
-                if (ctl.claimed >= 0) {          /* a table of the workgroup has become free: move in */
-                    moved = true;
-                    uint32_t *slot = lds + 4096u * (uint32_t)ctl.claimed;
-#pragma unroll 4
-                    for (int k = lane; k < 1024; k += 64) ((uint4 *)slot)[k] = ((const uint4 *)gt)[k];
-                    wave_sync();
-                    my_slot = ctl.claimed;
-                    table = slot; table_in_lds = true;
-                    ctl.resume = true; ctl.free_slots = nullptr; ctl.claimed = -1;
-                    continue;
-                }
-                break;
+            uint32_t n = 0u;
+            const int ret = parse_one<K, TT, false>(a, p, lds, seen, in_lds, wave, waves, lane, b, a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], a.dstCap[b], nullptr, &n);
+            if (lane == 0) {
+                meta[0] = n; meta[1] = 0u;
+                if (p.inline_emit) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
             }
-            if (free_slots && lane == 0) {
-                if (my_slot >= 0) atomicOr(free_slots, 1u << my_slot);                 /* ... and free again for the next one */
-                else if (in_lds && !p.queue) atomicOr(free_slots, 1u << wave);          /* this wave's table is free now */
-            }
-#ifdef K4_PARSE_PROF
-            if (a.prof) { if (lane == 0) { pc[9] = __builtin_amdgcn_s_memrealtime(); pc[15] = in_lds ? 1u : 2u; } }
-#endif
-            if (lane == 0) { meta[0] = n; meta[1] = 0u; }
-#ifndef K4_PARSE_PROF
-            /* k4lz4_profile_batch_device mode 4 (stamps only): [12] when the parse was through, [9] when the block was written, [11]
-             * where its table lived (4 LDS, 5 memory, 6 memory first and an LDS table from some round on) */
-            if (a.prof) { prof_place<true>(a.prof + PROF_STRIDE * b, 12, lane); if (lane == 0) a.prof[PROF_STRIDE * b + 11] = in_lds ? 4u : (moved ? 6u : 5u); }
-#endif
-            if (p.inline_emit) {
-                wave_sync();                 /* the records are this wave's own stores: in order with the loads that follow */
-                int ret = 0;
-                if (room && emit_records<false, U32>(src, (uint32_t)src_len, dst, cap < 0 ? 0 : cap, recs, n, lane, est))
-                    ret = emit_tail(src, (uint32_t)src_len, dst, cap < 0 ? 0 : cap, lane, est);
-                if (lane == 0) a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
-            }
-#ifndef K4_PARSE_PROF
-            if (a.prof) prof_place<true>(a.prof + PROF_STRIDE * b, 9, lane);
-#endif
         }
         if (!p.queue) return;
     }

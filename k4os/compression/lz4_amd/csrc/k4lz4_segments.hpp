@@ -21,6 +21,7 @@
  */
 #pragma once
 #include "k4lz4_encode_fast.hpp"
+#include "k4lz4_parse.hpp"
 
 namespace k4 {
 
@@ -180,6 +181,91 @@ __global__ __launch_bounds__(64 * ENCODE_WAVES_PER_WG) __attribute__((amdgpu_wav
     if (lane == 0) {
         g.items[it].cut = r.cut; g.items[it].stop = r.stop; g.items[it].state = ret > 0 ? r.state : 3u; g.items[it].bytes = ret;
     }
+}
+
+/*
+ * Round 6: the same runs by the two-step encoder (k4lz4_parse.hpp, parse_block<.., SEG>) -- ONE persistent launch, a workgroup of sixteen
+ * waves per CU (nine tables in LDS, the others in memory until one becomes free), for every block of 65 547 bytes and more of the batch:
+ * the later segments of the cut blocks (the work list, a block's last segment first: a run never waits for one that has not been
+ * taken), then the blocks themselves in cost order -- a cut block's first segment with the stop rule, the others whole.  The waves
+ * with LDS tables take from that end, the others from the cheap end of the order.  Blocks below 65 547 bytes are k4_parse_kernel's
+ * (launched before this one: it marks whose every block is).  What a run leaves behind -- SegItem's cut / stop / state / bytes, the
+ * published snapshots, the table of a cut that did not verify -- is what k4_encode_seg_kernel and the *_seg twins leave, so
+ * k4_seg_join_kernel joins the pieces of either.
+ */
+template <int TT>
+__device__ __forceinline__ void parse_seg_kernel_body(const BatchArgs &a, const ParseArgs &p, const SegArgs &g, uint32_t *lds)
+{
+    const int lane = lane_id();
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t waves = blockDim.x >> 6;
+    const uint32_t lds_tables = waves < (uint32_t)PARSE_LDS_TABLES ? waves : (uint32_t)PARSE_LDS_TABLES;
+    uint32_t *seen = lds + 4096u * (uint32_t)PARSE_LDS_TABLES + (uint32_t)PARSE_SEEN_DWORDS * wave;
+    const bool in_lds = wave < lds_tables;
+    if (p.migrate) {
+        if (threadIdx.x == 0) lds[PARSE_LDS_DWORDS - 1] = 0u;
+        __syncthreads();
+    }
+    const uint32_t n_work = uni(g.hdr->n_work);
+    const uint32_t total = n_work + (uint32_t)a.n;
+    for (;;) {
+        uint32_t t = 0u;
+        if (lane == 0) {
+            t = atomicAdd(p.queue, 1u);
+            if (t < total) t = in_lds ? atomicAdd(p.queue + 1, 1u) : total - 1u - atomicAdd(p.queue + 2, 1u);
+            else t = 0xffffffffu;
+        }
+        t = uni(t);
+        if (t == 0xffffffffu) {
+            if (p.migrate && in_lds && lane == 0) atomicOr(lds + PARSE_LDS_DWORDS - 1, 1u << wave);
+            return;
+        }
+        if (t < n_work) {
+            /* a later segment of a cut block */
+            const uint32_t it = uni(g.work[t]);
+            SegItem s = g.items[it];
+            /* (what comes out of memory is the same in every lane; uni() says so to the compiler, which wants the block's length, the
+             * cursors and everything the scalar chains take in scalar registers) */
+            s.block = uni(s.block); s.k = uni(s.k); s.nseg = uni(s.nseg); s.start = uni(s.start); s.next_start = uni(s.next_start); s.warm_from = uni(s.warm_from);
+            const long long b = (long long)s.block;
+            const int U = (int)uni((uint32_t)a.srcLen[b]);
+            SegRun r = seg_run_of(g, it, s);
+            /* its piece lies at `start` of the block's slot and may reach neither the next segment's place nor the end of the slot */
+            const int dcap = (int)uni((uint32_t)a.dstCap[b]);
+            const uint32_t slot_cap = dcap < 0 ? 0u : (uint32_t)dcap;
+            uint32_t end = s.next_start != SEG_NONE ? s.next_start : (uint32_t)U;
+            if (end > slot_cap) end = slot_cap;
+            if (end <= s.start) {            /* no room for this piece: say so to the run before it, which waits for this one's cut */
+                if (lane == 0) { agent_publish(r.snap_pub, SEG_NONE); g.items[it].cut = 0u; g.items[it].stop = 0u; g.items[it].state = 3u; g.items[it].bytes = 0; }
+                continue;
+            }
+            uint32_t n = 0u;
+            const int ret = parse_one<1, TT, true>(a, p, lds, seen, in_lds, wave, waves, lane, b, a.src + a.srcOff[b], U, a.dst + a.dstOff[b] + s.start, (int)(end - s.start), &r, &n);
+            if (lane == 0) { g.items[it].cut = r.cut; g.items[it].stop = r.stop; g.items[it].state = ret > 0 ? r.state : 3u; g.items[it].bytes = ret; }
+        } else {
+            const long long idx = (long long)(t - n_work);
+            const long long b = a.order ? (long long)uni(a.order[idx]) : idx;
+            const int src_len = (int)uni((uint32_t)a.srcLen[b]);
+            if (src_len < LIMIT_64K || a.accel != 1) continue;         /* k4_parse_kernel's, or the one-kernel encoder's */
+            SegFirst f = seg_first_of(a, b);     /* (neutral fields when the block is not cut: begin 0, no cut, stop at the end) */
+            const int cap = (int)uni((uint32_t)a.dstCap[b]);
+            const int c = cap < 0 ? 0 : (f.cut && (uint32_t)cap > f.cap ? (int)f.cap : cap);
+            uint32_t n = 0u;
+            const int ret = parse_one<1, TT, true>(a, p, lds, seen, in_lds, wave, waves, lane, b, a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], c, &f.run, &n);
+            seg_first_done(a, b, f, ret, lane);
+            if (lane == 0) {
+                p.meta[2ull * (unsigned long long)b] = n;
+                a.outLen[b] = codec_encode_result(src_len, ret, a.flags);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * PARSE_MAX_WAVES) void k4_parse_seg_kernel(BatchArgs a, ParseArgs p, SegArgs g)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[PARSE_LDS_DWORDS];
+    if (a.flags & FLAG_X32) parse_seg_kernel_body<2>(a, p, g, lds);
+    else parse_seg_kernel_body<0>(a, p, g, lds);
 }
 
 /* Per cut block, after every encoder kernel of the launch: join or encode again.  outLen gets what the block's encoder call

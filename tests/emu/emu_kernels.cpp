@@ -277,9 +277,32 @@ int k4emu_pickle_seg_batch(const uint8_t *src, const uint64_t *srcOff, const int
     g.snaps = snaps.data();
     g.tables = snaps.data() + (size_t)g.max_items * k4::SEG_SNAP_DWORDS;
     e.seg_first = g.first; e.seg_items = g.items; e.seg_snaps = g.snaps;
+    const bool two_step = (flags & (1 << 30)) != 0;         /* the emulator's own flag: the runs by the two-step encoder (k4_parse_kernel for the blocks
+                                                             * below 65 547 bytes, k4_parse_seg_kernel for the others and the later segments), round 6 */
+    e.flags &= ~(1 << 30); a.flags &= ~(1 << 30);
+    std::vector<uint2> recs;
+    std::vector<uint32_t> meta, gtab, q(8, 0u), ident;
+    if (two_step) {
+        const unsigned waves = (unsigned)((flags >> 24) & 31) ? (unsigned)((flags >> 24) & 31) : 16u;      /* bits 24-28: waves per workgroup (0: sixteen) */
+        e.flags &= ~(31 << 24); a.flags &= ~(31 << 24);
+        k4::ParseArgs p{};
+        p.nwg = 1u;                                         /* one persistent workgroup takes everything (the emulator runs workgroups one after the other) */
+        recs.resize((size_t)p.nwg * waves * k4::PARSE_REC_STRIDE);
+        meta.assign((size_t)n * 2, 0x12345678u); gtab.assign((size_t)p.nwg * k4::PARSE_MAX_WAVES * 4096u, 0xdeadbeefu);
+        ident.resize((size_t)n); for (long long i = 0; i < n; i++) ident[(size_t)i] = (uint32_t)i;
+        e.order = ident.data();
+        p.recs = recs.data(); p.meta = meta.data(); p.gtab = gtab.data();
+        p.inline_emit = 1u; p.slot_recs = 1u; p.migrate = 1u; p.big = 1u; p.queue = q.data();
+        k4emu::launch_fn(dim3(p.nwg), dim3(64 * waves), [=] { k4::k4_parse_kernel(e, p); }, 1);
+        k4::ParseArgs pb = p;
+        pb.queue = q.data() + 4;
+        k4emu::launch_fn(dim3(p.nwg), dim3(64 * waves), [=] { k4::k4_parse_seg_kernel(e, pb, g); }, 1);
+        k4emu::launch_fn(dim3((unsigned)((n + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG), [=] { k4::k4_encode_fast_rest_kernel(e, p); }, threads);
+    } else {
     if (hdr.n_work)
         k4emu::launch_fn(dim3((hdr.n_work + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG), dim3(64 * k4::ENCODE_WAVES_PER_WG), [=] { k4::k4_encode_seg_kernel(e, g); }, 1);
     k4emu::launch_fn(dim3((unsigned)((n + k4::ENCODE_WAVES_PER_WG - 1) / k4::ENCODE_WAVES_PER_WG)), dim3(64 * k4::ENCODE_WAVES_PER_WG), [=] { k4::k4_encode_fast_seg_kernel(e); }, threads);
+    }
     if (stats) {
         stats[0] = hdr.n_blocks; stats[1] = hdr.n_items; stats[2] = 0; stats[3] = 0;
         for (uint32_t i = 0; i < hdr.n_items; i++) stats[3] += items[i].state == 4u && items[i].bytes > 0 ? 1u : 0u;    /* pieces that kept their output behind a boundary that did not verify */

@@ -330,7 +330,11 @@ def test_pickle_matches_oracle(emu, oracle):
             assert udst[int(uoff[i]):int(uoff[i]) + b.size].tobytes() == b.tobytes()
 
 
-def test_pickle_in_segments_matches_oracle(emu, oracle):
+TWO_STEP = 1 << 30          # the emulator's flag: the segments' runs by the two-step encoder (k4_parse_kernel + k4_parse_seg_kernel, round 6)
+
+
+@pytest.mark.parametrize("engine", [0, TWO_STEP, TWO_STEP | (5 << 24)], ids=["one_kernel", "two_step", "two_step_5_waves"])
+def test_pickle_in_segments_matches_oracle(emu, oracle, engine):
     """k4lz4_segments.hpp: big messages cut into segments, every piece by a wave of its own, are byte for byte the oracle's
     pickles -- where a boundary verifies (the pieces are joined) and where it does not (the message is encoded again).  Small
     segment sizes so that the emulator gets through it; both outcomes must occur over the set."""
@@ -343,7 +347,7 @@ def test_pickle_in_segments_matches_oracle(emu, oracle):
     joined = cut = 0
     for (seg_target, seg_warm) in ((32768, 65536), (40000, 8192)):
         dst, doff, dcap = arena(caps)
-        out, stats = emu.pickle_seg_batch(src, soff, slen, dst, doff, dcap, 70000, seg_target, seg_warm)
+        out, stats = emu.pickle_seg_batch(src, soff, slen, dst, doff, dcap, 70000, seg_target, seg_warm, flags=engine)
         for i, b in enumerate(blocks):
             want = oracle.pickle(b, 0, 0)
             got = dst[int(doff[i]):int(doff[i]) + int(out[i])].tobytes()
@@ -354,7 +358,8 @@ def test_pickle_in_segments_matches_oracle(emu, oracle):
     assert 0 < joined < cut, (joined, cut)
 
 
-def test_segments_behind_a_bad_boundary_are_kept(emu, oracle):
+@pytest.mark.parametrize("engine", [0, TWO_STEP], ids=["one_kernel", "two_step"])
+def test_segments_behind_a_bad_boundary_are_kept(emu, oracle, engine):
     """round 4: a piece whose successor is not in step keeps its output and leaves the cut's table in its item's slot (state 4;
     the successor's published snapshot stays what it was: overwriting it once made a later check pass against the wrong table),
     and the join's one wave goes on from there only as far as the next boundary whose piece IS in step.  Messages whose middle
@@ -370,7 +375,7 @@ def test_segments_behind_a_bad_boundary_are_kept(emu, oracle):
     kept = resumed = stops = 0
     for (seg_target, seg_warm) in ((32768, 65536), (49152, 70000), (16384, 4096), (24576, 66000)):
         dst, doff, dcap = arena(caps)
-        out, stats = emu.pickle_seg_batch(src, soff, slen, dst, doff, dcap, 70000, seg_target, seg_warm)
+        out, stats = emu.pickle_seg_batch(src, soff, slen, dst, doff, dcap, 70000, seg_target, seg_warm, flags=engine)
         for i, b in enumerate(blocks):
             assert dst[int(doff[i]):int(doff[i]) + int(out[i])].tobytes() == oracle.pickle(b, 0, 0), (i, seg_target, seg_warm)
             assert (dst[int(doff[i]) + max(int(dcap[i]), int(out[i])):int(doff[i]) + int(dcap[i]) + 16] == 0xCD).all()
