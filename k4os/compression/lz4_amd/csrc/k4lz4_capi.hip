@@ -63,7 +63,7 @@ struct k4lz4_ctx {
     uint8_t *d_seg_first = nullptr; size_t d_seg_first_cap = 0;   /* per block: its first segment's record or -1 */
     bool use_segments = true;                                 /* K4LZ4_NO_SEGMENTS */
     uint32_t seg_min = 1024u << 10, seg_target = 640u << 10, seg_warm = 384u << 10;   /* K4LZ4_SEG_MIN / _TARGET / _WARM (bytes) */
-    uint32_t seg_target_max = 1152u << 10;                    /* K4LZ4_SEG_TARGET_MAX; K4LZ4_SEG_TARGET alone fixes the size */
+    uint32_t seg_target_max = 1408u << 10;                    /* K4LZ4_SEG_TARGET_MAX; K4LZ4_SEG_TARGET alone fixes the size (1152 KiB until round 6: the two-step encoder's runs are faster, gpurun_out/r6o) */
     uint32_t seg_spin_max = 0;                                /* K4LZ4_SEG_SPIN_MAX: polls a run waits for its successor's cut (0: SEG_SPIN_MAX); tests force the exit with 1 */
     uint32_t seg_div = 3500;                                  /* K4LZ4_SEG_DIV: blocks shorter than the batch's bytes / this stay whole */
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
