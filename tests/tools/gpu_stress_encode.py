@@ -3,7 +3,7 @@
 the adversarial inputs of emu_stress_encode.py -- equal hashes inside a window, matches ending at window edges, long literal runs,
 incompressible stretches -- mixed with the corpus classes), ragged output limits, through the default path (k4_parse_kernel with
 tables that move into LDS, then the one-kernel encoder for the blocks it leaves alone).  Every block: return value, bytes, and the
-slack behind them untouched.  Usage: tests/tools/gpu_stress_encode.py [rounds] [seed] [blocks per round] [device]     (K4_STRESS_REPEATS=n: every batch n times)"""
+slack behind them untouched.  Usage: tests/tools/gpu_stress_encode.py [rounds] [seed] [blocks per round] [device] [big]     (K4_STRESS_REPEATS=n: every batch n times)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,8 +13,9 @@ from emu_stress_encode import gen
 from k4os.compression.lz4_amd import pack_blocks, make_arena, LZ4Codec, corpus
 
 
-def run(rounds, seed, per, oracle=None, device=False, repeats=1):
-    """device: through k4lz4_encode_batch_device on HBM-resident buffers (no host staging); repeats: every batch that many times"""
+def run(rounds, seed, per, oracle=None, device=False, repeats=1, big=False):
+    """device: through k4lz4_encode_batch_device on HBM-resident buffers (no host staging); repeats: every batch that many times;
+    big: a third of the blocks of 65 547 .. 400 000 bytes (byU32 tables: k4_parse_big_kernel, round 6)"""
     oracle = oracle or Oracle()
     if device:
         import torch
@@ -27,6 +28,7 @@ def run(rounds, seed, per, oracle=None, device=False, repeats=1):
         blocks = []
         for i in range(per):
             n = int(rng.choice([rng.integers(0, 40), rng.integers(100, 400), rng.integers(300, 6000), rng.integers(6000, 65547), rng.integers(64000, 65547), 65536]))
+            if big and i % 3 == 0: n = int(rng.choice([rng.integers(65547, 66000), rng.integers(65547, 140000), rng.integers(100000, 400000)]))
             if n == 0: blocks.append(np.zeros(0, np.uint8))
             elif rng.random() < 0.5: blocks.append(gen(rng, n))
             else: blocks.append(corpus.class_bytes(corpus.SILESIA_NAMES[int(rng.integers(0, 12))], n, int(rng.integers(0, 1 << 30))))
@@ -67,4 +69,4 @@ def run(rounds, seed, per, oracle=None, device=False, repeats=1):
 if __name__ == "__main__":
     sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 10, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
                       int(sys.argv[3]) if len(sys.argv) > 3 else 3000, device="device" in sys.argv[4:],
-                      repeats=int(os.environ.get("K4_STRESS_REPEATS", "1"))) else 0)
+                      repeats=int(os.environ.get("K4_STRESS_REPEATS", "1")), big="big" in sys.argv[4:]) else 0)
