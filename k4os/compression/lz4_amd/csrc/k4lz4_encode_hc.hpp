@@ -231,6 +231,9 @@ __global__ __launch_bounds__(64 * HC_CHAIN_LDS_WAVES_PER_WG) void k4_hc_chain_ld
 
 /* ---- kernel 1b: candidates + forward lengths, every position independently ------------------ */
 constexpr int HC_CAND_POS_PER_WG = 1024;
+#ifndef K4_HC_CAND_GROUP
+#define K4_HC_CAND_GROUP 1
+#endif
 __global__ __launch_bounds__(256) void k4_hc_cand_kernel(HcArgs a)
 {
     const long long b = (long long)blockIdx.x;
@@ -245,62 +248,121 @@ __global__ __launch_bounds__(256) void k4_hc_cand_kernel(HcArgs a)
     uint32_t *cand = (uint32_t *)prev + ((U + 3u) & ~3u);
     uint2 *flen = (uint2 *)(cand + 4u * ((U + 3u) & ~3u));
     uint2 *blen = flen + ((U + 3u) & ~3u);
-    /* first four chain candidates of every position; a chain step of 65535 or more ends the walk
-     * (LL.high.cs:114 caps the delta, and such a candidate is below lowestMatchIndex) */
-    for (uint32_t p = first + threadIdx.x; p < first + (uint32_t)HC_CAND_POS_PER_WG; p += 256u) {
-        if (p < npos) {
-            uint32_t c0 = prev[p], c1 = HC_NONE, c2 = HC_NONE, c3 = HC_NONE;
-            if (c0 != HC_NONE) { const uint32_t q = prev[c0]; if (q != HC_NONE && c0 - q < (uint32_t)DISTANCE_MAX) c1 = q; }
-            if (c1 != HC_NONE) { const uint32_t q = prev[c1]; if (q != HC_NONE && c1 - q < (uint32_t)DISTANCE_MAX) c2 = q; }
-            if (c2 != HC_NONE) { const uint32_t q = prev[c2]; if (q != HC_NONE && c2 - q < (uint32_t)DISTANCE_MAX) c3 = q; }
-            ((uint4 *)cand)[p] = make_uint4(c0, c1, c2, c3);
-            /* forward match length against each candidate a search at p may use (:87-88 lowest,
-             * :120 4-byte test, :126 LZ4_count up to matchlimit), capped at HC_FLEN_CAP */
-            const uint32_t lowest = p > (uint32_t)DISTANCE_MAX ? p - (uint32_t)DISTANCE_MAX : 0u;
-            const uint32_t matchlimit = U - LASTLITERALS;
-            const uint32_t maxn = p + MINMATCH < matchlimit ? matchlimit - (p + MINMATCH) : 0u;
-            const uint32_t seq = ld32u(src + p);
-            /* the position's own eight bytes behind its first four and before it: read once, not once per candidate -- an
-             * eight-byte read at an address of its own per lane is what this kernel's time is made of (experiments/hc_cand_lds) */
-            const uint32_t lim0 = maxn < HC_FLEN_CAP - MINMATCH ? maxn : HC_FLEN_CAP - MINMATCH;
-            const uint64_t pf0 = lim0 >= 8u ? ld64u(src + p + MINMATCH) : 0ull;
-            const uint64_t pb0 = p >= 8u ? ld64u(src + p - 8u) : 0ull;
-            uint32_t fl[4], bl[4];
-            bool chain_ok = true;
+    /* Per position: the first four chain candidates (a chain step of 65535 or more ends the walk: LL.high.cs:114 caps the delta, and such
+     * a candidate is below lowestMatchIndex), per candidate the forward match length a search at p may use (:87-88 lowest, :120 the
+     * 4-byte test, :126 LZ4_count up to matchlimit, capped at HC_FLEN_CAP) and the equal bytes before the two positions (LZ4HC_countBack
+     * without its limits, capped at HC_BLEN_CAP).  Written so that K4_HC_CAND_GROUP of a thread's four positions go TOGETHER, every
+     * step's loads -- prev[p], prev[c0], prev[c1], prev[c2], the candidates' first four bytes, their eight bytes forward and backward
+     * -- issued for all of them before the first is used.  Round 6 measured what that is worth: nothing -- groups of 1 / 2 / 4: 11.07 /
+     * 11.24 / 13.96 ms for the bench batch (46 / 73 / 131 VGPRs; the one-position loop of rounds 1-5: 11.58).  The kernel is not
+     * waiting for its chains: an unaligned eight-byte read at an address of its own per lane costs what it costs wherever it is
+     * issued (experiments/hc_cand_lds), and more in flight per wave only takes waves away. */
+    constexpr int PP = K4_HC_CAND_GROUP;                  /* positions of a thread that go together (of HC_CAND_POS_PER_WG / 256 = 4) */
+    static_assert((HC_CAND_POS_PER_WG / 256) % PP == 0, "groups divide a thread's positions");
+    const uint32_t matchlimit = U - LASTLITERALS;
+  for (int grp = 0; grp < HC_CAND_POS_PER_WG / 256 / PP; grp++) {
+    uint32_t pos[PP], c[PP][4], seq[PP], lim[PP];
+    uint64_t pf0[PP], pb0[PP];
+    bool in[PP];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t c = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
-                chain_ok = chain_ok && c != HC_NONE && c >= lowest;
-                uint32_t f = 0;
-                const uint32_t lim = lim0;
-                if (chain_ok && ld32u(src + c) == seq) {
-                    uint32_t i = 0;
-                    while (i + 8u <= lim) {
-                        const uint64_t x = (i == 0u ? pf0 : ld64u(src + p + MINMATCH + i)) ^ ld64u(src + c + MINMATCH + i);
+    for (int j = 0; j < PP; j++) {
+        pos[j] = first + threadIdx.x + 256u * (uint32_t)(grp * PP + j);
+        in[j] = pos[j] < npos;
+        const uint32_t p = in[j] ? pos[j] : 0u;
+        c[j][0] = in[j] ? prev[p] : HC_NONE;
+        seq[j] = ld32u(src + p);
+        const uint32_t maxn = p + MINMATCH < matchlimit ? matchlimit - (p + MINMATCH) : 0u;
+        lim[j] = maxn < HC_FLEN_CAP - MINMATCH ? maxn : HC_FLEN_CAP - MINMATCH;
+        /* the position's own eight bytes behind its first four and before it: read once, not once per candidate */
+        pf0[j] = (in[j] && lim[j] >= 8u) ? ld64u(src + p + MINMATCH) : 0ull;
+        pb0[j] = (in[j] && p >= 8u) ? ld64u(src + p - 8u) : 0ull;
+    }
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+        uint32_t q[PP];
+#pragma unroll
+        for (int j = 0; j < PP; j++) q[j] = c[j][k - 1] != HC_NONE ? prev[c[j][k - 1]] : HC_NONE;
+#pragma unroll
+        for (int j = 0; j < PP; j++) c[j][k] = (q[j] != HC_NONE && c[j][k - 1] - q[j] < (uint32_t)DISTANCE_MAX) ? q[j] : HC_NONE;
+    }
+    /* which candidates a search at p may use, and their first four bytes */
+    bool ok[PP][4];
+    uint32_t cseq[PP][4];
+#pragma unroll
+    for (int j = 0; j < PP; j++) {
+        const uint32_t lowest = pos[j] > (uint32_t)DISTANCE_MAX ? pos[j] - (uint32_t)DISTANCE_MAX : 0u;
+        bool chain_ok = in[j];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            chain_ok = chain_ok && c[j][k] != HC_NONE && c[j][k] >= lowest;
+            ok[j][k] = chain_ok;
+            cseq[j][k] = chain_ok ? ld32u(src + c[j][k]) : 0u;
+        }
+    }
+    /* the first eight bytes forward and backward of every candidate that has the four */
+    uint64_t cf[PP][4], cb[PP][4];
+#pragma unroll
+    for (int j = 0; j < PP; j++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ok[j][k] = ok[j][k] && cseq[j][k] == seq[j];
+            const uint32_t cc = c[j][k];
+            cf[j][k] = (ok[j][k] && lim[j] >= 8u) ? ld64u(src + cc + MINMATCH) : 0ull;
+            cb[j][k] = (ok[j][k] && cc >= 8u) ? ld64u(src + cc - 8u) : 0ull;
+        }
+#pragma unroll
+    for (int j = 0; j < PP; j++) {
+        uint32_t fl[4], bl[4];
+        const uint32_t p = pos[j];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t cc = c[j][k];
+            uint32_t f = 0, bk = 0;
+            if (ok[j][k]) {
+                const uint32_t l = lim[j];
+                uint32_t i = 0;
+                bool more = true;                       /* the count is not finished by the first eight bytes */
+                if (l >= 8u) {
+                    const uint64_t x = pf0[j] ^ cf[j][k];
+                    if (x) { i = (uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3; more = false; }
+                    else i = 8u;
+                }
+                if (more) {
+                    while (i + 8u <= l) {
+                        const uint64_t x = ld64u(src + p + MINMATCH + i) ^ ld64u(src + cc + MINMATCH + i);
                         if (x) { i += (uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3; break; }
                         i += 8u;
                     }
-                    if (i + 8u > lim) while (i < lim && src[p + MINMATCH + i] == src[c + MINMATCH + i]) i++;
-                    f = MINMATCH + i;
+                    if (i + 8u > l) while (i < l && src[p + MINMATCH + i] == src[cc + MINMATCH + i]) i++;
                 }
-                fl[k] = f;
-                /* equal bytes before the two positions (LZ4HC_countBack without its limits) */
-                uint32_t bk = 0;
-                if (f) {
-                    const uint32_t blim = c < HC_BLEN_CAP ? c : HC_BLEN_CAP;       /* c < p */
+                f = MINMATCH + i;
+                /* equal bytes before the two positions */
+                const uint32_t blim = cc < HC_BLEN_CAP ? cc : HC_BLEN_CAP;       /* cc < p */
+                more = true;
+                if (blim >= 8u) {
+                    const uint64_t x = pb0[j] ^ cb[j][k];
+                    if (x) { bk = (uint32_t)__clzll((unsigned long long)x) >> 3; more = false; }
+                    else bk = 8u;
+                }
+                if (more) {
                     while (bk + 8u <= blim) {
-                        const uint64_t x = (bk == 0u ? pb0 : ld64u(src + p - 8u - bk)) ^ ld64u(src + c - 8u - bk);
+                        const uint64_t x = ld64u(src + p - 8u - bk) ^ ld64u(src + cc - 8u - bk);
                         if (x) { bk += (uint32_t)__clzll((unsigned long long)x) >> 3; break; }
                         bk += 8u;
                     }
-                    if (bk + 8u > blim) while (bk < blim && src[p - 1u - bk] == src[c - 1u - bk]) bk++;
+                    if (bk + 8u > blim) while (bk < blim && src[p - 1u - bk] == src[cc - 1u - bk]) bk++;
                 }
-                bl[k] = bk;
             }
+            fl[k] = f;
+            bl[k] = bk;
+        }
+        if (in[j]) {
+            ((uint4 *)cand)[p] = make_uint4(c[j][0], c[j][1], c[j][2], c[j][3]);
             flen[p] = make_uint2(fl[0] | (fl[1] << 16), fl[2] | (fl[3] << 16));
             blen[p] = make_uint2(bl[0] | (bl[1] << 16), bl[2] | (bl[3] << 16));
         }
     }
+  }
 }
 
 /* ---- kernel 2: parse -------------------------------------------------------------------- */
