@@ -351,7 +351,7 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
             if (h.recs) hipLaunchKernelGGL(k4::k4_hc_parse_rec_kernel, dim3((unsigned)((cnt + k4::HC_REC_WAVES_PER_WG - 1) / k4::HC_REC_WAVES_PER_WG)), dim3(64 * k4::HC_REC_WAVES_PER_WG), 0, pstream, h);
             else hipLaunchKernelGGL(k4::k4_hc_parse_kernel, dim3((unsigned)((cnt + k4::HC_PARSE_WAVES_PER_WG - 1) / k4::HC_PARSE_WAVES_PER_WG)), dim3(64 * k4::HC_PARSE_WAVES_PER_WG), 0, pstream, h);
         }
-        if (pickle) hipLaunchKernelGGL(k4::k4_pickle_finish_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a, d_enclen);
+        if (pickle) hipLaunchKernelGGL(k4::k4_pickle_finish_kernel, dim3((unsigned)((cnt + k4::PICKLE_FINISH_WAVES_PER_WG - 1) / k4::PICKLE_FINISH_WAVES_PER_WG)), dim3(64 * k4::PICKLE_FINISH_WAVES_PER_WG), 0, stream, a, d_enclen);
         K4_HIP(ctx, hipGetLastError());
     }
     return K4LZ4_OK;
@@ -472,7 +472,7 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             rc = launch_inner(ctx, KIND_ENCODE, src, srcOff + first, srcLen + first, dst, d_encoff, d_enccap, d_enclen, cnt, level,
                               (flags & (K4LZ4_FLAG_NO_REORDER | K4LZ4_FLAG_X32)) | K4LZ4_FLAG_RAW_RETURN | FLAG_SEGMENTS_OK, stream, nullptr, hostLen ? hostLen + first : nullptr);
             if (rc != K4LZ4_OK) return rc;
-            hipLaunchKernelGGL(k4::k4_pickle_finish_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, a, d_enclen);
+            hipLaunchKernelGGL(k4::k4_pickle_finish_kernel, dim3((unsigned)((cnt + k4::PICKLE_FINISH_WAVES_PER_WG - 1) / k4::PICKLE_FINISH_WAVES_PER_WG)), dim3(64 * k4::PICKLE_FINISH_WAVES_PER_WG), 0, stream, a, d_enclen);
             K4_HIP(ctx, hipGetLastError());
         }
         return K4LZ4_OK;

@@ -181,10 +181,12 @@ __global__ __launch_bounds__(256) void k4_pickle_prep_kernel(BatchArgs a, uint64
     encCap[b] = (U > 0 && a.dstCap[b] >= 1 + 4 + U) ? U - 1 : 0;
 }
 /* finish: encLen[i] = LLxx-level encoder result for message i */
-__global__ __launch_bounds__(64) void k4_pickle_finish_kernel(BatchArgs a, const int32_t *encLen)
+constexpr int PICKLE_FINISH_WAVES_PER_WG = 4;        /* (one-wave workgroups are placed badly: see k4_hc_parse_kernel) */
+__global__ __launch_bounds__(64 * PICKLE_FINISH_WAVES_PER_WG) void k4_pickle_finish_kernel(BatchArgs a, const int32_t *encLen)
 {
     const int lane = lane_id();
-    const long long b = (long long)blockIdx.x;
+    const long long b = (long long)blockIdx.x * PICKLE_FINISH_WAVES_PER_WG + (long long)uni(threadIdx.x >> 6);
+    if (b >= a.n) return;
     const int U = a.srcLen[b];
     int r;
     if (U <= 0) r = 0;

@@ -320,7 +320,7 @@ int k4emu_pickle_seg_batch(const uint8_t *src, const uint64_t *srcOff, const int
     if (hdr.n_blocks) k4emu::launch_fn(dim3(hdr.n_blocks), dim3(64), [=] { k4::k4_seg_join_kernel(e, g); }, threads);
     if (stats) { stats[4] = hdr.n_resumed; stats[5] = hdr.n_resume_stops; stats[6] = hdr.n_plain; }
     const int32_t *el = encLen.data();
-    k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_pickle_finish_kernel(a, el); }, threads);
+    k4emu::launch_fn(dim3((unsigned)((n + k4::PICKLE_FINISH_WAVES_PER_WG - 1) / k4::PICKLE_FINISH_WAVES_PER_WG)), dim3(64 * k4::PICKLE_FINISH_WAVES_PER_WG), [=] { k4::k4_pickle_finish_kernel(a, el); }, threads);
     return 0;
 }
 
