@@ -638,10 +638,11 @@ int launch_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t *
             pa.slot_recs = slot_recs ? 1u : 0u;
             pa.migrate = ctx->parse_migrate ? 1u : 0u;
             pa.big = any_big ? 1u : 0u;
-            if (queue || seg_two_step) {
-                K4_HIP(ctx, hipMemsetAsync(pa.meta + 2 * cnt, 0, 32, stream));
-                if (queue) pa.queue = pa.meta + 2 * cnt;
-            }
+            /* eight words behind the counts: the two launches' queues (three words each) and, word 3, the number of blocks the first
+             * launch leaves to the second */
+            K4_HIP(ctx, hipMemsetAsync(pa.meta + 2 * cnt, 0, 32, stream));
+            if (queue) pa.queue = pa.meta + 2 * cnt;
+            pa.nbig = pa.meta + 2 * cnt + 3;
             /* (the first launch also says whose every block is -- PARSE_BIG / PARSE_REST --, so it runs even without a block of its own) */
             hipLaunchKernelGGL(k4::k4_parse_kernel, dim3((unsigned)nwg), dim3((unsigned)(64 * waves)), 0, stream, a, pa);
             if (seg_two_step) {
@@ -1284,9 +1285,17 @@ int run_host_inner(k4lz4_ctx *ctx, Kind kind, const uint8_t *src, const uint64_t
             if (he != hipSuccess) return finish(hip_fail(ctx, he, "hipEventRecord"));
         }
         DictArgs dpart = ddev;
-        /* (the kernels' target is the context's staging buffer: a hostile stream's offset-0 matches are zeroed there instead of handing
-         * this caller what an earlier call left in it -- ADVICE round 5) */
-        rc = launch(ctx, kind, ctx->d_src, d_soff + b0, d_slen + b0, ctx->d_dst, d_doff + b0, d_cap + b0, d_out + b0, cnt, level, flags | k4::FLAG_ZERO_GAPS, st,
+        /* The kernels' target is the context's staging buffer, and a hostile stream with a match offset of 0 "copies output bytes onto
+         * themselves" (LL64.dec.cs:408-418): those bytes stay what the target held.  Decode-like calls therefore start from a zeroed
+         * target (this part's range of it; a memset on the device, ~0.1 ms per 256 MB beside the milliseconds of PCIe), so that such
+         * bytes are zeros and never what an earlier call of this context left there.  Not in the kernels: carrying the
+         * case through decode_block cost the pair kernel five spilled VGPRs and the single-wave kernels a wave per SIMD. */
+        if (kind != KIND_ENCODE && kind != KIND_PICKLE) {
+            const uint64_t lo_d = h_doff[(size_t)b0];
+            const uint64_t hi_d = b1 < n ? h_doff[(size_t)b1] : dtotal;
+            if (hi_d > lo_d) { const hipError_t me = hipMemsetAsync(ctx->d_dst + lo_d, 0, (size_t)(hi_d - lo_d), st); if (me != hipSuccess) return finish(hip_fail(ctx, me, "hipMemsetAsync")); }
+        }
+        rc = launch(ctx, kind, ctx->d_src, d_soff + b0, d_slen + b0, ctx->d_dst, d_doff + b0, d_cap + b0, d_out + b0, cnt, level, flags, st,
                     &dpart, srcLen + b0);
         if (rc != K4LZ4_OK) return finish(rc);
         he = hipMemcpyAsync(h_len + b0, d_out + b0, (size_t)cnt * 4, hipMemcpyDeviceToHost, st);
@@ -1791,24 +1800,10 @@ int k4lz4_xxh32_batch(k4lz4_ctx *ctx, const uint8_t *data, const uint64_t *off, 
     return K4LZ4_OK;
 }
 
-static int decode_chain_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *blkOff, const uint32_t *blkLen,
-                               const uint64_t *firstBlk, const uint32_t *nBlk, const int32_t *blockSize,
-                               const uint8_t *chained, uint8_t *dst, const uint64_t *dstOff, const uint64_t *dstCap,
-                               int64_t *outLen, int64_t nStreams, void *stream, bool staged);
-
 int k4lz4_decode_chain_batch_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *blkOff, const uint32_t *blkLen,
                                     const uint64_t *firstBlk, const uint32_t *nBlk, const int32_t *blockSize,
                                     const uint8_t *chained, uint8_t *dst, const uint64_t *dstOff, const uint64_t *dstCap,
                                     int64_t *outLen, int64_t nStreams, void *stream)
-{
-    return decode_chain_device(ctx, src, blkOff, blkLen, firstBlk, nBlk, blockSize, chained, dst, dstOff, dstCap, outLen, nStreams, stream, false);
-}
-
-/* staged: the target is the context's staging buffer (the host-pointer entry point): offset-0 matches are zeroed there */
-static int decode_chain_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t *blkOff, const uint32_t *blkLen,
-                               const uint64_t *firstBlk, const uint32_t *nBlk, const int32_t *blockSize,
-                               const uint8_t *chained, uint8_t *dst, const uint64_t *dstOff, const uint64_t *dstCap,
-                               int64_t *outLen, int64_t nStreams, void *stream, bool staged)
 {
     if (!ctx) return fail(nullptr, K4LZ4_E_ARG, "ctx is NULL");
     if (nStreams < 0 || (nStreams > 0 && (!src || !blkOff || !blkLen || !firstBlk || !nBlk || !blockSize || !chained || !dst ||
@@ -1816,7 +1811,7 @@ static int decode_chain_device(k4lz4_ctx *ctx, const uint8_t *src, const uint64_
         return fail(ctx, K4LZ4_E_ARG, "bad argument");
     if (nStreams == 0) return K4LZ4_OK;
     K4_HIP(ctx, hipSetDevice(ctx->device));
-    k4::ChainArgs a{src, blkOff, blkLen, firstBlk, nBlk, blockSize, chained, dst, dstOff, dstCap, (long long *)outLen, nStreams, ctx->d_status, staged ? 1 : 0};
+    k4::ChainArgs a{src, blkOff, blkLen, firstBlk, nBlk, blockSize, chained, dst, dstOff, dstCap, (long long *)outLen, nStreams, ctx->d_status};
     const unsigned grid = (unsigned)((nStreams + k4::DECODE_WAVES_PER_WG - 1) / k4::DECODE_WAVES_PER_WG);
     if (nStreams <= 16 * (int64_t)ctx->cu_count && !ctx->no_pair) {  /* room for two waves per stream */
         hipLaunchKernelGGL(k4::k4_decode_chain_pair_kernel, dim3((unsigned)((nStreams + k4::DECODE_PAIRS_PER_WG - 1) / k4::DECODE_PAIRS_PER_WG)),
@@ -1882,8 +1877,9 @@ int k4lz4_decode_chain_batch(k4lz4_ctx *ctx, const uint8_t *src, const uint64_t 
     K4_HIP(ctx, hipMemcpyAsync(d_nblk, nBlk, (size_t)nStreams * 4, hipMemcpyHostToDevice, st));
     K4_HIP(ctx, hipMemcpyAsync(d_bsize, blockSize, (size_t)nStreams * 4, hipMemcpyHostToDevice, st));
     K4_HIP(ctx, hipMemcpyAsync(d_chained, chained, (size_t)nStreams, hipMemcpyHostToDevice, st));
-    rc = decode_chain_device(ctx, ctx->d_src, d_boff, d_blen, d_first, d_nblk, d_bsize, d_chained, ctx->d_dst, d_doff,
-                             d_dcap, d_out, nStreams, st, true);
+    K4_HIP(ctx, hipMemsetAsync(ctx->d_dst, 0, (size_t)dtotal, st));       /* (offset-0 matches of a hostile stream leave zeros, not an earlier call's bytes: see run_host_inner) */
+    rc = k4lz4_decode_chain_batch_device(ctx, ctx->d_src, d_boff, d_blen, d_first, d_nblk, d_bsize, d_chained, ctx->d_dst, d_doff,
+                                         d_dcap, d_out, nStreams, st);
     if (rc != K4LZ4_OK) return rc;
     K4_HIP(ctx, hipMemcpyAsync(outLen, d_out, (size_t)nStreams * 8, hipMemcpyDeviceToHost, st));
     if (dtotal) K4_HIP(ctx, hipMemcpyAsync(ctx->h_stage, ctx->d_dst, (size_t)dtotal, hipMemcpyDeviceToHost, st));

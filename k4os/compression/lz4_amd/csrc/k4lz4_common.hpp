@@ -34,8 +34,6 @@ enum : int {
     FLAG_PICKLE_WRITER = 2,
     FLAG_X32 = 128,        /* fast encoder: LZ4Codec.Enforce32 -- the 32-bit engine's hash for inputs of 64 KiB and more */
     FLAG_PARTIAL = 32,     /* decode: LZ4_decompress_safe_partial semantics, dstCap = target size */
-    FLAG_ZERO_GAPS = 1 << 21,  /* decode-like calls that stage through the context's buffers (set by the host-pointer entry points, not part of
-                                * the API): the bytes of an offset-0 match are zeroed instead of left as they are (k4lz4_decode.hpp, DecodeDict) */
 };
 
 struct BatchArgs {

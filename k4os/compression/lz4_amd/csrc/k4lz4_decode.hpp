@@ -207,14 +207,7 @@ __device__ __forceinline__ void wave_match_copy(uint8_t *out, uint32_t op, uint3
  * LL64.dec.cs:523-546): mode 0 none, 1 prefix (the dictionary sits immediately before the output:
  * `size` bytes, 65536 when it is 64 KiB-1 or more -- withPrefix64k), 2 external.
  * `end` = one past the last dictionary byte (mode 1: == out). */
-struct DecodeDict {
-    const uint8_t *end; uint32_t size; int mode;
-    /* (rides along with the dictionary because every caller of decode_block already hands one over) a match with offset 0 -- hostile
-     * input, which the reference lets through: LL64.dec.cs:408-418 copies output bytes onto themselves -- leaves its bytes as they
-     * are (false: device buffers, the caller's target stays untouched there like the reference's) or zeroes them (true: the call
-     * stages through the context's buffers, whose old contents -- another call's output -- must not reach this caller) */
-    bool zero_gaps;
-};
+struct DecodeDict { const uint8_t *end; uint32_t size; int mode; };
 
 /* match that starts before the block: `from_dict` bytes come out of the dictionary, the rest from
  * the start of the output with the usual replicating semantics (LL64.dec.cs:342-378) */
@@ -377,7 +370,7 @@ __device__ __forceinline__ bool pipe_wait(const uint32_t *pipe, int which, uint3
 template <bool PROF = false, int ROLE = 0, bool HOP2 = false>
 __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uint8_t *out, int out_size, int lane,
                                             uint32_t *lds, unsigned long long *pc = nullptr, bool partial = false,
-                                            DecodeDict dict = DecodeDict{nullptr, 0u, 0, false}, uint32_t *pipe = nullptr,
+                                            DecodeDict dict = DecodeDict{nullptr, 0u, 0}, uint32_t *pipe = nullptr,
                                             uint32_t *seq = nullptr, uint32_t *pace = nullptr)
 {
     /* lowPrefix relative to out (<= 0), the size used by the offset check (:149,:338) */
@@ -651,14 +644,14 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                 } else if (partial && cpy > oend - MATCH_SAFEGUARD) {     /* :387-406: truncated final match */
                     const uint32_t mlen = (int64_t)length < oend - op ? length : (uint32_t)(oend - op);
                     s_moff = offset;
-                    s_mlen = (offset != 0u || dict.zero_gaps) ? mlen : 0u;
+                    s_mlen = offset != 0u ? mlen : 0u;
                     adv = mlen;
                     gap = gap || (offset == 0u && mlen != 0u);
                     if (op + (int64_t)mlen == oend) last = true;
                 } else {
                     if (cpy > oend - MATCH_SAFEGUARD && cpy > oend - LASTLITERALS) { err = (int)(-ip) - 1; break; }  /* :427-433 */
                     s_moff = offset;
-                    s_mlen = (offset != 0u || dict.zero_gaps) ? length : 0u;       /* offset 0 (hostile): output left as is, or zeroed (DecodeDict::zero_gaps) */
+                    s_mlen = offset != 0u ? length : 0u;       /* offset 0 (hostile): output left as is */
                     adv = length;
                     gap = gap || offset == 0u;
                 }
@@ -861,8 +854,7 @@ __device__ __forceinline__ int decode_block(const uint8_t *in, int src_size, uin
                     big &= big - 1;
                     const uint32_t g_dst = __builtin_amdgcn_readlane(mdst, g), g_off = __builtin_amdgcn_readlane(v_moff, g),
                                    g_len = __builtin_amdgcn_readlane(v_mlen, g);
-                    if (g_off == 0u) wave_fill(out + g_dst, (uint8_t)0, g_len, lane);              /* (only with zero_gaps: else such a sequence has no match part) */
-                    else if ((negmask >> g) & 1ull) wave_dict_copy(out, dict.end, g_dst, g_off - g_dst, g_len, lane);
+                    if ((negmask >> g) & 1ull) wave_dict_copy(out, dict.end, g_dst, g_off - g_dst, g_len, lane);
                     else wave_match_copy(out, g_dst, g_off, g_len, lane);
                 }
                 pend &= ~rmask;
@@ -906,7 +898,7 @@ constexpr int DECODE_WAVES_PER_WG = 2;       /* measured on 1 M x 4 KiB blocks: 
 /* LL64.LZ4_decompress_safe_usingDict (LL64.dec.cs:523-546): no dictionary / prefix / external */
 __device__ __forceinline__ DecodeDict block_dict(const BatchArgs &a, long long b, const uint8_t *out)
 {
-    DecodeDict d{nullptr, 0u, 0, (a.flags & FLAG_ZERO_GAPS) != 0};
+    DecodeDict d{nullptr, 0u, 0};
     if (!a.dict || !a.dictLen) return d;
     const int len = a.dictLen[b];
     if (len <= 0) return d;
@@ -1007,7 +999,7 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) void k4_decode_pair_prof
     const int cap = a.dstCap[b];
     const uint8_t *in = a.src + a.srcOff[b];
     uint8_t *out = a.dst + a.dstOff[b];
-    const DecodeDict dict{nullptr, 0u, 0, false};
+    const DecodeDict dict{nullptr, 0u, 0};
     if (src_len <= 0) return;
     if (role == 0) {
         decode_block<true, 1>(in, src_len, out, cap < 0 ? 0 : cap, lane, ring, a.prof + 2 * PROF_STRIDE * b, false, dict, pipe);

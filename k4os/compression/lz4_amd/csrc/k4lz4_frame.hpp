@@ -66,7 +66,6 @@ struct ChainArgs {
     long long *outLen;           /* per stream: bytes produced, -6 a block does not decode, -9 target too small */
     long long n;
     uint32_t *status;            /* the context's status word (k4lz4_common.hpp), or nullptr */
-    int zero_gaps;               /* the target is the context's staging buffer: offset-0 matches are zeroed (k4lz4_decode.hpp, DecodeDict) */
 };
 
 __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_decode_chain_kernel(ChainArgs a)
@@ -96,7 +95,7 @@ __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_decode_chain_kern
             op += n;
         } else {
             const int want = (int)(room < (uint64_t)block_size ? room : (uint64_t)block_size);
-            DecodeDict dict{nullptr, 0u, 0, a.zero_gaps != 0};
+            DecodeDict dict{nullptr, 0u, 0};
             if (chained && op > 0) {
                 dict.end = out + op;
                 dict.size = op >= 65535u ? 65536u : (uint32_t)op;
@@ -149,7 +148,7 @@ __global__ __launch_bounds__(128 * DECODE_PAIRS_PER_WG) __attribute__((amdgpu_wa
             op += n;
         } else {
             const int want = (int)(room < (uint64_t)block_size ? room : (uint64_t)block_size);
-            DecodeDict dict{nullptr, 0u, 0, a.zero_gaps != 0};
+            DecodeDict dict{nullptr, 0u, 0};
             if (chained && op > 0) {
                 dict.end = out + op;
                 dict.size = op >= 65535u ? 65536u : (uint32_t)op;

@@ -68,6 +68,8 @@ struct ParseArgs {
     uint32_t migrate;       /* != 0: blocks without an LDS table move into one when a block of their workgroup is done with it (ParseCtl) */
     uint32_t inline_emit;   /* != 0: the wave that parsed a block writes it out as well (k4_emit_kernel is not launched): the blocks that are
                              * through early do that while the others still parse, only the last ones' bytes come on top of the launch */
+    uint32_t *nbig;         /* nullptr, or a zeroed word: k4_parse_kernel counts the blocks it marks PARSE_BIG there, and the launch behind it leaves at
+                             * once when there are none (a batch of 262 144 small blocks otherwise costs it a ticket per block for nothing) */
     uint32_t big;           /* != 0: k4_parse_big_kernel follows this launch and takes the blocks of 65 547 bytes and more (needs inline_emit) */
     uint32_t slot_recs;     /* != 0 (with inline_emit): a block's records are written out by the wave that made them, right behind its parse,
                              * so `recs` holds one slot per WAVE of the launch (workgroup x waves per workgroup + wave) instead of one per block:
@@ -1126,6 +1128,7 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
     const uint32_t lds_tables = waves < (uint32_t)PARSE_LDS_TABLES ? waves : (uint32_t)PARSE_LDS_TABLES;
     uint32_t *seen = lds + 4096u * (uint32_t)PARSE_LDS_TABLES + (uint32_t)PARSE_SEEN_DWORDS * wave;
     const bool in_lds = wave < lds_tables;
+    if (U32 && p.nbig && uni(*(volatile uint32_t *)p.nbig) == 0u) return;          /* the launch before this one found nothing for it */
     if (p.migrate) {
         if (threadIdx.x == 0) lds[PARSE_LDS_DWORDS - 1] = 0u;
         __syncthreads();
@@ -1155,7 +1158,10 @@ __device__ __forceinline__ void parse_kernel_body(const BatchArgs &a, const Pars
         const bool big = src_len >= LIMIT_64K && a.accel == 1;
         const bool mine = a.accel == 1 && (U32 ? big : (src_len >= (int)PARSE_MIN_LEN && src_len < LIMIT_64K));
         if (!mine) {
-            if (!U32 && lane == 0) { meta[0] = (big && p.big) ? PARSE_BIG : PARSE_REST; meta[1] = 0u; }
+            if (!U32 && lane == 0) {
+                meta[0] = (big && p.big) ? PARSE_BIG : PARSE_REST; meta[1] = 0u;
+                if (big && p.big && p.nbig) atomicAdd(p.nbig, 1u);
+            }
         } else {
             uint32_t n = 0u;
             const int ret = parse_one<K, TT, false>(a, p, lds, seen, in_lds, wave, waves, lane, b, a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], a.dstCap[b], nullptr, &n);

@@ -90,7 +90,7 @@ __device__ __forceinline__ PickleHeader unpickle_header(const uint8_t *src, int 
  * -1 where the reference throws (unpickle.cs:115-128,:134,:143-144) */
 template <int ROLE = 0, bool HOP2 = false>
 __device__ __forceinline__ int unpickle_block(const uint8_t *src, int len, uint8_t *dst, int cap, int lane, uint32_t *lds,
-                                              uint32_t *pipe = nullptr, uint32_t *pace = nullptr, bool zero_gaps = false)
+                                              uint32_t *pipe = nullptr, uint32_t *pace = nullptr)
 {
     if (len == 0) return 0;
     const PickleHeader h = unpickle_header(src, len);
@@ -104,7 +104,7 @@ __device__ __forceinline__ int unpickle_block(const uint8_t *src, int len, uint8
     int decoded = 0;                                        /* LZ4Codec.Decode: empty -> 0 */
     if (data_len > 0) {
         decoded = decode_block<false, ROLE, HOP2>(src + h.data_offset, data_len, dst, cap, lane, lds, nullptr, false,
-                                                  DecodeDict{nullptr, 0u, 0, zero_gaps}, pipe, nullptr, pace);
+                                                  DecodeDict{nullptr, 0u, 0}, pipe, nullptr, pace);
         if (decoded <= 0) decoded = -1;
     }
     return decoded == h.result_len ? decoded : -1;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * DECODE_WAVES_PER_WG) void k4_unpickle_kernel(B
     const long long slot = (long long)blockIdx.x * DECODE_WAVES_PER_WG + (long long)wave;
     if (slot >= a.n) return;
     const long long b = a.order ? (long long)uni(a.order[slot]) : slot;    /* longest envelope first */
-    const int r = unpickle_block(a.src + a.srcOff[b], a.srcLen[b], a.dst + a.dstOff[b], a.dstCap[b], lane, lds[wave], nullptr, nullptr, (a.flags & FLAG_ZERO_GAPS) != 0);
+    const int r = unpickle_block(a.src + a.srcOff[b], a.srcLen[b], a.dst + a.dstOff[b], a.dstCap[b], lane, lds[wave]);
     if (lane == 0) a.outLen[b] = r;
 }
 
@@ -152,9 +152,9 @@ __device__ __forceinline__ void unpickle_pair_kernel_body(const BatchArgs &a, ui
     const int cap = a.dstCap[b];
     if (role == 0) {
         if (K4_DEC_PACE) Pace::begin(a.pace, pipe + 2, lane);
-        unpickle_block<1, HOP2>(src, len, dst, cap, lane, ring, pipe, a.pace, (a.flags & FLAG_ZERO_GAPS) != 0);
+        unpickle_block<1, HOP2>(src, len, dst, cap, lane, ring, pipe, a.pace);
     } else {
-        const int r = unpickle_block<2>(src, len, dst, cap, lane, ring, pipe, a.pace, (a.flags & FLAG_ZERO_GAPS) != 0);
+        const int r = unpickle_block<2>(src, len, dst, cap, lane, ring, pipe, a.pace);
         if (lane == 0) a.outLen[b] = r;
     }
 }

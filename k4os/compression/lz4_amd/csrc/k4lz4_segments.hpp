@@ -207,6 +207,7 @@ __device__ __forceinline__ void parse_seg_kernel_body(const BatchArgs &a, const 
         __syncthreads();
     }
     const uint32_t n_work = uni(g.hdr->n_work);
+    if (n_work == 0u && p.nbig && uni(*(volatile uint32_t *)p.nbig) == 0u) return;    /* no block of 65 547 bytes or more in this batch */
     const uint32_t total = n_work + (uint32_t)a.n;
     for (;;) {
         uint32_t t = 0u;

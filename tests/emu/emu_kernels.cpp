@@ -146,6 +146,7 @@ int k4emu_encode_parse_batch(const uint8_t *src, const uint64_t *srcOff, const i
     p.migrate = migrate ? 1u : 0u;
     std::vector<uint32_t> q(8, 0u);
     p.big = inline_emit ? 1u : 0u;                      /* blocks of 65 547 bytes and more: k4_parse_big_kernel behind the first launch */
+    p.nbig = q.data() + 3;
     std::vector<uint32_t> ident;
     if (use_queue) {
         p.queue = q.data();
@@ -292,7 +293,7 @@ int k4emu_pickle_seg_batch(const uint8_t *src, const uint64_t *srcOff, const int
         ident.resize((size_t)n); for (long long i = 0; i < n; i++) ident[(size_t)i] = (uint32_t)i;
         e.order = ident.data();
         p.recs = recs.data(); p.meta = meta.data(); p.gtab = gtab.data();
-        p.inline_emit = 1u; p.slot_recs = 1u; p.migrate = 1u; p.big = 1u; p.queue = q.data();
+        p.inline_emit = 1u; p.slot_recs = 1u; p.migrate = 1u; p.big = 1u; p.queue = q.data(); p.nbig = q.data() + 3;
         k4emu::launch_fn(dim3(p.nwg), dim3(64 * waves), [=] { k4::k4_parse_kernel(e, p); }, 1);
         k4::ParseArgs pb = p;
         pb.queue = q.data() + 4;

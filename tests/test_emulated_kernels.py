@@ -745,57 +745,6 @@ def test_encode_x32_arm_matches_oracle(emu, oracle):
     assert differs >= 3            # the large compressible blocks really take the other hash
 
 
-@pytest.mark.parametrize("pair", [False, True])
-def test_offset_zero_bytes_are_zeroed_for_staged_targets(emu, oracle, pair):
-    """FLAG_ZERO_GAPS (set by the host-pointer entry points, whose target is the context's staging buffer): the bytes of an
-    offset-0 match -- which the reference copies onto themselves, LL64.dec.cs:408-418 -- come out as zeros instead of staying
-    what the buffer held; return values and all other bytes are unchanged.  Also in the partial arm."""
-    hostile = bytes([0x82]) + b"ABCDEFGH" + bytes([0, 0]) + bytes([0x21]) + b"ij" + bytes([8, 0]) + bytes([0xC0]) + b"123456789012"
-    rng = np.random.default_rng(3)
-    comp, caps = [np.frombuffer(hostile, np.uint8)], [64]
-    for i in range(40):
-        b = corpus.class_bytes(corpus.SILESIA_NAMES[i % 12], int(rng.integers(300, 9000)), i)
-        e = bytearray(oracle.encode(b))
-        # zero the offset of one sequence somewhere in the stream (walk the tokens)
-        ip, offs = 0, []
-        while ip < len(e):
-            t = e[ip]; ip += 1
-            L = t >> 4
-            if L == 15:
-                while True:
-                    x = e[ip]; ip += 1; L += x
-                    if x != 255: break
-            ip += L
-            if ip >= len(e): break
-            offs.append(ip); ip += 2
-            if (t & 15) == 15:
-                while True:
-                    x = e[ip]; ip += 1
-                    if x != 255: break
-        if not offs:
-            continue
-        k = offs[int(rng.integers(0, len(offs)))]
-        e[k] = 0; e[k + 1] = 0
-        comp.append(np.frombuffer(bytes(e), np.uint8)); caps.append(b.size)
-    emu.pair = pair
-    try:
-        src, soff, slen = pack(comp)
-        for flags, fill in ((FLAG_RAW, None), (FLAG_RAW | (1 << 21), 0)):
-            dst, doff, dcap = arena(caps)
-            out = emu.decode_batch(src, soff, slen, dst, doff, dcap, flags=flags)
-            for i, c in enumerate(comp):
-                n, ref = oracle.decompress_safe(c, caps[i], fill=0xCD if fill is None else fill)
-                assert out[i] == n, (flags, i)
-                if n > 0:
-                    assert dst[int(doff[i]):int(doff[i]) + n].tobytes() == ref[:n].tobytes(), (flags, i)
-            mask = np.ones(dst.size, bool)
-            for i in range(len(caps)):
-                mask[int(doff[i]):int(doff[i]) + max(int(out[i]), 0)] = False
-            assert (dst[mask] == 0xCD).all()
-    finally:
-        emu.pair = False
-
-
 @pytest.fixture()
 def emu_pair(emu):
     """the same emulator driver with decode routed to k4_decode_pair_kernel (parse wave + copy wave per block)"""
