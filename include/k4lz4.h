@@ -107,7 +107,7 @@ K4LZ4_API int k4lz4_ctx_device(const k4lz4_ctx *ctx);
 /* blocks until everything this ctx enqueued on `stream` (NULL = default stream) has finished; returns the call-level
  * status of that work (see "Trouble that is not a property of a block's data" above) */
 K4LZ4_API int k4lz4_synchronize(k4lz4_ctx *ctx, void *stream);
-/* HC levels (L03_HC and up) need work areas proportional to the batch: 36 bytes per input byte.  A device-resident call
+/* HC levels (L03_HC and up) need work areas proportional to the batch: 20 bytes per input byte (36 before round 6).  A device-resident call
  * does not know its batch's size on the host, so by default it reads it back -- ONE synchronisation per 4096 blocks.
  * After this call, device-resident HC encodes / pickles on ctx whose blocks total at most totalSrcBytes (per call) and are
  * at most longestBlock bytes each only enqueue, like every other *_device call; a batch that exceeds the reservation is

@@ -107,6 +107,7 @@ struct k4lz4_ctx {
     int cost_pct = 48;                    /* K4LZ4_COST_PCT: the LDS-table kernel's share of a batch's estimated cost (k4_order_kernel) */
     int dec_parts = 4, dec_parts_direct = 8;   /* K4LZ4_DEC_PARTS, K4LZ4_DEC_PARTS_DIRECT: parts of a big decode-like host-pointer call (2..MAX_PARTS); with a registered destination */
     int hop2_max_per_cu = 12;             /* K4LZ4_HOP2_MAX: pair decoders follow the token chain two links per hop in launches of up to this many blocks per CU */
+    bool hc_chain_parts = true;           /* K4LZ4_HC_CHAIN_OLD unsets it: blocks of at most 64 KiB build their chains with sixteen waves per block (k4_hc_chain_part_kernel) */
     int hc_mem_pct = 33;                  /* K4LZ4_HC_MEM_PCT: share of an HC chunk whose chains are built with the table in memory, beside the LDS-table kernel */
     int pace_min_per_cu = 6;              /* K4LZ4_PACE_MIN: batches of more blocks per CU than this use the priorities (measured: 8 per CU +3 % encode, +7 % decode; 4 per CU -1 %, -4 %) */
     bool use_pace = true;                 /* K4LZ4_NO_PACE: without the late-blocks-first priorities */
@@ -277,12 +278,12 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
             for (int64_t i = 0; i < cnt; i++) {
                 const int32_t len = hostLen[first + i];
                 if (len > 0) {
-                    tail[0] += (((unsigned long long)len + 3u) & ~3ull) * 36u;
+                    tail[0] += (((unsigned long long)len + 3u) & ~3ull) * k4::HC_WORK_PER_BYTE;
                     tail[1] = std::max<unsigned long long>(tail[1], (unsigned long long)len);
                 }
             }
         } else if (ctx->hc_res_total) {
-            tail[0] = (ctx->hc_res_total + 4u * (unsigned long long)cnt) * 36u;
+            tail[0] = (ctx->hc_res_total + 4u * (unsigned long long)cnt) * k4::HC_WORK_PER_BYTE;
             tail[1] = ctx->hc_res_longest;
             h.workCap = tail[0]; h.maxLen = ctx->hc_res_longest;
         } else {
@@ -301,8 +302,12 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
             if (rc != K4LZ4_OK) return rc;
         }
         h.work = ctx->d_hc_work;
-        if (tail[1] <= 65536) {
-            /* no block over 64 KiB (known from the host lengths, the reservation or the device): hash tables in LDS -- two blocks
+        if (tail[1] <= 65536 && ctx->hc_chain_parts) {
+            /* no block over 64 KiB: sixteen waves per block, each with a sixteenth of the hash values and of the table (round 6) */
+            h.nChain = cnt;
+            hipLaunchKernelGGL(k4::k4_hc_chain_part_kernel, dim3((unsigned)cnt), dim3(64 * k4::HC_CHAIN_PARTS), 0, stream, h);
+        } else if (tail[1] <= 65536) {
+            /* (rounds 3-5, K4LZ4_HC_CHAIN_OLD) no block over 64 KiB (known from the host lengths, the reservation or the device): hash tables in LDS -- two blocks
              * per CU, a wave each, which leaves the CU's other wave slots empty; so the last third of a big chunk goes through the
              * table-in-memory kernel on the second queue at the same time (its tables: 128 KiB per block, cleared here) */
             const int64_t n_mem = cnt >= 8 * (int64_t)ctx->cu_count ? cnt * ctx->hc_mem_pct / 100 : 0;
@@ -1440,6 +1445,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (const char *e = getenv("K4LZ4_DEC_PARTS")) ctx->dec_parts = std::max(2, std::min(MAX_PARTS, atoi(e)));
     if (const char *e = getenv("K4LZ4_DEC_PARTS_DIRECT")) ctx->dec_parts_direct = std::max(2, std::min(MAX_PARTS, atoi(e)));
     if (const char *e = getenv("K4LZ4_HOP2_MAX")) ctx->hop2_max_per_cu = std::max(0, atoi(e));
+    ctx->hc_chain_parts = getenv("K4LZ4_HC_CHAIN_OLD") == nullptr;
     if (const char *e = getenv("K4LZ4_HC_MEM_PCT")) ctx->hc_mem_pct = std::max(0, std::min(100, atoi(e)));
     ctx->use_segments = getenv("K4LZ4_NO_SEGMENTS") == nullptr;
     if (const char *e = getenv("K4LZ4_SEG_MIN")) ctx->seg_min = (uint32_t)std::max(65536 + 4096, atoi(e));

@@ -34,11 +34,11 @@
  *                        candidate.
  *
  * Scratch (context-owned, device): per block a 128 KiB hash table (u32 x 32768, zero = empty with
- * positions stored +1), prev[U] (u32), cand[U][4] (u32), flen[U][4] and blen[U][4] (u16: forward /
- * backward match length of position p against its k-th candidate, exact below HC_FLEN_CAP /
- * HC_BLEN_CAP), see k4_hc_layout_kernel.  With the lengths precomputed, level 3 (4 attempts =
- * exactly one record) needs no data compare at all in the common case: a search is one record
- * load, literal runs are skipped 64 positions per load.
+ * positions stored +1; blocks of at most 64 KiB keep theirs in LDS), prev[U] (u32) and one 16-byte record per
+ * position (its first four chain candidates as distances, and per candidate the forward / backward match
+ * length, exact below HC_FLEN_CAP / HC_BLEN_CAP: k4_hc_cand_kernel), see k4_hc_layout_kernel.  With the
+ * lengths precomputed, level 3 (4 attempts = exactly one record) needs no data compare at all in the common
+ * case: a search is one record load, literal runs are skipped 64 positions per load.
  */
 #pragma once
 #include "k4lz4_common.hpp"
@@ -89,7 +89,8 @@ __device__ __forceinline__ bool hc_scratch_ok(const HcArgs &a)
 __device__ __forceinline__ uint32_t hc_hash(uint32_t v) { return (v * 2654435761u) >> (MINMATCH * 8 - HC_HASH_LOG); }
 constexpr uint32_t HC_FLEN_CAP = 4 + 32;   /* precomputed match lengths are exact below this value */
 constexpr uint32_t HC_BLEN_CAP = 32;       /* precomputed backward lengths are exact below this value */
-__device__ __forceinline__ uint64_t hc_work_bytes(int len) { return len > 0 ? (((uint64_t)len + 3u) & ~3ull) * 36u : 0u; }
+constexpr uint32_t HC_WORK_PER_BYTE = 20u;   /* prev[] 4 + one 16-byte record (k4_hc_cand_kernel) */
+__device__ __forceinline__ uint64_t hc_work_bytes(int len) { return len > 0 ? (((uint64_t)len + 3u) & ~3ull) * HC_WORK_PER_BYTE : 0u; }
 
 /* exclusive scan of the per-block work sizes (one workgroup; n is at most a launch chunk) */
 __global__ __launch_bounds__(256) void k4_hc_layout_kernel(HcArgs a)
@@ -132,9 +133,13 @@ __global__ __launch_bounds__(256) void k4_hc_layout_kernel(HcArgs a)
  * TAB: the hash table, slot = position + 1 (0 = empty): uint32 in context scratch (any block length), or uint16 in LDS for
  * blocks of up to 64 KiB -- 4096 tables of 128 KiB in memory are 512 MiB of two-byte-at-a-time traffic past every cache,
  * 64 KiB of LDS per block is two blocks per CU and a look-up at LDS latency. */
-template <typename TAB>
-__device__ __forceinline__ void hc_chain_block(const uint8_t *src, uint32_t U, TAB *tab, uint32_t *prev, uint32_t *seen, int lane)
+/* PARTS > 1 (round 6, k4_hc_chain_part_kernel): the wave owns the hash values with h % PARTS == part and a table of 32768 / PARTS slots
+ * indexed by h / PARTS; it looks at every position of the block (the hash of 64 positions is a load, a multiply and a shift) and
+ * enters only its own -- PARTS waves per block side by side, each with a sixteenth of the table work and none of each other's. */
+template <typename TAB, int PARTS = 1>
+__device__ __forceinline__ void hc_chain_block(const uint8_t *src, uint32_t U, TAB *tab, uint32_t *prev, uint32_t *seen, int lane, uint32_t part = 0u)
 {
+    static_assert((PARTS & (PARTS - 1)) == 0, "a power of two");
     const uint32_t npos = U - 3u;                          /* positions whose 4 bytes exist */
     const unsigned long long below_me = (1ull << lane) - 1ull, above_me = ~(below_me | (1ull << lane));
     /* The source bytes of a step are asked for four steps ahead (unconditionally, at a clamped position), into a register
@@ -148,13 +153,14 @@ __device__ __forceinline__ void hc_chain_block(const uint8_t *src, uint32_t U, T
         for (uint32_t u = 0; u < 4u; u++) {
             const uint32_t p0 = q0 + 64u * u;
             const uint32_t p = p0 + (uint32_t)lane;
-            const bool act = p < npos;
             const uint32_t w = wq[u];
             wq[u] = ld32u(src + (p + 256u < npos ? p + 256u : 0u));
+            const uint32_t hh = hc_hash(w);
+            const bool act = p < npos && (PARTS == 1 || (hh & (uint32_t)(PARTS - 1)) == part);
             uint32_t h = 0, pr = HC_NONE;
             bool flagged = false;
             if (act) {
-                h = hc_hash(w);
+                h = PARTS == 1 ? hh : hh / (uint32_t)PARTS;
                 const uint32_t t = tab[h];
                 pr = t ? t - 1u : HC_NONE;
                 flagged = ((atomicOr(&seen[h >> 5], 1u << (h & 31u)) >> (h & 31u)) & 1u) != 0u;
@@ -229,11 +235,45 @@ __global__ __launch_bounds__(64 * HC_CHAIN_LDS_WAVES_PER_WG) void k4_hc_chain_ld
     hc_chain_block<uint16_t>(a.src + a.srcOff[b], (uint32_t)len, tab, (uint32_t *)(a.work + a.workOff[b]), seen, lane);
 }
 
+/* Round 6: sixteen waves per block, each with a sixteenth of the hash values (hc_chain_block<.., PARTS>): 2048 slots of 16 bits and 2048
+ * bits per wave, 68 KiB of LDS per block as before but sixteen waves working in it instead of one -- two blocks and 32 waves per CU
+ * where k4_hc_chain_lds_kernel had two waves (its step is a chain of LDS round trips with nothing to hide them behind).  Every block
+ * of the launch is at most 64 KiB long. */
+constexpr int HC_CHAIN_PARTS = 16;
+__global__ __launch_bounds__(64 * HC_CHAIN_PARTS) void k4_hc_chain_part_kernel(HcArgs a)
+{
+    __shared__ uint32_t seen_all[HC_CHAIN_PARTS][(1u << HC_HASH_LOG) / HC_CHAIN_PARTS / 32u];
+    __shared__ uint16_t tab_all[HC_CHAIN_PARTS][(1u << HC_HASH_LOG) / HC_CHAIN_PARTS];
+    const int lane = lane_id();
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    uint32_t *seen = seen_all[wave];
+    uint16_t *tab = tab_all[wave];
+    const long long b = (long long)blockIdx.x + (long long)a.blockBase;
+    if ((long long)blockIdx.x >= a.nChain) return;
+    const int len = a.srcLen[b];
+    if (len < MFLIMIT + 1 || len > 65536 || !hc_scratch_ok(a)) return;
+    for (uint32_t k = (uint32_t)lane; k < (1u << HC_HASH_LOG) / HC_CHAIN_PARTS / 32u; k += 64u) seen[k] = 0u;
+    for (uint32_t k = (uint32_t)lane; k < (1u << HC_HASH_LOG) / HC_CHAIN_PARTS / 2u; k += 64u) ((uint32_t *)tab)[k] = 0u;
+    lds_sync();
+    hc_chain_block<uint16_t, HC_CHAIN_PARTS>(a.src + a.srcOff[b], (uint32_t)len, tab, (uint32_t *)(a.work + a.workOff[b]), seen, lane, wave);
+}
+
 /* ---- kernel 1b: candidates + forward lengths, every position independently ------------------ */
+/* One 16-byte record per position (round 6; 32 bytes in three arrays before):
+ *   x = d0 | d1 << 16, y = d2 | d3 << 16   the first four chain candidates as distances p - c (1 .. 65535; 0: the chain has ended --
+ *                                          no earlier position with this hash, a chain step of 65535 or more, LL.high.cs:114, or a
+ *                                          candidate more than 65535 back, below lowestMatchIndex, LL64.high.cs:87-88)
+ *   z = fl0 | fl1 << 8 | fl2 << 16 | fl3 << 24   forward match lengths (0: the four bytes differ), exact below HC_FLEN_CAP
+ *   w = bl0 | ...                                equal bytes before the two positions, exact below HC_BLEN_CAP */
 constexpr int HC_CAND_POS_PER_WG = 1024;
-#ifndef K4_HC_CAND_GROUP
-#define K4_HC_CAND_GROUP 1
-#endif
+
+__device__ __forceinline__ uint32_t hc_rec_dist(const uint4 &r, int k) { return k == 0 ? r.x & 0xffffu : k == 1 ? r.x >> 16 : k == 2 ? r.y & 0xffffu : r.y >> 16; }
+
+/* equal bytes from a / b on, at most n (bytewise: block edges only) */
+__device__ __forceinline__ uint32_t hc_count_fwd_bytes(const uint8_t *a, const uint8_t *b, uint32_t n) { uint32_t i = 0; while (i < n && a[i] == b[i]) i++; return i; }
+/* equal bytes before a / b, at most n */
+__device__ __forceinline__ uint32_t hc_count_back_bytes(const uint8_t *a, const uint8_t *b, uint32_t n) { uint32_t i = 0; while (i < n && a[-1 - (int)i] == b[-1 - (int)i]) i++; return i; }
+
 __global__ __launch_bounds__(256) void k4_hc_cand_kernel(HcArgs a)
 {
     const long long b = (long long)blockIdx.x;
@@ -245,124 +285,91 @@ __global__ __launch_bounds__(256) void k4_hc_cand_kernel(HcArgs a)
     if (first >= npos) return;
     const uint8_t *src = a.src + a.srcOff[b];
     const uint32_t *prev = (const uint32_t *)(a.work + a.workOff[b]);
-    uint32_t *cand = (uint32_t *)prev + ((U + 3u) & ~3u);
-    uint2 *flen = (uint2 *)(cand + 4u * ((U + 3u) & ~3u));
-    uint2 *blen = flen + ((U + 3u) & ~3u);
+    uint4 *rec = (uint4 *)(prev + ((U + 3u) & ~3u));
     /* Per position: the first four chain candidates (a chain step of 65535 or more ends the walk: LL.high.cs:114 caps the delta, and such
      * a candidate is below lowestMatchIndex), per candidate the forward match length a search at p may use (:87-88 lowest, :120 the
      * 4-byte test, :126 LZ4_count up to matchlimit, capped at HC_FLEN_CAP) and the equal bytes before the two positions (LZ4HC_countBack
-     * without its limits, capped at HC_BLEN_CAP).  Written so that K4_HC_CAND_GROUP of a thread's four positions go TOGETHER, every
-     * step's loads -- prev[p], prev[c0], prev[c1], prev[c2], the candidates' first four bytes, their eight bytes forward and backward
-     * -- issued for all of them before the first is used.  Round 6 measured what that is worth: nothing -- groups of 1 / 2 / 4: 11.07 /
-     * 11.24 / 13.96 ms for the bench batch (46 / 73 / 131 VGPRs; the one-position loop of rounds 1-5: 11.58).  The kernel is not
-     * waiting for its chains: an unaligned eight-byte read at an address of its own per lane costs what it costs wherever it is
-     * issued (experiments/hc_cand_lds), and more in flight per wave only takes waves away. */
-    constexpr int PP = K4_HC_CAND_GROUP;                  /* positions of a thread that go together (of HC_CAND_POS_PER_WG / 256 = 4) */
-    static_assert((HC_CAND_POS_PER_WG / 256) % PP == 0, "groups divide a thread's positions");
+     * without its limits, capped at HC_BLEN_CAP).
+     * What the kernel costs is the number of loads at addresses of their own per lane (experiments/hc_cand_lds: about one lane per cycle
+     * and CU, whatever a lane reads), so a candidate is ONE such load: the sixteen bytes from four before it -- four bytes backward, the
+     * four of the :120 test, eight forward -- where rounds 1-5 made three (4 + 8 + 8 bytes).  More only for the candidates whose four
+     * bytes backward or eight forward are all equal.  The positions at a block's edges (the first four, the last eleven) count
+     * bytewise. */
     const uint32_t matchlimit = U - LASTLITERALS;
-  for (int grp = 0; grp < HC_CAND_POS_PER_WG / 256 / PP; grp++) {
-    uint32_t pos[PP], c[PP][4], seq[PP], lim[PP];
-    uint64_t pf0[PP], pb0[PP];
-    bool in[PP];
+    for (int j = 0; j < HC_CAND_POS_PER_WG / 256; j++) {
+        const uint32_t p = first + threadIdx.x + 256u * (uint32_t)j;
+        if (p >= npos) continue;
+        uint32_t c[4];
+        c[0] = prev[p];
 #pragma unroll
-    for (int j = 0; j < PP; j++) {
-        pos[j] = first + threadIdx.x + 256u * (uint32_t)(grp * PP + j);
-        in[j] = pos[j] < npos;
-        const uint32_t p = in[j] ? pos[j] : 0u;
-        c[j][0] = in[j] ? prev[p] : HC_NONE;
-        seq[j] = ld32u(src + p);
+        for (int k = 1; k < 4; k++) {
+            const uint32_t q = c[k - 1] != HC_NONE ? prev[c[k - 1]] : HC_NONE;
+            c[k] = (q != HC_NONE && c[k - 1] - q < (uint32_t)DISTANCE_MAX) ? q : HC_NONE;
+        }
         const uint32_t maxn = p + MINMATCH < matchlimit ? matchlimit - (p + MINMATCH) : 0u;
-        lim[j] = maxn < HC_FLEN_CAP - MINMATCH ? maxn : HC_FLEN_CAP - MINMATCH;
-        /* the position's own eight bytes behind its first four and before it: read once, not once per candidate */
-        pf0[j] = (in[j] && lim[j] >= 8u) ? ld64u(src + p + MINMATCH) : 0ull;
-        pb0[j] = (in[j] && p >= 8u) ? ld64u(src + p - 8u) : 0ull;
-    }
-#pragma unroll
-    for (int k = 1; k < 4; k++) {
-        uint32_t q[PP];
-#pragma unroll
-        for (int j = 0; j < PP; j++) q[j] = c[j][k - 1] != HC_NONE ? prev[c[j][k - 1]] : HC_NONE;
-#pragma unroll
-        for (int j = 0; j < PP; j++) c[j][k] = (q[j] != HC_NONE && c[j][k - 1] - q[j] < (uint32_t)DISTANCE_MAX) ? q[j] : HC_NONE;
-    }
-    /* which candidates a search at p may use, and their first four bytes */
-    bool ok[PP][4];
-    uint32_t cseq[PP][4];
-#pragma unroll
-    for (int j = 0; j < PP; j++) {
-        const uint32_t lowest = pos[j] > (uint32_t)DISTANCE_MAX ? pos[j] - (uint32_t)DISTANCE_MAX : 0u;
-        bool chain_ok = in[j];
+        const uint32_t lim = maxn < HC_FLEN_CAP - MINMATCH ? maxn : HC_FLEN_CAP - MINMATCH;
+        const bool inner = p >= 4u && p + 12u <= U;          /* the sixteen bytes around p, and around every candidate from 4 on, are the block's */
+        uint32_t o0 = 0, o1, o2 = 0, o3 = 0;                 /* bytes p-4 .. p-1, p .. p+3, p+4 .. p+11 */
+        if (inner) { const U128u v = ld128u(src + p - 4u); o0 = v.v[0]; o1 = v.v[1]; o2 = v.v[2]; o3 = v.v[3]; }
+        else o1 = ld32u(src + p);
+        uint32_t d[4], fl[4], bl[4];
+        bool chain_ok = true;
+        U128u cv[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            chain_ok = chain_ok && c[j][k] != HC_NONE && c[j][k] >= lowest;
-            ok[j][k] = chain_ok;
-            cseq[j][k] = chain_ok ? ld32u(src + c[j][k]) : 0u;
-        }
-    }
-    /* the first eight bytes forward and backward of every candidate that has the four */
-    uint64_t cf[PP][4], cb[PP][4];
-#pragma unroll
-    for (int j = 0; j < PP; j++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            ok[j][k] = ok[j][k] && cseq[j][k] == seq[j];
-            const uint32_t cc = c[j][k];
-            cf[j][k] = (ok[j][k] && lim[j] >= 8u) ? ld64u(src + cc + MINMATCH) : 0ull;
-            cb[j][k] = (ok[j][k] && cc >= 8u) ? ld64u(src + cc - 8u) : 0ull;
+            chain_ok = chain_ok && c[k] != HC_NONE && p - c[k] <= (uint32_t)DISTANCE_MAX;
+            d[k] = chain_ok ? p - c[k] : 0u;
+            cv[k].v[0] = 0u; cv[k].v[1] = 0u; cv[k].v[2] = 0u; cv[k].v[3] = 0u;
+            if (chain_ok && inner && c[k] >= 4u) cv[k] = ld128u(src + c[k] - 4u);
         }
 #pragma unroll
-    for (int j = 0; j < PP; j++) {
-        uint32_t fl[4], bl[4];
-        const uint32_t p = pos[j];
-#pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t cc = c[j][k];
             uint32_t f = 0, bk = 0;
-            if (ok[j][k]) {
-                const uint32_t l = lim[j];
-                uint32_t i = 0;
-                bool more = true;                       /* the count is not finished by the first eight bytes */
-                if (l >= 8u) {
-                    const uint64_t x = pf0[j] ^ cf[j][k];
-                    if (x) { i = (uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3; more = false; }
-                    else i = 8u;
-                }
-                if (more) {
-                    while (i + 8u <= l) {
-                        const uint64_t x = ld64u(src + p + MINMATCH + i) ^ ld64u(src + cc + MINMATCH + i);
-                        if (x) { i += (uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3; break; }
-                        i += 8u;
-                    }
-                    if (i + 8u > l) while (i < l && src[p + MINMATCH + i] == src[cc + MINMATCH + i]) i++;
-                }
-                f = MINMATCH + i;
-                /* equal bytes before the two positions */
+            const uint32_t cc = c[k];
+            if (d[k] != 0u) {
                 const uint32_t blim = cc < HC_BLEN_CAP ? cc : HC_BLEN_CAP;       /* cc < p */
-                more = true;
-                if (blim >= 8u) {
-                    const uint64_t x = pb0[j] ^ cb[j][k];
-                    if (x) { bk = (uint32_t)__clzll((unsigned long long)x) >> 3; more = false; }
-                    else bk = 8u;
-                }
-                if (more) {
-                    while (bk + 8u <= blim) {
-                        const uint64_t x = ld64u(src + p - 8u - bk) ^ ld64u(src + cc - 8u - bk);
-                        if (x) { bk += (uint32_t)__clzll((unsigned long long)x) >> 3; break; }
-                        bk += 8u;
+                if (inner && cc >= 4u) {
+                    if (cv[k].v[1] == o1) {
+                        uint32_t i = 0;
+                        if (lim >= 8u) {
+                            const uint64_t x = (((uint64_t)(o3 ^ cv[k].v[3])) << 32) | (uint64_t)(o2 ^ cv[k].v[2]);
+                            if (x) i = (uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3;
+                            else {
+                                i = 8u;
+                                while (i + 8u <= lim) {
+                                    const uint64_t y = ld64u(src + p + MINMATCH + i) ^ ld64u(src + cc + MINMATCH + i);
+                                    if (y) { i += (uint32_t)(__ffsll((unsigned long long)y) - 1) >> 3; break; }
+                                    i += 8u;
+                                }
+                                if (i + 8u > lim) i += hc_count_fwd_bytes(src + p + MINMATCH + i, src + cc + MINMATCH + i, lim - i);
+                            }
+                        } else {
+                            i = hc_count_fwd_bytes(src + p + MINMATCH, src + cc + MINMATCH, lim);
+                        }
+                        f = MINMATCH + i;
+                        const uint32_t xb = o0 ^ cv[k].v[0];               /* blim >= 4 */
+                        if (xb) bk = (uint32_t)__clz((int)xb) >> 3;
+                        else {
+                            bk = 4u;
+                            while (bk + 8u <= blim) {
+                                const uint64_t y = ld64u(src + p - 8u - bk) ^ ld64u(src + cc - 8u - bk);
+                                if (y) { bk += (uint32_t)__clzll((long long)y) >> 3; break; }
+                                bk += 8u;
+                            }
+                            if (bk + 8u > blim) bk += hc_count_back_bytes(src + p - bk, src + cc - bk, blim - bk);
+                        }
                     }
-                    if (bk + 8u > blim) while (bk < blim && src[p - 1u - bk] == src[cc - 1u - bk]) bk++;
+                } else if (ld32u(src + cc) == o1) {
+                    f = MINMATCH + hc_count_fwd_bytes(src + p + MINMATCH, src + cc + MINMATCH, lim);
+                    bk = hc_count_back_bytes(src + p, src + cc, blim);
                 }
             }
             fl[k] = f;
             bl[k] = bk;
         }
-        if (in[j]) {
-            ((uint4 *)cand)[p] = make_uint4(c[j][0], c[j][1], c[j][2], c[j][3]);
-            flen[p] = make_uint2(fl[0] | (fl[1] << 16), fl[2] | (fl[3] << 16));
-            blen[p] = make_uint2(bl[0] | (bl[1] << 16), bl[2] | (bl[3] << 16));
-        }
+        rec[p] = make_uint4(d[0] | (d[1] << 16), d[2] | (d[3] << 16), fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24),
+                            bl[0] | (bl[1] << 8) | (bl[2] << 16) | (bl[3] << 24));
     }
-  }
 }
 
 /* ---- kernel 2: parse -------------------------------------------------------------------- */
@@ -482,7 +489,7 @@ __device__ __forceinline__ void hc_search_serial(const uint8_t *src, const uint3
  * length so far `longest` (matchpos / startpos of the caller stay untouched unless it is beaten).
  * Four candidates per step, 16 lanes each.
  */
-__device__ __forceinline__ HcMatch hc_search(const uint8_t *src, const uint32_t *cand, uint32_t ip, uint32_t ilow,
+__device__ __forceinline__ HcMatch hc_search(const uint8_t *src, const uint4 *cand, uint32_t ip, uint32_t ilow,
                                              uint32_t matchlimit, int longest, uint32_t mpos, uint32_t spos,
                                              int max_attempts, int lane, const uint32_t *prev = nullptr, bool pa = false)
 {
@@ -496,8 +503,9 @@ __device__ __forceinline__ HcMatch hc_search(const uint8_t *src, const uint32_t 
     int attempts = max_attempts;
     bool first_record = true;
     while (attempts > 0) {
-        const uint4 rec = ((const uint4 *)cand)[rec_at];
-        uint32_t c = grp == 0 ? rec.x : grp == 1 ? rec.y : grp == 2 ? rec.z : rec.w;
+        const uint4 rec = cand[rec_at];
+        const uint32_t dist = hc_rec_dist(rec, grp);        /* the record's distances are from rec_at */
+        uint32_t c = dist ? rec_at - dist : HC_NONE;
         /* the first candidate of a search may be exactly 65535 back; later chain steps may not */
         bool ok = c != HC_NONE && c >= lowest && grp < attempts;
         if (!first_record && grp == 0 && ok) ok = rec_at - c < (uint32_t)DISTANCE_MAX;
@@ -511,7 +519,8 @@ __device__ __forceinline__ HcMatch hc_search(const uint8_t *src, const uint32_t 
         /* level 9: the first candidate whose chain step is 1 ends the four-at-a-time walk */
         int pa_at = -1;
         if (pa) {
-            uint32_t nx = grp == 0 ? rec.y : grp == 1 ? rec.z : grp == 2 ? rec.w : HC_NONE;
+            const uint32_t nd = grp < 3 ? hc_rec_dist(rec, grp + 1) : 0u;
+            uint32_t nx = nd ? rec_at - nd : HC_NONE;
             if (grp == 3 && ok) nx = prev[c];
             const unsigned long long pm = __ballot(ok && sub == 0 && nx != HC_NONE && c - nx == 1u);
             if (pm) {
@@ -593,45 +602,39 @@ __device__ __forceinline__ HcMatch hc_search(const uint8_t *src, const uint32_t 
     return r;
 }
 
-/* one position's precomputed record, wave-uniform */
-struct HcRec { uint32_t c0, c1, c2, c3, fl01, fl23, bl01, bl23; };
+/* one position's precomputed record (k4_hc_cand_kernel), wave-uniform */
+struct HcRec { uint32_t d01, d23, fl, bl; };
 
-__device__ __forceinline__ HcRec hc_load_rec(const uint32_t *cand, const uint2 *flen, const uint2 *blen, uint32_t p)
+__device__ __forceinline__ HcRec hc_load_rec(const uint4 *cand, uint32_t p)
 {
-    const uint4 rc = ((const uint4 *)cand)[p];
-    const uint2 f = flen[p], b = blen[p];
+    const uint4 rc = cand[p];
     HcRec r;
-    r.c0 = uni(rc.x); r.c1 = uni(rc.y); r.c2 = uni(rc.z); r.c3 = uni(rc.w);
-    r.fl01 = uni(f.x); r.fl23 = uni(f.y); r.bl01 = uni(b.x); r.bl23 = uni(b.y);
+    r.d01 = uni(rc.x); r.d23 = uni(rc.y); r.fl = uni(rc.z); r.bl = uni(rc.w);
     return r;
 }
 
-/* The records of 128 consecutive positions, two per lane: [base, base + 64) in rc / f / b, the 64 after them in rc2 / f2 /
- * b2.  The second set is asked for when the parse enters the first one and has a window's worth of work to arrive in;
- * the searches of the three-match arbitration look ahead by a match length at most, so they find their records here. */
-struct HcWindow { uint32_t base; bool valid; uint4 rc; uint2 f, b; uint4 rc2; uint2 f2, b2; };
+/* The records of 128 consecutive positions, two per lane: [base, base + 64) in rc, the 64 after them in rc2.  The second set is
+ * asked for when the parse enters the first one and has a window's worth of work to arrive in; the searches of the three-match
+ * arbitration look ahead by a match length at most, so they find their records here. */
+struct HcWindow { uint32_t base; bool valid; uint4 rc, rc2; };
 
-__device__ __forceinline__ HcRec hc_get_rec(const HcWindow &w, const uint32_t *cand, const uint2 *flen, const uint2 *blen, uint32_t p)
+__device__ __forceinline__ HcRec hc_get_rec(const HcWindow &w, const uint4 *cand, uint32_t p)
 {
     if (w.valid && p - w.base < 64u) {
         const int l = (int)(p - w.base);
         HcRec r;
-        r.c0 = __builtin_amdgcn_readlane(w.rc.x, l); r.c1 = __builtin_amdgcn_readlane(w.rc.y, l);
-        r.c2 = __builtin_amdgcn_readlane(w.rc.z, l); r.c3 = __builtin_amdgcn_readlane(w.rc.w, l);
-        r.fl01 = __builtin_amdgcn_readlane(w.f.x, l); r.fl23 = __builtin_amdgcn_readlane(w.f.y, l);
-        r.bl01 = __builtin_amdgcn_readlane(w.b.x, l); r.bl23 = __builtin_amdgcn_readlane(w.b.y, l);
+        r.d01 = __builtin_amdgcn_readlane(w.rc.x, l); r.d23 = __builtin_amdgcn_readlane(w.rc.y, l);
+        r.fl = __builtin_amdgcn_readlane(w.rc.z, l); r.bl = __builtin_amdgcn_readlane(w.rc.w, l);
         return r;
     }
     if (w.valid && p - w.base < 128u) {
         const int l = (int)(p - w.base - 64u);
         HcRec r;
-        r.c0 = __builtin_amdgcn_readlane(w.rc2.x, l); r.c1 = __builtin_amdgcn_readlane(w.rc2.y, l);
-        r.c2 = __builtin_amdgcn_readlane(w.rc2.z, l); r.c3 = __builtin_amdgcn_readlane(w.rc2.w, l);
-        r.fl01 = __builtin_amdgcn_readlane(w.f2.x, l); r.fl23 = __builtin_amdgcn_readlane(w.f2.y, l);
-        r.bl01 = __builtin_amdgcn_readlane(w.b2.x, l); r.bl23 = __builtin_amdgcn_readlane(w.b2.y, l);
+        r.d01 = __builtin_amdgcn_readlane(w.rc2.x, l); r.d23 = __builtin_amdgcn_readlane(w.rc2.y, l);
+        r.fl = __builtin_amdgcn_readlane(w.rc2.z, l); r.bl = __builtin_amdgcn_readlane(w.rc2.w, l);
         return r;
     }
-    return hc_load_rec(cand, flen, blen, p);
+    return hc_load_rec(cand, p);
 }
 
 /*
@@ -639,16 +642,18 @@ __device__ __forceinline__ HcRec hc_get_rec(const HcWindow &w, const uint32_t *c
  * come from the precomputed record, nothing is compared.  Falls back to hc_search when a length
  * sits at its cap and could be longer.
  */
-__device__ __forceinline__ HcMatch hc_search_l3(const uint8_t *src, const uint32_t *cand, const HcRec &rec, uint32_t ip, uint32_t ilow,
+__device__ __forceinline__ HcMatch hc_search_l3(const uint8_t *src, const uint4 *cand, const HcRec &rec, uint32_t ip, uint32_t ilow,
                                                 uint32_t matchlimit, int longest, uint32_t mpos, uint32_t spos, int lane)
 {
-    uint32_t l0 = rec.fl01 & 0xffffu, l1 = rec.fl01 >> 16, l2 = rec.fl23 & 0xffffu, l3 = rec.fl23 >> 16;
+    uint32_t l0 = rec.fl & 0xffu, l1 = (rec.fl >> 8) & 0xffu, l2 = (rec.fl >> 16) & 0xffu, l3 = rec.fl >> 24;
+    /* (a candidate without a forward length -- the chain has ended, or its four bytes differ -- is never looked at: its position may be anything) */
+    const uint32_t c0 = ip - (rec.d01 & 0xffffu), c1 = ip - (rec.d01 >> 16), c2 = ip - (rec.d23 & 0xffffu), c3 = ip - (rec.d23 >> 16);
     const uint32_t look_back = ip - ilow;
     if (l0 == HC_FLEN_CAP || l1 == HC_FLEN_CAP || l2 == HC_FLEN_CAP || l3 == HC_FLEN_CAP) {
         /* a forward length at its cap: the count goes on from there, 16 lanes per candidate and 64 bytes per step -- one
          * trip to memory for the usual match, where the general search would start from the candidate records again */
         const int grp = lane >> 4, sub = lane & 15;
-        const uint32_t c = grp == 0 ? rec.c0 : grp == 1 ? rec.c1 : grp == 2 ? rec.c2 : rec.c3;
+        const uint32_t c = grp == 0 ? c0 : grp == 1 ? c1 : grp == 2 ? c2 : c3;
         const uint32_t l = grp == 0 ? l0 : grp == 1 ? l1 : grp == 2 ? l2 : l3;
         const uint32_t maxn = matchlimit - (ip + MINMATCH);
         bool open = l == HC_FLEN_CAP;
@@ -680,9 +685,9 @@ __device__ __forceinline__ HcMatch hc_search_l3(const uint8_t *src, const uint32
     bool slow = false;
     uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
     if (look_back) {                                        /* LZ4HC_countBack = min(equal bytes, ip - ilow, match - 0) */
-        const uint32_t s0 = rec.bl01 & 0xffffu, s1 = rec.bl01 >> 16, s2 = rec.bl23 & 0xffffu, s3 = rec.bl23 >> 16;
-        const uint32_t m0 = look_back < rec.c0 ? look_back : rec.c0, m1 = look_back < rec.c1 ? look_back : rec.c1,
-                       m2 = look_back < rec.c2 ? look_back : rec.c2, m3 = look_back < rec.c3 ? look_back : rec.c3;
+        const uint32_t s0 = rec.bl & 0xffu, s1 = (rec.bl >> 8) & 0xffu, s2 = (rec.bl >> 16) & 0xffu, s3 = rec.bl >> 24;
+        const uint32_t m0 = look_back < c0 ? look_back : c0, m1 = look_back < c1 ? look_back : c1,
+                       m2 = look_back < c2 ? look_back : c2, m3 = look_back < c3 ? look_back : c3;
         b0 = s0 < m0 ? s0 : m0; b1 = s1 < m1 ? s1 : m1; b2 = s2 < m2 ? s2 : m2; b3 = s3 < m3 ? s3 : m3;
         slow = slow || (l0 && s0 == HC_BLEN_CAP && m0 > HC_BLEN_CAP) || (l1 && s1 == HC_BLEN_CAP && m1 > HC_BLEN_CAP) ||
                (l2 && s2 == HC_BLEN_CAP && m2 > HC_BLEN_CAP) || (l3 && s3 == HC_BLEN_CAP && m3 > HC_BLEN_CAP);
@@ -691,10 +696,10 @@ __device__ __forceinline__ HcMatch hc_search_l3(const uint8_t *src, const uint32
     HcMatch r;
     r.len = longest; r.mpos = mpos; r.spos = spos;
     const int m0 = l0 ? (int)(l0 + b0) : 0, m1 = l1 ? (int)(l1 + b1) : 0, m2 = l2 ? (int)(l2 + b2) : 0, m3 = l3 ? (int)(l3 + b3) : 0;
-    if (m0 > r.len) { r.len = m0; r.mpos = rec.c0 - b0; r.spos = ip - b0; }
-    if (m1 > r.len) { r.len = m1; r.mpos = rec.c1 - b1; r.spos = ip - b1; }
-    if (m2 > r.len) { r.len = m2; r.mpos = rec.c2 - b2; r.spos = ip - b2; }
-    if (m3 > r.len) { r.len = m3; r.mpos = rec.c3 - b3; r.spos = ip - b3; }
+    if (m0 > r.len) { r.len = m0; r.mpos = c0 - b0; r.spos = ip - b0; }
+    if (m1 > r.len) { r.len = m1; r.mpos = c1 - b1; r.spos = ip - b1; }
+    if (m2 > r.len) { r.len = m2; r.mpos = c2 - b2; r.spos = ip - b2; }
+    if (m3 > r.len) { r.len = m3; r.mpos = c3 - b3; r.spos = ip - b3; }
     return r;
 }
 
@@ -1022,7 +1027,7 @@ __device__ __forceinline__ int hc_nb_searches(int level)
  * spills: profiles/r6_hc_ab.txt).  Only where a match length fits the record: blocks of at most 64 KiB. */
 template <bool L3, bool REC = false>
 __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap, int level,
-                                              const uint32_t *cand, const uint2 *flen, const uint2 *blen, int lane,
+                                              const uint4 *cand, int lane,
                                               uint32_t *pace = nullptr, uint32_t *pace_mine = nullptr, uint2 *recs = nullptr)
 {
     uint32_t nrec = 0;
@@ -1035,21 +1040,20 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
         } else if (!hc_encode_sequence(src, dst, ip, op, anchor, (ML), (REF), limited, oend, lane, (PFA), (PFB))) return 0; \
     } while (0)
 #define K4_HC_SEARCH(P, LOW, LONGEST, MPOS, SPOS) \
-    (L3 ? hc_search_l3(src, cand, hc_get_rec(win, cand, flen, blen, (P)), (P), (LOW), matchlimit, (LONGEST), (MPOS), (SPOS), lane) \
+    (L3 ? hc_search_l3(src, cand, hc_get_rec(win, cand, (P)), (P), (LOW), matchlimit, (LONGEST), (MPOS), (SPOS), lane) \
         : hc_search(src, cand, (P), (LOW), matchlimit, (LONGEST), (MPOS), (SPOS), max_attempts, lane, prev, pattern_analysis))
     if ((uint32_t)src_len > (uint32_t)MAX_INPUT_SIZE) return 0;      /* :1153 */
     const bool limited = dst_cap < compress_bound(src_len);         /* :1348 */
     const int64_t oend = dst_cap;
     const int max_attempts = hc_nb_searches(level);
     const bool pattern_analysis = max_attempts > 128;               /* LZ4HC_compress_hashChain: patternAnalysis = (maxNbAttempts > 128), level 9 */
-    const uint32_t *prev = cand - (((uint32_t)(src_len > 0 ? src_len : 0) + 3u) & ~3u);
+    const uint32_t *prev = (const uint32_t *)cand - (((uint32_t)(src_len > 0 ? src_len : 0) + 3u) & ~3u);
     const uint32_t U = (uint32_t)src_len;
     uint32_t ip = 0, anchor = 0;
     int64_t op = 0;
     HcWindow win;
     win.base = 0; win.valid = false;
-    win.rc = make_uint4(0u, 0u, 0u, 0u); win.f = make_uint2(0u, 0u); win.b = make_uint2(0u, 0u);
-    win.rc2 = make_uint4(0u, 0u, 0u, 0u); win.f2 = make_uint2(0u, 0u); win.b2 = make_uint2(0u, 0u);
+    win.rc = make_uint4(0u, 0u, 0u, 0u); win.rc2 = make_uint4(0u, 0u, 0u, 0u);
 
     if (src_len >= MFLIMIT + 1) {
         const uint32_t mflimit = U - MFLIMIT;
@@ -1062,16 +1066,16 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
              * not waited for where it is issued.  After a long match the window starts afresh at the cursor. */
             if (K4_HC_PACE && pace && ((ip ^ win.base) >> 11) != 0u && ip >= 2048u) Pace::update<13>(pace, pace_mine, ip, U, lane);   /* late blocks first */
             if (win.valid && ip - win.base - 64u < 64u) {
-                win.rc = win.rc2; win.f = win.f2; win.b = win.b2;
+                win.rc = win.rc2;
                 win.base += 64u;
             } else {
                 const uint32_t pos = ip + (uint32_t)lane < U - 4u ? ip + (uint32_t)lane : U - 4u;
-                win.rc = ((const uint4 *)cand)[pos]; win.f = flen[pos]; win.b = blen[pos];
+                win.rc = cand[pos];
                 win.base = ip;
             }
             win.valid = true;
             const uint32_t pos2 = win.base + 64u + (uint32_t)lane < U - 4u ? win.base + 64u + (uint32_t)lane : U - 4u;
-            win.rc2 = ((const uint4 *)cand)[pos2]; win.f2 = flen[pos2]; win.b2 = blen[pos2];
+            win.rc2 = cand[pos2];
           }
           do {      /* L3: the sequences that start in this window; other levels: one pass */
             uint32_t pf_anchor = HC_NONE;
@@ -1086,11 +1090,11 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
                     if (anchor + (uint32_t)lane < U) pf_byte = src[anchor + (uint32_t)lane];
                     pf_anchor = anchor;
                 }
-                const unsigned long long hm = __ballot(pos >= ip && pos <= mflimit && (win.f.x | win.f.y) != 0u);
+                const unsigned long long hm = __ballot(pos >= ip && pos <= mflimit && win.rc.z != 0u);
                 if (!hm) { ip = win.base + 64u; continue; }
                 const int fz = ctz64(hm);
                 ip = win.base + (uint32_t)fz;
-                const HcRec rec = hc_get_rec(win, cand, flen, blen, ip);
+                const HcRec rec = hc_get_rec(win, cand, ip);
                 m = hc_search_l3(src, cand, rec, ip, ip, matchlimit, MINMATCH - 1, 0u, ip, lane);
             } else {
                 m = hc_search(src, cand, ip, ip, matchlimit, MINMATCH - 1, 0u, ip, max_attempts, lane, prev, pattern_analysis);
@@ -1226,13 +1230,11 @@ __global__ __launch_bounds__(64 * HC_PARSE_WAVES_PER_WG) void k4_hc_parse_kernel
     if ((src_len > 0 || (a.flags & FLAG_RAW_RETURN)) && hc_scratch_ok(a)) {
         const uint32_t *prev = (const uint32_t *)(a.work + a.workOff[b]);
         const uint32_t al = ((uint32_t)(src_len > 0 ? src_len : 0) + 3u) & ~3u;
-        const uint32_t *cand = prev + al;
-        const uint2 *flen = (const uint2 *)(cand + 4u * al);
-        const uint2 *blen = flen + al;
+        const uint4 *cand = (const uint4 *)(prev + al);
         const uint8_t *s = a.src + a.srcOff[b];
         uint8_t *d = a.dst + a.dstOff[b];
-        if (hc_nb_searches(a.level) <= 4) ret = hc_parse_block<true>(s, src_len, d, cap < 0 ? 0 : cap, a.level, cand, flen, blen, lane, a.pace, pace_mine);
-        else ret = hc_parse_block<false>(s, src_len, d, cap < 0 ? 0 : cap, a.level, cand, flen, blen, lane);
+        if (hc_nb_searches(a.level) <= 4) ret = hc_parse_block<true>(s, src_len, d, cap < 0 ? 0 : cap, a.level, cand, lane, a.pace, pace_mine);
+        else ret = hc_parse_block<false>(s, src_len, d, cap < 0 ? 0 : cap, a.level, cand, lane);
     }
     if (lane == 0) {
         int r = ret;
@@ -1260,10 +1262,8 @@ __global__ __launch_bounds__(64 * HC_REC_WAVES_PER_WG) void k4_hc_parse_rec_kern
     if ((src_len > 0 || (a.flags & FLAG_RAW_RETURN)) && hc_scratch_ok(a)) {
         const uint32_t *prev = (const uint32_t *)(a.work + a.workOff[b]);
         const uint32_t al = ((uint32_t)(src_len > 0 ? src_len : 0) + 3u) & ~3u;
-        const uint32_t *cand = prev + al;
-        const uint2 *flen = (const uint2 *)(cand + 4u * al);
-        const uint2 *blen = flen + al;
-        ret = hc_parse_block<true, true>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.level, cand, flen, blen, lane, a.pace, pace_mine,
+        const uint4 *cand = (const uint4 *)(prev + al);
+        ret = hc_parse_block<true, true>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.level, cand, lane, a.pace, pace_mine,
                                          a.recs + (unsigned long long)b * PARSE_REC_STRIDE);
     }
     if (lane == 0) {

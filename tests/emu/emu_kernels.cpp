@@ -216,7 +216,9 @@ int k4emu_encode_hc_batch(const uint8_t *src, const uint64_t *srcOff, const int3
     a.hash = hash.data();
     a.work = work.data();
     a.nChain = n;
-    if (off[(size_t)n + 1] <= 65536) k4emu::launch_fn(dim3((unsigned)((n + k4::HC_CHAIN_LDS_WAVES_PER_WG - 1) / k4::HC_CHAIN_LDS_WAVES_PER_WG)), dim3(64 * k4::HC_CHAIN_LDS_WAVES_PER_WG), [=] { k4::k4_hc_chain_lds_kernel(a); }, threads);   /* as the launcher chooses */
+    /* flags bit 29 (the emulator's own): the chains by k4_hc_chain_lds_kernel (rounds 3-5) instead of sixteen waves per block */
+    if (off[(size_t)n + 1] <= 65536 && !(flags & (1 << 29))) k4emu::launch_fn(dim3((unsigned)n), dim3(64 * k4::HC_CHAIN_PARTS), [=] { k4::k4_hc_chain_part_kernel(a); }, threads);
+    else if (off[(size_t)n + 1] <= 65536) k4emu::launch_fn(dim3((unsigned)((n + k4::HC_CHAIN_LDS_WAVES_PER_WG - 1) / k4::HC_CHAIN_LDS_WAVES_PER_WG)), dim3(64 * k4::HC_CHAIN_LDS_WAVES_PER_WG), [=] { k4::k4_hc_chain_lds_kernel(a); }, threads);   /* as the launcher chooses */
     else k4emu::launch_fn(dim3((unsigned)((n + k4::HC_CHAIN_WAVES_PER_WG - 1) / k4::HC_CHAIN_WAVES_PER_WG)), dim3(64 * k4::HC_CHAIN_WAVES_PER_WG), [=] { k4::k4_hc_chain_kernel(a); }, threads);
     if (off[(size_t)n + 1] >= 13 && level < 10) {
         const unsigned gy = (unsigned)((off[(size_t)n + 1] + k4::HC_CAND_POS_PER_WG - 1) / k4::HC_CAND_POS_PER_WG);
@@ -225,7 +227,7 @@ int k4emu_encode_hc_batch(const uint8_t *src, const uint64_t *srcOff, const int3
     /* flags bit 30 (the emulator's own): level 3 with sequence records (HcArgs::recs), as the launcher runs blocks of at most 64 KiB */
     std::vector<uint2> recs;
     if ((flags & (1 << 30)) && level <= 3 && off[(size_t)n + 1] <= 65536) { recs.resize((size_t)n * k4::PARSE_REC_STRIDE); a.recs = recs.data(); }
-    a.flags = flags & ~(1 << 30);
+    a.flags = flags & ~((1 << 30) | (1 << 29));
     if (level >= 10) k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_hc_parse_opt_kernel(a); }, threads);
     else if (a.recs) k4emu::launch_fn(dim3((unsigned)((n + k4::HC_REC_WAVES_PER_WG - 1) / k4::HC_REC_WAVES_PER_WG)), dim3(64 * k4::HC_REC_WAVES_PER_WG), [=] { k4::k4_hc_parse_rec_kernel(a); }, threads);
     else k4emu::launch_fn(dim3((unsigned)((n + k4::HC_PARSE_WAVES_PER_WG - 1) / k4::HC_PARSE_WAVES_PER_WG)), dim3(64 * k4::HC_PARSE_WAVES_PER_WG), [=] { k4::k4_hc_parse_kernel(a); }, threads);
