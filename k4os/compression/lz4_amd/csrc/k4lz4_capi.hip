@@ -107,6 +107,7 @@ struct k4lz4_ctx {
     int cost_pct = 48;                    /* K4LZ4_COST_PCT: the LDS-table kernel's share of a batch's estimated cost (k4_order_kernel) */
     int dec_parts = 4, dec_parts_direct = 8;   /* K4LZ4_DEC_PARTS, K4LZ4_DEC_PARTS_DIRECT: parts of a big decode-like host-pointer call (2..MAX_PARTS); with a registered destination */
     int hop2_max_per_cu = 12;             /* K4LZ4_HOP2_MAX: pair decoders follow the token chain two links per hop in launches of up to this many blocks per CU */
+    int hc_segs = 0;                      /* K4LZ4_HC_SEGS = 1 / 2 / 4: waves per block of the level-3 parse (0: by the batch's size) */
     bool hc_chain_parts = true;           /* K4LZ4_HC_CHAIN_OLD unsets it: blocks of at most 64 KiB build their chains with sixteen waves per block (k4_hc_chain_part_kernel) */
     int hc_mem_pct = 33;                  /* K4LZ4_HC_MEM_PCT: share of an HC chunk whose chains are built with the table in memory, beside the LDS-table kernel */
     int pace_min_per_cu = 6;              /* K4LZ4_PACE_MIN: batches of more blocks per CU than this use the priorities (measured: 8 per CU +3 % encode, +7 % decode; 4 per CU -1 %, -4 %) */
@@ -332,10 +333,13 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
         const bool optimal = level >= K4LZ4_L10_OPT;              /* clTable (LL64.high.cs:1124-1138): lz4opt strategy */
         if (tail[1] >= 13 && !optimal) {
             const unsigned gy = (unsigned)((tail[1] + k4::HC_CAND_POS_PER_WG - 1) / k4::HC_CAND_POS_PER_WG);
-            for (unsigned y0 = 0; y0 < gy; y0 += 65535u) {   /* grid.y limit */
+            const unsigned groups = (unsigned)((cnt + 7) / 8);                     /* eight blocks, one per XCD (k4_hc_cand_kernel) */
+            const unsigned per = std::max(1u, (1u << 30) / (8u * groups));         /* chunks per launch: the grid stays below 2^31 workgroups */
+            for (unsigned y0 = 0; y0 < gy; y0 += per) {
                 k4::HcArgs hy = h;
                 hy.posBase = y0 * (unsigned)k4::HC_CAND_POS_PER_WG;
-                hipLaunchKernelGGL(k4::k4_hc_cand_kernel, dim3((unsigned)cnt, std::min(65535u, gy - y0)), dim3(256), 0, stream, hy);
+                hy.candChunks = std::min(per, gy - y0);
+                hipLaunchKernelGGL(k4::k4_hc_cand_kernel, dim3(groups * 8u * hy.candChunks), dim3(256), 0, stream, hy);
             }
         }
         const hipStream_t pstream = stream;
@@ -343,17 +347,28 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
         else {
             /* level 3 on blocks of at most 64 KiB: the parse writes 8-byte sequence records (the fast encoder's scratch, a slot per
              * block) and the same wave turns them into bytes afterwards; without room for them LZ4HC_encodeSequence stays in the loop */
+            /* ... by two or four waves per block while the chip has the wave slots for them (k4lz4_encode_hc.hpp, HcSegs; round 6) */
+            int nseg = 1;
             if (level <= K4LZ4_L03_HC && tail[1] <= 65536 && ctx->hc_records) {
-                const size_t need = (size_t)cnt * k4::PARSE_REC_STRIDE * sizeof(uint2);
-                if (need > ctx->d_parse_cap) K4_HIP(ctx, hipStreamSynchronize(stream));
-                if (grow(ctx, &ctx->d_parse, &ctx->d_parse_cap, need, false) == K4LZ4_OK) h.recs = (uint2 *)ctx->d_parse;
-                else { std::lock_guard<std::mutex> g(g_err_mu); ctx->error.clear(); }
+                const int64_t slots = 32 * (int64_t)ctx->cu_count;
+                nseg = ctx->hc_segs > 0 ? ctx->hc_segs : (cnt * 2 <= slots ? 4 : 1);      /* (measured, profiles/r6_hc_ab.txt: four waves per block beat two even when they take turns -- 4096 blocks: 9.5 against 12.2-13.3 ms, one wave 13.9) */
+                if (tail[1] < k4::HC_SEG_MIN_LEN) nseg = 1;
+                for (;;) {
+                    const size_t need = (size_t)cnt * (nseg == 4 ? k4::hc_seg_rec_off(4, 4) : nseg == 2 ? k4::hc_seg_rec_off(2, 2) : k4::PARSE_REC_STRIDE) * sizeof(uint2);
+                    if (need > ctx->d_parse_cap) K4_HIP(ctx, hipStreamSynchronize(stream));
+                    if (grow(ctx, &ctx->d_parse, &ctx->d_parse_cap, need, false) == K4LZ4_OK) { h.recs = (uint2 *)ctx->d_parse; break; }
+                    { std::lock_guard<std::mutex> g(g_err_mu); ctx->error.clear(); }
+                    if (nseg == 1) break;
+                    nseg = 1;
+                }
             }
             if (ctx->use_pace && ctx->d_pace && cnt > 8 * (int64_t)ctx->cu_count) {
                 h.pace = ctx->d_pace;
                 K4_HIP(ctx, hipMemsetAsync(h.pace, 0, k4::PACE_BYTES, pstream));
             }
-            if (h.recs) hipLaunchKernelGGL(k4::k4_hc_parse_rec_kernel, dim3((unsigned)((cnt + k4::HC_REC_WAVES_PER_WG - 1) / k4::HC_REC_WAVES_PER_WG)), dim3(64 * k4::HC_REC_WAVES_PER_WG), 0, pstream, h);
+            if (h.recs && nseg == 4) hipLaunchKernelGGL(k4::k4_hc_parse_seg4_kernel, dim3((unsigned)((cnt + 1) / 2)), dim3(64 * k4::HC_SEG_WAVES_PER_WG), 0, pstream, h);
+            else if (h.recs && nseg == 2) hipLaunchKernelGGL(k4::k4_hc_parse_seg2_kernel, dim3((unsigned)((cnt + 3) / 4)), dim3(64 * k4::HC_SEG_WAVES_PER_WG), 0, pstream, h);
+            else if (h.recs) hipLaunchKernelGGL(k4::k4_hc_parse_rec_kernel, dim3((unsigned)((cnt + k4::HC_REC_WAVES_PER_WG - 1) / k4::HC_REC_WAVES_PER_WG)), dim3(64 * k4::HC_REC_WAVES_PER_WG), 0, pstream, h);
             else hipLaunchKernelGGL(k4::k4_hc_parse_kernel, dim3((unsigned)((cnt + k4::HC_PARSE_WAVES_PER_WG - 1) / k4::HC_PARSE_WAVES_PER_WG)), dim3(64 * k4::HC_PARSE_WAVES_PER_WG), 0, pstream, h);
         }
         if (pickle) hipLaunchKernelGGL(k4::k4_pickle_finish_kernel, dim3((unsigned)((cnt + k4::PICKLE_FINISH_WAVES_PER_WG - 1) / k4::PICKLE_FINISH_WAVES_PER_WG)), dim3(64 * k4::PICKLE_FINISH_WAVES_PER_WG), 0, stream, a, d_enclen);
@@ -1446,6 +1461,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (const char *e = getenv("K4LZ4_DEC_PARTS_DIRECT")) ctx->dec_parts_direct = std::max(2, std::min(MAX_PARTS, atoi(e)));
     if (const char *e = getenv("K4LZ4_HOP2_MAX")) ctx->hop2_max_per_cu = std::max(0, atoi(e));
     ctx->hc_chain_parts = getenv("K4LZ4_HC_CHAIN_OLD") == nullptr;
+    if (const char *e = getenv("K4LZ4_HC_SEGS")) { const int v = atoi(e); ctx->hc_segs = v >= 4 ? 4 : (v >= 2 ? 2 : (v == 1 ? 1 : 0)); }
     if (const char *e = getenv("K4LZ4_HC_MEM_PCT")) ctx->hc_mem_pct = std::max(0, std::min(100, atoi(e)));
     ctx->use_segments = getenv("K4LZ4_NO_SEGMENTS") == nullptr;
     if (const char *e = getenv("K4LZ4_SEG_MIN")) ctx->seg_min = (uint32_t)std::max(65536 + 4096, atoi(e));

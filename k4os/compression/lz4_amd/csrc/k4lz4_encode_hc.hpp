@@ -65,7 +65,8 @@ struct HcArgs {
     int flags;
     uint32_t *hash;            /* n x 32768, zeroed before k4_hc_chain_kernel */
     uint8_t *work;             /* prev[] and cand[] of every block */
-    unsigned int posBase;      /* k4_hc_cand_kernel: first position covered by blockIdx.y == 0 */
+    unsigned int posBase;      /* k4_hc_cand_kernel: first position covered by chunk 0 of this launch */
+    unsigned int candChunks;   /* ... and how many chunks of HC_CAND_POS_PER_WG positions per block it covers (grid: 8 * chunks workgroups per eight blocks) */
     unsigned long long *workOff;   /* n + 2: byte offset of block i's work area, [n] = total, [n+1] = longest block (k4_hc_layout_kernel) */
     unsigned long long workCap;    /* bytes behind `work` when the launch was sized without asking the device (0 = sized from [n]) */
     unsigned int maxLen;           /* the longest block the launch was sized for (same case) */
@@ -136,25 +137,34 @@ __global__ __launch_bounds__(256) void k4_hc_layout_kernel(HcArgs a)
 /* PARTS > 1 (round 6, k4_hc_chain_part_kernel): the wave owns the hash values with h % PARTS == part and a table of 32768 / PARTS slots
  * indexed by h / PARTS; it looks at every position of the block (the hash of 64 positions is a load, a multiply and a shift) and
  * enters only its own -- PARTS waves per block side by side, each with a sixteenth of the table work and none of each other's. */
-template <typename TAB, int PARTS = 1>
-__device__ __forceinline__ void hc_chain_block(const uint8_t *src, uint32_t U, TAB *tab, uint32_t *prev, uint32_t *seen, int lane, uint32_t part = 0u)
+#ifndef K4_HC_CHAIN_AHEAD
+#define K4_HC_CHAIN_AHEAD 16
+#endif
+/* `stage` (PARTS > 1): 2 x 64 * AHEAD dwords of LDS shared by the block's waves.  Each wave owns one position in PARTS, so its store of
+ * prev[] is a handful of lanes per step -- 61.6 M store instructions and 4.6 GB of partial-sector writes per launch of the bench batch for
+ * 1.07 GB of prev[].  The owners put their values into the stage instead; after AHEAD steps (a barrier: all waves of a block walk the
+ * same positions) every wave writes 64 of the stage's positions out, whole lines.  Two stages in turn: the barrier behind the next
+ * group of steps is also the one that says the previous write-out is over. */
+template <typename TAB, int PARTS = 1, int AHEAD = 4>
+__device__ __forceinline__ void hc_chain_block(const uint8_t *src, uint32_t U, TAB *tab, uint32_t *prev, uint32_t *seen, int lane, uint32_t part = 0u,
+                                               uint32_t *stage = nullptr)
 {
     static_assert((PARTS & (PARTS - 1)) == 0, "a power of two");
     const uint32_t npos = U - 3u;                          /* positions whose 4 bytes exist */
     const unsigned long long below_me = (1ull << lane) - 1ull, above_me = ~(below_me | (1ull << lane));
-    /* The source bytes of a step are asked for four steps ahead (unconditionally, at a clamped position), into a register
-     * of their own: the loop is unrolled four times so that no word has to be moved from one register to another while it
+    /* The source bytes of a step are asked for AHEAD steps ahead (unconditionally, at a clamped position), into a register
+     * of their own: the loop is unrolled AHEAD times so that no word has to be moved from one register to another while it
      * is still on its way -- such a move waits for the load, and a step would wait for memory after all. */
-    uint32_t wq[4];
+    uint32_t wq[AHEAD];
 #pragma unroll
-    for (uint32_t u = 0; u < 4u; u++) wq[u] = ld32u(src + (64u * u + (uint32_t)lane < npos ? 64u * u + (uint32_t)lane : 0u));
-    for (uint32_t q0 = 0; q0 < npos; q0 += 256u) {
+    for (uint32_t u = 0; u < (uint32_t)AHEAD; u++) wq[u] = ld32u(src + (64u * u + (uint32_t)lane < npos ? 64u * u + (uint32_t)lane : 0u));
+    for (uint32_t q0 = 0; q0 < npos; q0 += 64u * (uint32_t)AHEAD) {
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; u++) {
+        for (uint32_t u = 0; u < (uint32_t)AHEAD; u++) {
             const uint32_t p0 = q0 + 64u * u;
             const uint32_t p = p0 + (uint32_t)lane;
             const uint32_t w = wq[u];
-            wq[u] = ld32u(src + (p + 256u < npos ? p + 256u : 0u));
+            wq[u] = ld32u(src + (p + 64u * (uint32_t)AHEAD < npos ? p + 64u * (uint32_t)AHEAD : 0u));
             const uint32_t hh = hc_hash(w);
             const bool act = p < npos && (PARTS == 1 || (hh & (uint32_t)(PARTS - 1)) == part);
             uint32_t h = 0, pr = HC_NONE;
@@ -180,11 +190,20 @@ __device__ __forceinline__ void hc_chain_block(const uint8_t *src, uint32_t U, T
                 }
                 fl &= ~m;
             }
-            if (act) prev[p] = pr;
+            if (PARTS > 1 && stage) { if (act) stage[(q0 / (64u * (uint32_t)AHEAD) & 1u) * 64u * (uint32_t)AHEAD + 64u * u + (uint32_t)lane] = pr; }
+            else if (act) prev[p] = pr;
             if (last) tab[h] = (TAB)(p + 1u);
             /* the next step's look-ups come after these puts: program order for a table in LDS (nothing waits for the
              * stores of prev[], which nobody reads here), wave_sync for one in memory */
             if (sizeof(TAB) == 2) lds_sync(); else wave_sync();
+        }
+        if (PARTS > 1 && stage) {
+            __syncthreads();
+            const uint32_t *st = stage + (q0 / (64u * (uint32_t)AHEAD) & 1u) * 64u * (uint32_t)AHEAD;
+            for (uint32_t v = part; v < (uint32_t)AHEAD; v += (uint32_t)PARTS) {
+                const uint32_t p = q0 + 64u * v + (uint32_t)lane;
+                if (p < npos) prev[p] = st[64u * v + (uint32_t)lane];
+            }
         }
     }
 }
@@ -235,15 +254,22 @@ __global__ __launch_bounds__(64 * HC_CHAIN_LDS_WAVES_PER_WG) void k4_hc_chain_ld
     hc_chain_block<uint16_t>(a.src + a.srcOff[b], (uint32_t)len, tab, (uint32_t *)(a.work + a.workOff[b]), seen, lane);
 }
 
-/* Round 6: sixteen waves per block, each with a sixteenth of the hash values (hc_chain_block<.., PARTS>): 2048 slots of 16 bits and 2048
- * bits per wave, 68 KiB of LDS per block as before but sixteen waves working in it instead of one -- two blocks and 32 waves per CU
- * where k4_hc_chain_lds_kernel had two waves (its step is a chain of LDS round trips with nothing to hide them behind).  Every block
- * of the launch is at most 64 KiB long. */
-constexpr int HC_CHAIN_PARTS = 16;
+/* Round 6: HC_CHAIN_PARTS waves per block, each with its share of the hash values (hc_chain_block<.., PARTS>): per wave 32768 / PARTS
+ * slots of 16 bits and as many bits, 68 KiB of LDS per block as before but several waves working in it instead of one -- two blocks
+ * per CU where k4_hc_chain_lds_kernel had two waves (its step is a chain of LDS round trips with nothing to hide them behind).  Every
+ * block of the launch is at most 64 KiB long.  Measured on the bench batch (profiles/r6_hc_ab.txt): one wave per block 5.7 ms (beside
+ * the memory-table kernel with a third of the blocks), 16 / 8 / 4 parts 4.27 / 4.07 / 4.23 ms, with prev[] through the LDS stage 4.13 /
+ * 3.74 / -; the sources asked for 4 / 8 / 16 steps ahead: no difference.  With sixteen parts the vector port is 83 % busy (every wave
+ * hashes every position: 32 vector instructions per step), with fewer the step's two LDS round trips are what a wave waits for. */
+#ifndef K4_HC_CHAIN_PARTS
+#define K4_HC_CHAIN_PARTS 8
+#endif
+constexpr int HC_CHAIN_PARTS = K4_HC_CHAIN_PARTS;
 __global__ __launch_bounds__(64 * HC_CHAIN_PARTS) void k4_hc_chain_part_kernel(HcArgs a)
 {
     __shared__ uint32_t seen_all[HC_CHAIN_PARTS][(1u << HC_HASH_LOG) / HC_CHAIN_PARTS / 32u];
     __shared__ uint16_t tab_all[HC_CHAIN_PARTS][(1u << HC_HASH_LOG) / HC_CHAIN_PARTS];
+    __shared__ uint32_t stage[2 * 64 * K4_HC_CHAIN_AHEAD];
     const int lane = lane_id();
     const uint32_t wave = uni(threadIdx.x >> 6);
     uint32_t *seen = seen_all[wave];
@@ -255,7 +281,11 @@ __global__ __launch_bounds__(64 * HC_CHAIN_PARTS) void k4_hc_chain_part_kernel(H
     for (uint32_t k = (uint32_t)lane; k < (1u << HC_HASH_LOG) / HC_CHAIN_PARTS / 32u; k += 64u) seen[k] = 0u;
     for (uint32_t k = (uint32_t)lane; k < (1u << HC_HASH_LOG) / HC_CHAIN_PARTS / 2u; k += 64u) ((uint32_t *)tab)[k] = 0u;
     lds_sync();
-    hc_chain_block<uint16_t, HC_CHAIN_PARTS>(a.src + a.srcOff[b], (uint32_t)len, tab, (uint32_t *)(a.work + a.workOff[b]), seen, lane, wave);
+#ifdef K4_HC_CHAIN_NO_STAGE
+    hc_chain_block<uint16_t, HC_CHAIN_PARTS, K4_HC_CHAIN_AHEAD>(a.src + a.srcOff[b], (uint32_t)len, tab, (uint32_t *)(a.work + a.workOff[b]), seen, lane, wave);
+#else
+    hc_chain_block<uint16_t, HC_CHAIN_PARTS, K4_HC_CHAIN_AHEAD>(a.src + a.srcOff[b], (uint32_t)len, tab, (uint32_t *)(a.work + a.workOff[b]), seen, lane, wave, stage);
+#endif
 }
 
 /* ---- kernel 1b: candidates + forward lengths, every position independently ------------------ */
@@ -276,12 +306,21 @@ __device__ __forceinline__ uint32_t hc_count_back_bytes(const uint8_t *a, const 
 
 __global__ __launch_bounds__(256) void k4_hc_cand_kernel(HcArgs a)
 {
-    const long long b = (long long)blockIdx.x;
+    /* Which block, which 1024 positions of it.  A workgroup's loads go anywhere in the 64 KiB before its positions (prev[] and the
+     * candidates' bytes), so the chunks of ONE block should run at the same time and behind the same L2: workgroups go to the
+     * chip's eight XCDs in turn (workgroup w to XCD w % 8), so workgroup w takes block 8 * (w / (8 * chunks)) + w % 8 and chunk
+     * (w / 8) % chunks -- every XCD works its way through one block of each group of eight, four or so of them in flight, ~1.3 MiB
+     * of sources and prev[] against 4 MiB of L2.  (Rounds 1-5 ran chunk 0 of every block of the launch, then chunk 1, ...: the two
+     * thousand workgroups in flight touched two thousand blocks, 650 MB, and every load of a candidate came from memory.) */
+    const uint32_t chunks = a.candChunks;
+    const uint32_t grp = blockIdx.x / (8u * chunks), rem = blockIdx.x % (8u * chunks);
+    const long long b = (long long)grp * 8 + (long long)(rem & 7u);
+    if (b >= a.n) return;
     const int len = a.srcLen[b];
     if (len < MFLIMIT + 1 || !hc_scratch_ok(a)) return;
     const uint32_t U = (uint32_t)len;
     const uint32_t npos = U - 3u;
-    const uint32_t first = a.posBase + (uint32_t)blockIdx.y * (uint32_t)HC_CAND_POS_PER_WG;
+    const uint32_t first = a.posBase + (rem >> 3) * (uint32_t)HC_CAND_POS_PER_WG;
     if (first >= npos) return;
     const uint8_t *src = a.src + a.srcOff[b];
     const uint32_t *prev = (const uint32_t *)(a.work + a.workOff[b]);
@@ -312,8 +351,8 @@ __global__ __launch_bounds__(256) void k4_hc_cand_kernel(HcArgs a)
         uint32_t o0 = 0, o1, o2 = 0, o3 = 0;                 /* bytes p-4 .. p-1, p .. p+3, p+4 .. p+11 */
         if (inner) { const U128u v = ld128u(src + p - 4u); o0 = v.v[0]; o1 = v.v[1]; o2 = v.v[2]; o3 = v.v[3]; }
         else o1 = ld32u(src + p);
-        uint32_t d[4], fl[4], bl[4];
-        bool chain_ok = true;
+        uint32_t d[4], fl[4], bl[4], blim[4];
+        bool chain_ok = true, fo[4], bo[4];                  /* fo / bo: the forward / backward count of candidate k is not finished yet */
         U128u cv[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -326,46 +365,73 @@ __global__ __launch_bounds__(256) void k4_hc_cand_kernel(HcArgs a)
         for (int k = 0; k < 4; k++) {
             uint32_t f = 0, bk = 0;
             const uint32_t cc = c[k];
+            fo[k] = false; bo[k] = false;
+            blim[k] = cc < HC_BLEN_CAP ? cc : HC_BLEN_CAP;                         /* cc < p */
             if (d[k] != 0u) {
-                const uint32_t blim = cc < HC_BLEN_CAP ? cc : HC_BLEN_CAP;       /* cc < p */
                 if (inner && cc >= 4u) {
                     if (cv[k].v[1] == o1) {
-                        uint32_t i = 0;
                         if (lim >= 8u) {
                             const uint64_t x = (((uint64_t)(o3 ^ cv[k].v[3])) << 32) | (uint64_t)(o2 ^ cv[k].v[2]);
-                            if (x) i = (uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3;
-                            else {
-                                i = 8u;
-                                while (i + 8u <= lim) {
-                                    const uint64_t y = ld64u(src + p + MINMATCH + i) ^ ld64u(src + cc + MINMATCH + i);
-                                    if (y) { i += (uint32_t)(__ffsll((unsigned long long)y) - 1) >> 3; break; }
-                                    i += 8u;
-                                }
-                                if (i + 8u > lim) i += hc_count_fwd_bytes(src + p + MINMATCH + i, src + cc + MINMATCH + i, lim - i);
-                            }
+                            if (x) f = MINMATCH + ((uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3);
+                            else { f = MINMATCH + 8u; fo[k] = lim > 8u; }
                         } else {
-                            i = hc_count_fwd_bytes(src + p + MINMATCH, src + cc + MINMATCH, lim);
+                            f = MINMATCH + hc_count_fwd_bytes(src + p + MINMATCH, src + cc + MINMATCH, lim);
                         }
-                        f = MINMATCH + i;
-                        const uint32_t xb = o0 ^ cv[k].v[0];               /* blim >= 4 */
+                        const uint32_t xb = o0 ^ cv[k].v[0];                       /* blim >= 4 */
                         if (xb) bk = (uint32_t)__clz((int)xb) >> 3;
-                        else {
-                            bk = 4u;
-                            while (bk + 8u <= blim) {
-                                const uint64_t y = ld64u(src + p - 8u - bk) ^ ld64u(src + cc - 8u - bk);
-                                if (y) { bk += (uint32_t)__clzll((long long)y) >> 3; break; }
-                                bk += 8u;
-                            }
-                            if (bk + 8u > blim) bk += hc_count_back_bytes(src + p - bk, src + cc - bk, blim - bk);
-                        }
+                        else { bk = 4u; bo[k] = blim[k] > 4u; }
                     }
                 } else if (ld32u(src + cc) == o1) {
                     f = MINMATCH + hc_count_fwd_bytes(src + p + MINMATCH, src + cc + MINMATCH, lim);
-                    bk = hc_count_back_bytes(src + p, src + cc, blim);
+                    bk = hc_count_back_bytes(src + p, src + cc, blim[k]);
                 }
             }
             fl[k] = f;
             bl[k] = bk;
+        }
+        /* The counts that are not finished go on TOGETHER, eight bytes per step and candidate, forward and backward in one step: all
+         * of a step's loads are issued before the first is looked at, so a position waits for memory once per step -- at most four
+         * times (forward 8 / 16 / 24 bytes in, backward 4 / 12 / 20 / 28) -- where one candidate after the other, forward and then
+         * backward, waited up to two dozen times.  What is left below eight bytes is one more 8-byte compare that overlaps the bytes
+         * already counted (shifted out), not a byte loop. */
+        for (uint32_t t = 0; t < 4u; t++) {
+            if (!(fo[0] || fo[1] || fo[2] || fo[3] || bo[0] || bo[1] || bo[2] || bo[3])) break;      /* (per lane: the wave goes on while a lane has something open) */
+            const uint32_t i = 8u + 8u * t, bb = 4u + 8u * t;
+            const uint32_t rf = lim > i ? lim - i : 0u;                           /* (> 0 for a candidate that is open) */
+            const uint32_t fa = rf >= 8u ? i : lim - 8u;
+            uint64_t yf[4], yb[4];
+            uint32_t rb[4];
+            const uint64_t own_f = (fo[0] || fo[1] || fo[2] || fo[3]) ? ld64u(src + p + MINMATCH + fa) : 0ull;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                yf[k] = fo[k] ? own_f ^ ld64u(src + c[k] + MINMATCH + fa) : 0ull;
+                rb[k] = blim[k] - bb;
+                const uint32_t ba = rb[k] >= 8u ? bb + 8u : blim[k];
+                yb[k] = bo[k] ? ld64u(src + p - ba) ^ ld64u(src + c[k] - ba) : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (fo[k]) {
+                    if (rf >= 8u) {
+                        if (yf[k]) { fl[k] += (uint32_t)(__ffsll((unsigned long long)yf[k]) - 1) >> 3; fo[k] = false; }
+                        else { fl[k] += 8u; if (rf == 8u) fo[k] = false; }
+                    } else {
+                        const uint64_t y = yf[k] >> (8u * (8u - rf));
+                        fl[k] += y ? (uint32_t)(__ffsll((unsigned long long)y) - 1) >> 3 : rf;
+                        fo[k] = false;
+                    }
+                }
+                if (bo[k]) {
+                    if (rb[k] >= 8u) {
+                        if (yb[k]) { bl[k] += (uint32_t)__clzll((long long)yb[k]) >> 3; bo[k] = false; }
+                        else { bl[k] += 8u; if (rb[k] == 8u) bo[k] = false; }
+                    } else {
+                        const uint64_t y = yb[k] << (8u * (8u - rb[k]));
+                        bl[k] += y ? (uint32_t)__clzll((long long)y) >> 3 : rb[k];
+                        bo[k] = false;
+                    }
+                }
+            }
         }
         rec[p] = make_uint4(d[0] | (d[1] << 16), d[2] | (d[3] << 16), fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24),
                             bl[0] | (bl[1] << 8) | (bl[2] << 16) | (bl[3] << 24));
@@ -1013,6 +1079,54 @@ __device__ __forceinline__ int hc_parse_block_opt(const uint8_t *src, int src_le
     return (int)op;
 }
 
+/*
+ * Round 6: one block parsed by several waves.  The tables of the HC encoder do not depend on the parse (top of this file), so what
+ * LZ4HC_compress_hashChain does from a cursor position on -- skip to the next position with a match, arbitrate, emit, go on behind
+ * the last match (LL64.high.cs:553-749) -- is a function of that position and the data alone: two parses of one block that ever
+ * stand at the same position with a first match in hand go on identically.  Wave j of a block's nseg waves starts at
+ * hc_seg_start(j), as if a sequence began there, and writes its records into a slot of its own; every position where it finds a
+ * first match (a SYNC POINT) inside its home range [start(j), start(j + 1)) it marks in an LDS bit set.  A wave that has left its
+ * home range looks its own sync points up in that set and stops at the first one the wave at home there has marked too (in text the
+ * cursors fall into step within a few sequences; a wave that never meets another's sync point simply parses on to the block's end,
+ * which is the one-wave parse).  The block's sequences are then wave 0's records up to where it stopped, the records of the wave it
+ * joined from that position on up to where THAT one stopped, and so on: wave 0 gathers them behind its own and writes the block
+ * out (emit_block<true>).  The bytes are those of the one-wave parse by construction -- nothing is guessed, positions are compared.
+ */
+constexpr uint32_t HC_SEG_NONE = 0xffffffffu;
+constexpr int HC_SEG_CTL = 5;                        /* LDS words per wave: [0] progress, [1] records, [2] the wave joined, [3] where, [4] done */
+constexpr uint32_t HC_SEG_SPIN_MAX = 1u << 24;
+/* where wave j's records begin inside a block's slots, in records: wave 0 may have to hold the whole block's (PARSE_REC_STRIDE), wave j > 0
+ * at most those of the block's last (nseg - j) / nseg */
+constexpr uint32_t hc_seg_rec_cap(int nseg, int j) { return j == 0 ? PARSE_REC_STRIDE : (PARSE_REC_STRIDE * (uint32_t)(nseg - j) + (uint32_t)nseg - 1u) / (uint32_t)nseg + 64u; }
+constexpr uint32_t hc_seg_rec_off(int nseg, int j) { return j == 0 ? 0u : hc_seg_rec_off(nseg, j - 1) + hc_seg_rec_cap(nseg, j - 1); }
+struct HcSegs {
+    uint32_t nseg, seg;       /* waves of this block, this wave's number */
+    uint32_t *ctl;            /* LDS, HC_SEG_CTL words per wave of the block, zeroed */
+    uint32_t *bits;           /* LDS, one bit per position from hc_seg_start(1) on, zeroed */
+    uint2 *recs0;             /* wave j's records: recs0 + hc_seg_rec_off(nseg, j) */
+    uint32_t *status;         /* the context's status word */
+};
+/* one bit per position from hc_seg_start(1) on, blocks of up to 64 KiB (the start is rounded down by up to 63) */
+constexpr uint32_t hc_seg_bit_dwords(int nseg) { return 65536u / 32u - (65536u / (uint32_t)nseg) / 32u + 2u; }
+__device__ __forceinline__ uint32_t hc_seg_start(uint32_t U, uint32_t nseg, uint32_t j) { return j >= nseg ? 0xffffffffu : ((U / nseg) * j) & ~63u; }
+__device__ __forceinline__ uint32_t hc_lds_load(const uint32_t *p)
+{
+#ifndef K4_HOST_EMU
+    return uni(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+#else
+    return uni(*(const volatile uint32_t *)p);
+#endif
+}
+/* (relaxed: LDS executes a wave's accesses in order, and the per-sync-point marks must not wait for the record stores) */
+__device__ __forceinline__ void hc_lds_store(uint32_t *p, uint32_t v)
+{
+#ifndef K4_HOST_EMU
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    *(volatile uint32_t *)p = v;
+#endif
+}
+
 /* clTable (LL64.high.cs:1124-1138), hash-chain levels */
 __device__ __forceinline__ int hc_nb_searches(int level)
 {
@@ -1025,11 +1139,12 @@ __device__ __forceinline__ int hc_nb_searches(int level)
  * LZ4HC_encodeSequence (LL64.high.cs:435-510) is a pure function of (anchor, start, match, length) and the source, and inside this
  * serial loop it was 28 % of the kernel (wave-wide copies and fills with their own trips to memory, 22 more VGPRs, 59 more SGPR
  * spills: profiles/r6_hc_ab.txt).  Only where a match length fits the record: blocks of at most 64 KiB. */
-template <bool L3, bool REC = false>
+template <bool L3, bool REC = false, bool SEG = false>
 __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, uint8_t *dst, int dst_cap, int level,
                                               const uint4 *cand, int lane,
-                                              uint32_t *pace = nullptr, uint32_t *pace_mine = nullptr, uint2 *recs = nullptr)
+                                              uint32_t *pace = nullptr, uint32_t *pace_mine = nullptr, uint2 *recs = nullptr, const HcSegs *sg = nullptr)
 {
+    static_assert(!SEG || (L3 && REC), "several waves per block: the level-3 parse with sequence records");
     uint32_t nrec = 0;
 /* one sequence: literals [anchor, ip), a match of ML bytes at REF; the cursor and the anchor move behind it */
 #define K4_HC_EMIT(ML, REF, PFA, PFB) \
@@ -1054,6 +1169,13 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
     HcWindow win;
     win.base = 0; win.valid = false;
     win.rc = make_uint4(0u, 0u, 0u, 0u); win.rc2 = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t home_hi = 0xffffffffu, seg_base = 0u, joined = HC_SEG_NONE, stop_e = U;
+    bool left = false;
+    if (SEG) {
+        ip = anchor = hc_seg_start(U, sg->nseg, sg->seg);
+        home_hi = hc_seg_start(U, sg->nseg, sg->seg + 1u);
+        seg_base = hc_seg_start(U, sg->nseg, 1u);
+    }
 
     if (src_len >= MFLIMIT + 1) {
         const uint32_t mflimit = U - MFLIMIT;
@@ -1064,7 +1186,7 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
              * records are in the second set already and move up, and the set after it is asked for -- unconditionally, at a
              * clamped address (records of positions past the last searchable one are never looked at), so that the load is
              * not waited for where it is issued.  After a long match the window starts afresh at the cursor. */
-            if (K4_HC_PACE && pace && ((ip ^ win.base) >> 11) != 0u && ip >= 2048u) Pace::update<13>(pace, pace_mine, ip, U, lane);   /* late blocks first */
+            if (K4_HC_PACE && !SEG && pace && ((ip ^ win.base) >> 11) != 0u && ip >= 2048u) Pace::update<13>(pace, pace_mine, ip, U, lane);   /* late blocks first */
             if (win.valid && ip - win.base - 64u < 64u) {
                 win.rc = win.rc2;
                 win.base += 64u;
@@ -1102,6 +1224,22 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
             int ml = m.len;
             uint32_t ref = m.mpos;
             if (ml < MINMATCH) { ip++; continue; }
+            if (SEG) {      /* a sync point: the cursor at ip, a first match in hand */
+                if (ip >= home_hi) {
+                    if (!left) { left = true; if (lane == 0) hc_lds_store(sg->ctl + HC_SEG_CTL * sg->seg, 0xffffffffu); }   /* every sync point of the home range is marked */
+                    uint32_t j = sg->seg + 1u;                                    /* the wave at home where the cursor stands */
+                    while (ip >= hc_seg_start(U, sg->nseg, j + 1u)) j++;
+                    if (ip <= hc_lds_load(sg->ctl + HC_SEG_CTL * j)) {             /* ... has been here */
+                        const uint32_t w = hc_lds_load(sg->bits + ((ip - seg_base) >> 5));
+                        if ((w >> ((ip - seg_base) & 31u)) & 1u) { joined = j; stop_e = ip; ip = U; break; }     /* ... with a first match in hand as well */
+                    }
+                } else if (sg->seg != 0u) {
+                    if (lane == 0) {
+                        atomicOr(sg->bits + ((ip - seg_base) >> 5), 1u << ((ip - seg_base) & 31u));
+                        hc_lds_store(sg->ctl + HC_SEG_CTL * sg->seg, ip);
+                    }
+                }
+            }
             uint32_t start0 = ip, ref0 = ref;
             int ml0 = ml;
             int ml2 = 0, ml3 = 0;
@@ -1183,6 +1321,41 @@ __device__ __forceinline__ int hc_parse_block(const uint8_t *src, int src_len, u
             }
           } while (L3 && ip <= mflimit && ip - win.base < 64u);
         }
+    }
+    if (REC && SEG) {
+        uint32_t *mine = sg->ctl + HC_SEG_CTL * sg->seg;
+        if (lane == 0) {
+            hc_lds_store(mine + 1, nrec); hc_lds_store(mine + 2, joined); hc_lds_store(mine + 3, stop_e); hc_lds_store(mine + 0, 0xffffffffu);
+#ifndef K4_HOST_EMU
+            __hip_atomic_store(mine + 4, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);        /* (behind the record stores) */
+#else
+            *(volatile uint32_t *)(mine + 4) = 1u;
+#endif
+        }
+        if (sg->seg != 0u) return 0;
+        /* wave 0: the records of the waves it went through, behind its own */
+        uint32_t total = nrec, j = joined, e = stop_e;
+        while (j != HC_SEG_NONE) {
+            const uint32_t *cj = sg->ctl + HC_SEG_CTL * j;
+            uint32_t spin = 0;
+            while (hc_lds_load(cj + 4) == 0u) {
+                if (++spin >= HC_SEG_SPIN_MAX) { dev_status_raise(sg->status, (uint32_t)DEV_STATUS_PIPE_TIMEOUT); return 0; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            const uint32_t nj = hc_lds_load(cj + 1);
+            const uint2 *rj = sg->recs0 + (sg->nseg == 2u ? hc_seg_rec_off(2, 1) : j == 1u ? hc_seg_rec_off(4, 1) : j == 2u ? hc_seg_rec_off(4, 2) : hc_seg_rec_off(4, 3));
+            uint32_t lo = 0, hi = nj;                    /* its first record at or behind e (records are in position order) */
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (uni(rj[mid].x) < e) lo = mid + 1u; else hi = mid;
+            }
+            for (uint32_t t = (uint32_t)lane; t < nj - lo; t += 64u) recs[total + t] = rj[lo + t];
+            total += nj - lo;
+            e = hc_lds_load(cj + 3);
+            j = hc_lds_load(cj + 2);
+        }
+        wave_sync();
+        return emit_block<true>(src, U, dst, dst_cap, recs, total, lane);
     }
     if (REC) {
         wave_sync();                 /* the records are this wave's own stores: in order with the loads that follow */
@@ -1272,6 +1445,64 @@ __global__ __launch_bounds__(64 * HC_REC_WAVES_PER_WG) void k4_hc_parse_rec_kern
         else if (!hc_scratch_ok(a)) r = HC_NO_SCRATCH;
         a.outLen[b] = r;
     }
+}
+
+/* ... and with NSEG waves per block (HcSegs above): eight waves per workgroup, 8 / NSEG blocks.  Blocks too short to be worth cutting
+ * are parsed by their wave 0 alone. */
+constexpr int HC_SEG_WAVES_PER_WG = 8;
+#ifndef K4_HC_SEG_ATTR
+#define K4_HC_SEG_ATTR
+#endif
+constexpr uint32_t HC_SEG_MIN_LEN = 8192u;
+template <int NSEG>
+__device__ __forceinline__ void hc_parse_seg_kernel_body(const HcArgs &a, uint32_t *lds)
+{
+    constexpr int BLOCKS = HC_SEG_WAVES_PER_WG / NSEG;
+    constexpr uint32_t BIT_DWORDS = hc_seg_bit_dwords(NSEG);
+    constexpr uint32_t PER_BLOCK = BIT_DWORDS + (uint32_t)(HC_SEG_CTL * NSEG);
+    const int lane = lane_id();
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t blk = wave / (uint32_t)NSEG, seg = wave % (uint32_t)NSEG;
+    for (uint32_t k = threadIdx.x; k < PER_BLOCK * (uint32_t)BLOCKS; k += 64u * HC_SEG_WAVES_PER_WG) lds[k] = 0u;
+    __syncthreads();
+    const long long b = (long long)blockIdx.x * BLOCKS + (long long)blk;
+    if (b >= a.n) return;
+    const int src_len = a.srcLen[b];
+    const int cap = a.dstCap[b];
+    const bool cut = src_len >= (int)HC_SEG_MIN_LEN && src_len <= 65536;
+    if (!cut && seg != 0u) return;
+    int ret = 0;
+    if ((src_len > 0 || (a.flags & FLAG_RAW_RETURN)) && hc_scratch_ok(a)) {
+        const uint32_t *prev = (const uint32_t *)(a.work + a.workOff[b]);
+        const uint32_t al = ((uint32_t)(src_len > 0 ? src_len : 0) + 3u) & ~3u;
+        const uint4 *cand = (const uint4 *)(prev + al);
+        uint2 *recs0 = a.recs + (unsigned long long)b * hc_seg_rec_off(NSEG, NSEG);
+        if (cut) {
+            HcSegs sg;
+            sg.nseg = (uint32_t)NSEG; sg.seg = seg; sg.bits = lds + PER_BLOCK * blk; sg.ctl = sg.bits + BIT_DWORDS; sg.recs0 = recs0; sg.status = a.status;
+            ret = hc_parse_block<true, true, true>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.level, cand, lane, nullptr, nullptr,
+                                                   recs0 + (seg == 0u ? 0u : seg == 1u ? hc_seg_rec_off(NSEG, 1) : seg == 2u ? hc_seg_rec_off(NSEG, 2) : hc_seg_rec_off(NSEG, 3)), &sg);
+            if (seg != 0u) return;
+        } else {
+            ret = hc_parse_block<true, true>(a.src + a.srcOff[b], src_len, a.dst + a.dstOff[b], cap < 0 ? 0 : cap, a.level, cand, lane, nullptr, nullptr, recs0);
+        }
+    }
+    if (lane == 0) {
+        int r = ret;
+        if (!(a.flags & FLAG_RAW_RETURN)) r = src_len <= 0 ? 0 : (ret <= 0 ? -1 : ret);   /* LZ4Codec.cs:45-51 */
+        else if (!hc_scratch_ok(a)) r = HC_NO_SCRATCH;
+        a.outLen[b] = r;
+    }
+}
+__global__ __launch_bounds__(64 * HC_SEG_WAVES_PER_WG) K4_HC_SEG_ATTR void k4_hc_parse_seg2_kernel(HcArgs a)
+{
+    __shared__ uint32_t lds[(hc_seg_bit_dwords(2) + HC_SEG_CTL * 2u) * 4u];
+    hc_parse_seg_kernel_body<2>(a, lds);
+}
+__global__ __launch_bounds__(64 * HC_SEG_WAVES_PER_WG) K4_HC_SEG_ATTR void k4_hc_parse_seg4_kernel(HcArgs a)
+{
+    __shared__ uint32_t lds[(hc_seg_bit_dwords(4) + HC_SEG_CTL * 4u) * 2u];
+    hc_parse_seg_kernel_body<4>(a, lds);
 }
 
 /* levels 10..12: one wavefront per block, the price table in LDS (48 KiB: three blocks per CU) */

@@ -209,7 +209,7 @@ int k4emu_encode_hc_batch(const uint8_t *src, const uint64_t *srcOff, const int3
 {
     if (n <= 0) return 0;
     std::vector<unsigned long long> off((size_t)n + 2);
-    k4::HcArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, nullptr, nullptr, 0u, off.data()};
+    k4::HcArgs a{src, srcOff, srcLen, dst, dstOff, dstCap, outLen, n, level, flags, nullptr, nullptr, 0u, 0u, off.data()};
     k4emu::launch_fn(dim3(1), dim3(256), [=] { k4::k4_hc_layout_kernel(a); }, 1);
     std::vector<uint32_t> hash((size_t)n << k4::HC_HASH_LOG, 0u);
     std::vector<uint8_t> work((size_t)off[(size_t)n] + 64);
@@ -222,13 +222,18 @@ int k4emu_encode_hc_batch(const uint8_t *src, const uint64_t *srcOff, const int3
     else k4emu::launch_fn(dim3((unsigned)((n + k4::HC_CHAIN_WAVES_PER_WG - 1) / k4::HC_CHAIN_WAVES_PER_WG)), dim3(64 * k4::HC_CHAIN_WAVES_PER_WG), [=] { k4::k4_hc_chain_kernel(a); }, threads);
     if (off[(size_t)n + 1] >= 13 && level < 10) {
         const unsigned gy = (unsigned)((off[(size_t)n + 1] + k4::HC_CAND_POS_PER_WG - 1) / k4::HC_CAND_POS_PER_WG);
-        k4emu::launch_fn(dim3((unsigned)n, gy), dim3(256), [=] { k4::k4_hc_cand_kernel(a); }, threads);
+        a.candChunks = gy;
+        k4emu::launch_fn(dim3((unsigned)((n + 7) / 8) * 8u * gy), dim3(256), [=] { k4::k4_hc_cand_kernel(a); }, threads);
     }
     /* flags bit 30 (the emulator's own): level 3 with sequence records (HcArgs::recs), as the launcher runs blocks of at most 64 KiB */
     std::vector<uint2> recs;
-    if ((flags & (1 << 30)) && level <= 3 && off[(size_t)n + 1] <= 65536) { recs.resize((size_t)n * k4::PARSE_REC_STRIDE); a.recs = recs.data(); }
-    a.flags = flags & ~((1 << 30) | (1 << 29));
+    /* flags bits 27-28 (the emulator's own, with bit 30): 1 / 2 -- two / four waves per block (HcSegs) */
+    const int nseg = 1 << ((flags >> 27) & 3);
+    if ((flags & (1 << 30)) && level <= 3 && off[(size_t)n + 1] <= 65536) { recs.resize((size_t)n * (nseg == 4 ? k4::hc_seg_rec_off(4, 4) : nseg == 2 ? k4::hc_seg_rec_off(2, 2) : k4::PARSE_REC_STRIDE)); a.recs = recs.data(); }
+    a.flags = flags & ~((1 << 30) | (1 << 29) | (3 << 27));
     if (level >= 10) k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_hc_parse_opt_kernel(a); }, threads);
+    else if (a.recs && nseg == 4) k4emu::launch_fn(dim3((unsigned)((n + 1) / 2)), dim3(64 * k4::HC_SEG_WAVES_PER_WG), [=] { k4::k4_hc_parse_seg4_kernel(a); }, threads);
+    else if (a.recs && nseg == 2) k4emu::launch_fn(dim3((unsigned)((n + 3) / 4)), dim3(64 * k4::HC_SEG_WAVES_PER_WG), [=] { k4::k4_hc_parse_seg2_kernel(a); }, threads);
     else if (a.recs) k4emu::launch_fn(dim3((unsigned)((n + k4::HC_REC_WAVES_PER_WG - 1) / k4::HC_REC_WAVES_PER_WG)), dim3(64 * k4::HC_REC_WAVES_PER_WG), [=] { k4::k4_hc_parse_rec_kernel(a); }, threads);
     else k4emu::launch_fn(dim3((unsigned)((n + k4::HC_PARSE_WAVES_PER_WG - 1) / k4::HC_PARSE_WAVES_PER_WG)), dim3(64 * k4::HC_PARSE_WAVES_PER_WG), [=] { k4::k4_hc_parse_kernel(a); }, threads);
     return 0;

@@ -524,10 +524,13 @@ def test_encode_hc_matches_oracle(emu, oracle, level):
     assert (dst[mask] == 0xCD).all()
 
 
-def test_encode_hc_level3_from_sequence_records(emu, oracle):
+@pytest.mark.parametrize("nseg_log2", [0, 1, 2])
+def test_encode_hc_level3_from_sequence_records(emu, oracle, nseg_log2):
     """round 6: at level 3, on blocks of at most 64 KiB, k4_hc_parse_kernel only decides -- 8-byte sequence records -- and the bytes are
     written from the records afterwards (emit_block<true>: LZ4HC_encodeSequence's format and ITS output-limit tests,
-    LL64.high.cs:435-510).  The oracle's bytes at full capacity, at exact fit, one byte short and far too small."""
+    LL64.high.cs:435-510).  The oracle's bytes at full capacity, at exact fit, one byte short and far too small.
+    nseg_log2 1 / 2: the same blocks parsed by two / four waves each (HcSegs: every wave from its own start, joined where their cursors
+    meet) -- byte for byte the one-wave parse."""
     rng = np.random.default_rng(44)
     blocks = [corpus.class_bytes(name, int(rng.integers(2000, 65537)), 7) for name in corpus.SILESIA_NAMES]
     blocks += [corpus.class_bytes(name, 65536, 9) for name in ("dickens", "xml", "nci", "sao")]
@@ -543,7 +546,7 @@ def test_encode_hc_level3_from_sequence_records(emu, oracle):
             cases.append((b, cap))
     src, soff, slen = pack([b for b, _ in cases])
     dst, doff, dcap = arena([c for _, c in cases])
-    out = emu.encode_hc_batch(src, soff, slen, dst, doff, dcap, level=3, flags=FLAG_RAW | (1 << 30))
+    out = emu.encode_hc_batch(src, soff, slen, dst, doff, dcap, level=3, flags=FLAG_RAW | (1 << 30) | (nseg_log2 << 27))
     for i, (b, cap) in enumerate(cases):
         r, w = oracle.compress_hc(b, 3, cap=cap)
         assert out[i] == r, (i, b.size, cap, out[i], r)
