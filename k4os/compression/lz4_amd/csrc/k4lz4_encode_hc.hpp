@@ -711,26 +711,34 @@ __device__ __forceinline__ HcRec hc_get_rec(const HcWindow &w, const uint4 *cand
 __device__ __forceinline__ HcMatch hc_search_l3(const uint8_t *src, const uint4 *cand, const HcRec &rec, uint32_t ip, uint32_t ilow,
                                                 uint32_t matchlimit, int longest, uint32_t mpos, uint32_t spos, int lane)
 {
-    uint32_t l0 = rec.fl & 0xffu, l1 = (rec.fl >> 8) & 0xffu, l2 = (rec.fl >> 16) & 0xffu, l3 = rec.fl >> 24;
+    /* The four candidates in four lanes (lane & 3: every quad computes the same, lanes 0..3 are the ones that are read).  The parse is
+     * wave-uniform code and the scalar port -- one instruction per four cycles and SIMD -- is what it uses up (4.2 G scalar against
+     * 0.3 G vector instructions per launch of the bench batch, gpurun_out/r6x_pmc); as scalar code this search was ~90 of them. */
+    const uint32_t k = (uint32_t)lane & 3u;
+    /* (a bit select, not `k & 2 ? rec.d23 : rec.d01`: the compiler turns a select between two neighbouring fields into a store of both and an
+     * indexed load -- through scratch memory or LDS, a round trip in every search) */
+    const uint32_t dd = rec.d01 ^ ((rec.d01 ^ rec.d23) & (0u - ((k >> 1) & 1u)));
+    const uint32_t d = (dd >> (16u * (k & 1u))) & 0xffffu;
+    uint32_t l = (rec.fl >> (8u * k)) & 0xffu;
+    const uint32_t s = (rec.bl >> (8u * k)) & 0xffu;
     /* (a candidate without a forward length -- the chain has ended, or its four bytes differ -- is never looked at: its position may be anything) */
-    const uint32_t c0 = ip - (rec.d01 & 0xffffu), c1 = ip - (rec.d01 >> 16), c2 = ip - (rec.d23 & 0xffffu), c3 = ip - (rec.d23 >> 16);
+    const uint32_t c = ip - d;
     const uint32_t look_back = ip - ilow;
-    if (l0 == HC_FLEN_CAP || l1 == HC_FLEN_CAP || l2 == HC_FLEN_CAP || l3 == HC_FLEN_CAP) {
+    if (__ballot(l == HC_FLEN_CAP) & 0xfull) {
         /* a forward length at its cap: the count goes on from there, 16 lanes per candidate and 64 bytes per step -- one
          * trip to memory for the usual match, where the general search would start from the candidate records again */
         const int grp = lane >> 4, sub = lane & 15;
-        const uint32_t c = grp == 0 ? c0 : grp == 1 ? c1 : grp == 2 ? c2 : c3;
-        const uint32_t l = grp == 0 ? l0 : grp == 1 ? l1 : grp == 2 ? l2 : l3;
+        const uint32_t cg = (uint32_t)__shfl((int)c, grp), lg = (uint32_t)__shfl((int)l, grp);
         const uint32_t maxn = matchlimit - (ip + MINMATCH);
-        bool open = l == HC_FLEN_CAP;
-        uint32_t done = HC_FLEN_CAP - MINMATCH, fwd = l;
+        bool open = lg == HC_FLEN_CAP;
+        uint32_t done = HC_FLEN_CAP - MINMATCH, fwd = lg;
         for (;;) {
             const uint32_t i = done + 4u * (uint32_t)sub;
             uint32_t neq = 4u;
             if (open) {
                 neq = 0;
                 if (i < maxn) {
-                    const uint32_t x = ld32u(src + ip + MINMATCH + i) ^ ld32u(src + c + MINMATCH + i);
+                    const uint32_t x = ld32u(src + ip + MINMATCH + i) ^ ld32u(src + cg + MINMATCH + i);
                     const uint32_t avail = maxn - i < 4u ? maxn - i : 4u;
                     const uint32_t e = x ? (uint32_t)(__ffs(x) - 1) >> 3 : 4u;
                     neq = e < avail ? e : avail;
@@ -746,26 +754,26 @@ __device__ __forceinline__ HcMatch hc_search_l3(const uint8_t *src, const uint4 
             }
             if (!__ballot(open)) break;
         }
-        l0 = readlane_u32(fwd, 0); l1 = readlane_u32(fwd, 16); l2 = readlane_u32(fwd, 32); l3 = readlane_u32(fwd, 48);
+        l = (uint32_t)__shfl((int)fwd, 16 * (int)k);
     }
-    bool slow = false;
-    uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-    if (look_back) {                                        /* LZ4HC_countBack = min(equal bytes, ip - ilow, match - 0) */
-        const uint32_t s0 = rec.bl & 0xffu, s1 = (rec.bl >> 8) & 0xffu, s2 = (rec.bl >> 16) & 0xffu, s3 = rec.bl >> 24;
-        const uint32_t m0 = look_back < c0 ? look_back : c0, m1 = look_back < c1 ? look_back : c1,
-                       m2 = look_back < c2 ? look_back : c2, m3 = look_back < c3 ? look_back : c3;
-        b0 = s0 < m0 ? s0 : m0; b1 = s1 < m1 ? s1 : m1; b2 = s2 < m2 ? s2 : m2; b3 = s3 < m3 ? s3 : m3;
-        slow = slow || (l0 && s0 == HC_BLEN_CAP && m0 > HC_BLEN_CAP) || (l1 && s1 == HC_BLEN_CAP && m1 > HC_BLEN_CAP) ||
-               (l2 && s2 == HC_BLEN_CAP && m2 > HC_BLEN_CAP) || (l3 && s3 == HC_BLEN_CAP && m3 > HC_BLEN_CAP);
-    }
-    if (slow) return hc_search(src, cand, ip, ilow, matchlimit, longest, mpos, spos, 4, lane);
+    const uint32_t m = look_back < c ? look_back : c;       /* LZ4HC_countBack = min(equal bytes, ip - ilow, match - 0) */
+    const uint32_t b = s < m ? s : m;
+    if (__ballot(l != 0u && s == HC_BLEN_CAP && m > HC_BLEN_CAP) & 0xfull)
+        return hc_search(src, cand, ip, ilow, matchlimit, longest, mpos, spos, 4, lane);
+    /* the first candidate in chain order that has the greatest length wins, if that beats `longest` (:128-133) */
+    uint32_t key = ((l ? l + b : 0u) << 2) | (3u - k);
+    { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x111, 0xf, 0xf, true); key = key > o ? key : o; }    /* row_shr:1 */
+    { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x112, 0xf, 0xf, true); key = key > o ? key : o; }    /* row_shr:2 */
+    const uint32_t best = readlane_u32(key, 3);
     HcMatch r;
     r.len = longest; r.mpos = mpos; r.spos = spos;
-    const int m0 = l0 ? (int)(l0 + b0) : 0, m1 = l1 ? (int)(l1 + b1) : 0, m2 = l2 ? (int)(l2 + b2) : 0, m3 = l3 ? (int)(l3 + b3) : 0;
-    if (m0 > r.len) { r.len = m0; r.mpos = c0 - b0; r.spos = ip - b0; }
-    if (m1 > r.len) { r.len = m1; r.mpos = c1 - b1; r.spos = ip - b1; }
-    if (m2 > r.len) { r.len = m2; r.mpos = c2 - b2; r.spos = ip - b2; }
-    if (m3 > r.len) { r.len = m3; r.mpos = c3 - b3; r.spos = ip - b3; }
+    if ((int)(best >> 2) > longest) {
+        const int kk = 3 - (int)(best & 3u);
+        const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)b, kk);
+        r.len = (int)(best >> 2);
+        r.mpos = (uint32_t)__builtin_amdgcn_readlane((int)c, kk) - bb;
+        r.spos = ip - bb;
+    }
     return r;
 }
 
