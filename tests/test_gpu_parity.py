@@ -601,6 +601,47 @@ def test_fast_encoder_paths_give_identical_bytes(oracle):
         ctx.close()
 
 
+def test_hc_level3_paths_give_identical_bytes(oracle):
+    """round 6: how a level-3 batch of blocks up to 64 KiB is parsed is scheduling only -- one, two or four waves per block, each
+    from its own start and joined where their cursors meet (K4LZ4_HC_SEGS; by default four), the chains by eight waves per block or
+    by the LDS-table kernel of rounds 3-5 (K4LZ4_HC_CHAIN_OLD), sequence records or LZ4HC_encodeSequence in the loop
+    (K4LZ4_NO_HC_RECORDS).  Every one of them: the oracle's bytes, ragged lengths and ragged output limits included."""
+    import os
+    from k4os.compression.lz4_amd import _native
+    rng = np.random.default_rng(33)
+    blocks = [corpus.class_bytes(name, int(rng.integers(200, 65537)), 11 + i) for i, name in enumerate(corpus.SILESIA_NAMES * 8)]
+    blocks += [b for b in corpus.silesia_like_blocks(96, 65536, seed=8)]
+    blocks += [corpus.lorem(n) for n in (0, 1, 12, 13, 14, 8191, 8192, 8193, 65536)] + [corpus.repeated(0xAA, n) for n in (13, 8192, 65536)]
+    blocks += [np.concatenate([np.zeros(30000, np.uint8), corpus.random_bytes(100, 1), np.zeros(30000, np.uint8)]), corpus.random_bytes(65536, 4)]
+    import adversarial_blocks
+    blocks.append(adversarial_blocks.dense_four_byte_matches(128, 65536, 128))
+    caps = []
+    for b in blocks:
+        bound = LZ4Codec.MaximumOutputSize(b.size)
+        caps.append(bound if rng.random() < 0.8 else int(rng.integers(0, bound + 1)))
+    caps = np.array(caps, np.int32)
+    src, soff, slen = pack_blocks(blocks)
+    ref_dst, ref_off = make_arena(caps + 16, fill=0xCD)
+    want = oracle.encode_batch(src, soff, slen, ref_dst, ref_off, caps, level=3, threads=8)
+    envs = [{}, {"K4LZ4_HC_SEGS": "1"}, {"K4LZ4_HC_SEGS": "2"}, {"K4LZ4_HC_SEGS": "4"}, {"K4LZ4_HC_CHAIN_OLD": "1"}, {"K4LZ4_NO_HC_RECORDS": "1"}]
+    for env in envs:
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ctx = _native.Context(-1)            # (the switches are read when a context is made)
+        finally:
+            for k, v in old.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+        dst, doff = make_arena(caps + 16, fill=0xCD)
+        out = LZ4Codec.EncodeBatchPacked(src, soff, slen, dst, doff, caps, level=LZ4Level.L03_HC, ctx=ctx)
+        assert np.array_equal(out, want), (env, np.nonzero(out != want)[0][:5])
+        for i in np.nonzero(want > 0)[0]:
+            a = dst[int(doff[i]):int(doff[i]) + caps[i] + 16]; b = ref_dst[int(ref_off[i]):int(ref_off[i]) + caps[i] + 16]
+            assert np.array_equal(a[:want[i]], b[:want[i]]) and (a[want[i]:] == 0xCD).all(), (env, int(i))
+        ctx.close()
+
+
 def test_decoder_kernel_variants_give_identical_results(oracle):
     """Which decoder kernel a batch gets is scheduling only: two waves per block (up to 16 blocks per CU), one wave
     per block (K4LZ4_NO_PAIR=1, or up to 24 per CU), the dense build (more).  Same bytes and the same verdict on
