@@ -304,7 +304,7 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
         }
         h.work = ctx->d_hc_work;
         if (tail[1] <= 65536 && ctx->hc_chain_parts) {
-            /* no block over 64 KiB: sixteen waves per block, each with a sixteenth of the hash values and of the table (round 6) */
+            /* no block over 64 KiB: eight waves per block, each with an eighth of the hash values and of the table (round 6) */
             h.nChain = cnt;
             hipLaunchKernelGGL(k4::k4_hc_chain_part_kernel, dim3((unsigned)cnt), dim3(64 * k4::HC_CHAIN_PARTS), 0, stream, h);
         } else if (tail[1] <= 65536) {
