@@ -107,6 +107,7 @@ struct k4lz4_ctx {
     int cost_pct = 48;                    /* K4LZ4_COST_PCT: the LDS-table kernel's share of a batch's estimated cost (k4_order_kernel) */
     int dec_parts = 4, dec_parts_direct = 8;   /* K4LZ4_DEC_PARTS, K4LZ4_DEC_PARTS_DIRECT: parts of a big decode-like host-pointer call (2..MAX_PARTS); with a registered destination */
     int hop2_max_per_cu = 12;             /* K4LZ4_HOP2_MAX: pair decoders follow the token chain two links per hop in launches of up to this many blocks per CU */
+    int hc_cand_dynlds = 0;               /* K4LZ4_HC_CAND_DYNLDS (a measurement switch): bytes of unused LDS per workgroup of k4_hc_cand_kernel, i.e. fewer of them per CU */
     int hc_segs = 0;                      /* K4LZ4_HC_SEGS = 1 / 2 / 4: waves per block of the level-3 parse (0: by the batch's size) */
     bool hc_chain_parts = true;           /* K4LZ4_HC_CHAIN_OLD unsets it: blocks of at most 64 KiB build their chains with sixteen waves per block (k4_hc_chain_part_kernel) */
     int hc_mem_pct = 33;                  /* K4LZ4_HC_MEM_PCT: share of an HC chunk whose chains are built with the table in memory, beside the LDS-table kernel */
@@ -339,7 +340,7 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
                 k4::HcArgs hy = h;
                 hy.posBase = y0 * (unsigned)k4::HC_CAND_POS_PER_WG;
                 hy.candChunks = std::min(per, gy - y0);
-                hipLaunchKernelGGL(k4::k4_hc_cand_kernel, dim3(groups * 8u * hy.candChunks), dim3(256), 0, stream, hy);
+                hipLaunchKernelGGL(k4::k4_hc_cand_kernel, dim3(groups * 8u * hy.candChunks), dim3(256), (size_t)ctx->hc_cand_dynlds, stream, hy);
             }
         }
         const hipStream_t pstream = stream;
@@ -1461,6 +1462,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (const char *e = getenv("K4LZ4_DEC_PARTS_DIRECT")) ctx->dec_parts_direct = std::max(2, std::min(MAX_PARTS, atoi(e)));
     if (const char *e = getenv("K4LZ4_HOP2_MAX")) ctx->hop2_max_per_cu = std::max(0, atoi(e));
     ctx->hc_chain_parts = getenv("K4LZ4_HC_CHAIN_OLD") == nullptr;
+    if (const char *e = getenv("K4LZ4_HC_CAND_DYNLDS")) ctx->hc_cand_dynlds = std::max(0, std::min(65536, atoi(e)));
     if (const char *e = getenv("K4LZ4_HC_SEGS")) { const int v = atoi(e); ctx->hc_segs = v >= 4 ? 4 : (v >= 2 ? 2 : (v == 1 ? 1 : 0)); }
     if (const char *e = getenv("K4LZ4_HC_MEM_PCT")) ctx->hc_mem_pct = std::max(0, std::min(100, atoi(e)));
     ctx->use_segments = getenv("K4LZ4_NO_SEGMENTS") == nullptr;

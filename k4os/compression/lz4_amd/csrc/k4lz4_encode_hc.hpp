@@ -304,7 +304,10 @@ __device__ __forceinline__ uint32_t hc_count_fwd_bytes(const uint8_t *a, const u
 /* equal bytes before a / b, at most n */
 __device__ __forceinline__ uint32_t hc_count_back_bytes(const uint8_t *a, const uint8_t *b, uint32_t n) { uint32_t i = 0; while (i < n && a[-1 - (int)i] == b[-1 - (int)i]) i++; return i; }
 
-__global__ __launch_bounds__(256) void k4_hc_cand_kernel(HcArgs a)
+#ifndef K4_HC_CAND_ATTR
+#define K4_HC_CAND_ATTR
+#endif
+__global__ __launch_bounds__(256) K4_HC_CAND_ATTR void k4_hc_cand_kernel(HcArgs a)
 {
     /* Which block, which 1024 positions of it.  A workgroup's loads go anywhere in the 64 KiB before its positions (prev[] and the
      * candidates' bytes), so the chunks of ONE block should run at the same time and behind the same L2: workgroups go to the
