@@ -78,6 +78,19 @@ __device__ __forceinline__ uint32_t ld32u(const uint8_t *p) { return ((const U32
 __device__ __forceinline__ uint64_t ld64u(const uint8_t *p) { return ((const U64u *)p)->v; }
 __device__ __forceinline__ U128u ld128u(const uint8_t *p) { return *(const U128u *)p; }
 __device__ __forceinline__ void st128u(uint8_t *p, U128u v) { *(U128u *)p = v; }
+/* the same load with the non-temporal hint (the L2 keeps such lines shortest): the fast encoder's candidate bytes under K4_NT_CAND, an A/B build */
+typedef uint32_t k4_v4u __attribute__((ext_vector_type(4)));
+typedef k4_v4u __attribute__((aligned(1))) k4_v4u_u;
+__device__ __forceinline__ U128u ld128u_nt(const uint8_t *p)
+{
+#ifndef K4_HOST_EMU
+    const k4_v4u v = __builtin_nontemporal_load((const k4_v4u_u *)p);
+    U128u r; r.v[0] = v.x; r.v[1] = v.y; r.v[2] = v.z; r.v[3] = v.w;
+    return r;
+#else
+    return *(const U128u *)p;
+#endif
+}
 
 /* write-once / read-once data (the two-step encoder's records, the encoded bytes) with the non-temporal hint, so that they do not
  * push the source lines the candidate fetches come back for out of the L2 and the Infinity Cache (K4_NT_RECS / K4_NT_OUT: A/B builds) */

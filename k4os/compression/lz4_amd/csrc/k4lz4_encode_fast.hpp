@@ -46,6 +46,24 @@ template <> struct FastTable<1> {   /* byU16: 8192 x u16, hash4 >> 19 (LL.tools.
     __device__ __forceinline__ static uint32_t hash_of(uint32_t seq, uint32_t) { return (seq * 2654435761u) >> (32 - 13); }
     __device__ __forceinline__ uint32_t get(uint32_t h) const { return t[h]; }
     __device__ __forceinline__ void put(uint32_t h, uint32_t pos) const { t[h] = (uint16_t)pos; }
+    /* (an A/B build, K4_NT_GTAB: a table in memory read and written with the non-temporal hint, so that the seven such tables of a
+     * workgroup -- 3.5 MiB per XCD, every line of them touched every round or two -- do not hold the L2 against the candidates' lines) */
+    __device__ __forceinline__ uint32_t get_nt(uint32_t h) const
+    {
+#ifndef K4_HOST_EMU
+        return __builtin_nontemporal_load(t + h);
+#else
+        return t[h];
+#endif
+    }
+    __device__ __forceinline__ void put_nt(uint32_t h, uint32_t pos) const
+    {
+#ifndef K4_HOST_EMU
+        __builtin_nontemporal_store((uint16_t)pos, t + h);
+#else
+        t[h] = (uint16_t)pos;
+#endif
+    }
 };
 template <> struct FastTable<0> {  /* byU32: 4096 x u32, hash5 (LL.tools.cs:53-58, LL64.tools.cs:135-143) */
     uint32_t *t;

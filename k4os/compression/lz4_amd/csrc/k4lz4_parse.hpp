@@ -722,7 +722,12 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         const uint32_t p = c0 + (uint32_t)lane;
         const uint32_t w0 = pw[0].v[0], w1 = pw[0].v[1], w2 = pw[0].v[2], w3 = pw[0].v[3];
         const uint32_t hh = Table::hash_of(w0, w1);
+#if defined(K4_NT_GTAB)
+        uint32_t cd;
+        if constexpr (GT && TT == 1) cd = tab.get_nt(hh); else cd = tab.get(hh);
+#else
         uint32_t cd = tab.get(hh);
+#endif
         const uint32_t bit = hh >> SEEN_SHIFT;
         const bool flg = ((atomicOr(&seen[bit >> 5], 1u << (bit & 31u)) >> (bit & 31u)) & 1u) != 0u;
         uint32_t hE2 = 0xffffffffu;
@@ -731,9 +736,15 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
             if (hh == hE2) cd = c0 - 2u;
         }
         K4_PT(0);
+#ifdef K4_NT_CAND
+        const U128u cw = ld128u_nt(src + cd);
+        U128u cw2 = {{0u, 0u, 0u, 0u}};
+        if (MORE) cw2 = ld128u_nt(src + cd + 16u);
+#else
         const U128u cw = ld128u(src + cd);
         U128u cw2 = {{0u, 0u, 0u, 0u}};
         if (MORE) cw2 = ld128u(src + cd + 16u);
+#endif
         __builtin_amdgcn_wave_barrier();
         seen[hh >> (5u + SEEN_SHIFT)] = 0u;
         /* groups */
@@ -882,7 +893,11 @@ __device__ __forceinline__ uint32_t parse_block(const uint8_t *src, const uint32
         /* one writer per slot: of the visited lanes of a group the highest (the latest position is what a slot holds in the end); the
          * put of c0 - 2 (:394) came before all of them and stands only where none of them has its hash */
         if (hE2 != 0xffffffffu && (ballot(hh == hE2) & vm) == 0ull && lane == 0) tab.put(hE2, c0 - 2u);
+#if defined(K4_NT_GTAB)
+        if (((vm >> lane) & 1ull) && (G & vm & ~(below_me | me)) == 0ull) { if constexpr (GT && TT == 1) tab.put_nt(hh, p); else tab.put(hh, p); }
+#else
         if (((vm >> lane) & 1ull) && (G & vm & ~(below_me | me)) == 0ull) tab.put(hh, p);
+#endif
         if (GT) wave_sync(); else lds_sync();       /* (never a wait for the records' stores or the next round's loads) */
         K4_PT(5);
         return true;
