@@ -9,7 +9,8 @@ struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
 struct __attribute__((packed, aligned(1))) U64u { uint64_t v; };
 struct __attribute__((packed, aligned(1))) U128u { uint32_t v[4]; };
 
-template <int BYTES, int PATTERN>       // PATTERN 0: consecutive bytes (lane l at base + l), 1: scattered aligned to BYTES, 2: scattered at any byte
+template <int BYTES, int PATTERN>       // PATTERN 0: consecutive bytes (lane l at base + l), 1: scattered aligned to BYTES, 2: scattered at any byte,
+                                        // 3: as 2 with 16 of the 64 lanes active, 4: as 2 with the lanes' addresses within 256 bytes of each other
 __global__ __launch_bounds__(256) void k(const uint8_t *src, uint32_t window, uint32_t iters, uint32_t *out)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -26,8 +27,10 @@ __global__ __launch_bounds__(256) void k(const uint8_t *src, uint32_t window, ui
             else off = (state >> 8) % (window - 64u);
             if (PATTERN == 0) { uint32_t s2 = __builtin_amdgcn_readfirstlane(state); off = ((s2 >> 8) % (window - 1024u)) + lane; }
             if (PATTERN == 1) off &= ~(uint32_t)(BYTES - 1);
+            if (PATTERN == 4) { uint32_t s2 = __builtin_amdgcn_readfirstlane(state); off = ((s2 >> 8) % (window - 1024u)) + ((state >> 12) & 255u); }
             a[u] = wg_base + off;
         }
+        if (PATTERN != 3 || lane < 16u)
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             if (BYTES == 4) acc ^= ((const U32u *)(src + a[u]))->v;
@@ -66,6 +69,8 @@ int main()
         run<4, 0>(d, o, window, "consecutive bytes", cus); run<8, 0>(d, o, window, "consecutive bytes", cus); run<16, 0>(d, o, window, "consecutive bytes", cus);
         run<4, 1>(d, o, window, "scattered, aligned", cus); run<8, 1>(d, o, window, "scattered, aligned", cus); run<16, 1>(d, o, window, "scattered, aligned", cus);
         run<4, 2>(d, o, window, "scattered, any byte", cus); run<8, 2>(d, o, window, "scattered, any byte", cus); run<16, 2>(d, o, window, "scattered, any byte", cus);
+        run<8, 3>(d, o, window, "scattered, 16 lanes active", cus); run<16, 3>(d, o, window, "scattered, 16 lanes active", cus);
+        run<8, 4>(d, o, window, "lanes within 256 bytes", cus); run<16, 4>(d, o, window, "lanes within 256 bytes", cus);
     }
     return 0;
 }
