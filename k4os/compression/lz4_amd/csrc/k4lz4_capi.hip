@@ -107,6 +107,7 @@ struct k4lz4_ctx {
     int cost_pct = 48;                    /* K4LZ4_COST_PCT: the LDS-table kernel's share of a batch's estimated cost (k4_order_kernel) */
     int dec_parts = 4, dec_parts_direct = 8;   /* K4LZ4_DEC_PARTS, K4LZ4_DEC_PARTS_DIRECT: parts of a big decode-like host-pointer call (2..MAX_PARTS); with a registered destination */
     int hop2_max_per_cu = 12;             /* K4LZ4_HOP2_MAX: pair decoders follow the token chain two links per hop in launches of up to this many blocks per CU */
+    bool hc_cand_lds = true;              /* K4LZ4_HC_CAND_MEM unsets it: blocks of at most 64 KiB get their candidate records by k4_hc_cand_kernel (from memory) */
     int hc_cand_dynlds = 0;               /* K4LZ4_HC_CAND_DYNLDS (a measurement switch): bytes of unused LDS per workgroup of k4_hc_cand_kernel, i.e. fewer of them per CU */
     int hc_segs = 0;                      /* K4LZ4_HC_SEGS = 1 / 2 / 4: waves per block of the level-3 parse (0: by the batch's size) */
     bool hc_chain_parts = true;           /* K4LZ4_HC_CHAIN_OLD unsets it: blocks of at most 64 KiB build their chains with sixteen waves per block (k4_hc_chain_part_kernel) */
@@ -332,7 +333,11 @@ int launch_hc(k4lz4_ctx *ctx, bool pickle, const uint8_t *src, const uint64_t *s
             hipLaunchKernelGGL(k4::k4_hc_chain_kernel, dim3((unsigned)((cnt + k4::HC_CHAIN_WAVES_PER_WG - 1) / k4::HC_CHAIN_WAVES_PER_WG)), dim3(64 * k4::HC_CHAIN_WAVES_PER_WG), 0, stream, h);
         }
         const bool optimal = level >= K4LZ4_L10_OPT;              /* clTable (LL64.high.cs:1124-1138): lz4opt strategy */
-        if (tail[1] >= 13 && !optimal) {
+        if (tail[1] >= 13 && tail[1] <= 65536 && !optimal && ctx->hc_cand_lds) {
+            /* no block over 64 KiB: the candidates' records out of LDS (k4_hc_walk_lds_kernel, k4_hc_cand_lds_kernel; round 6) */
+            hipLaunchKernelGGL(k4::k4_hc_walk_lds_kernel, dim3((unsigned)cnt), dim3(64 * k4::HC_LDS_WAVES), 0, stream, h);
+            hipLaunchKernelGGL(k4::k4_hc_cand_lds_kernel, dim3((unsigned)cnt), dim3(64 * k4::HC_CAND_LDS_WAVES), 0, stream, h);
+        } else if (tail[1] >= 13 && !optimal) {
             const unsigned gy = (unsigned)((tail[1] + k4::HC_CAND_POS_PER_WG - 1) / k4::HC_CAND_POS_PER_WG);
             const unsigned groups = (unsigned)((cnt + 7) / 8);                     /* eight blocks, one per XCD (k4_hc_cand_kernel) */
             const unsigned per = std::max(1u, (1u << 30) / (8u * groups));         /* chunks per launch: the grid stays below 2^31 workgroups */
@@ -1462,6 +1467,7 @@ int k4lz4_ctx_create(k4lz4_ctx **out, int device)
     if (const char *e = getenv("K4LZ4_DEC_PARTS_DIRECT")) ctx->dec_parts_direct = std::max(2, std::min(MAX_PARTS, atoi(e)));
     if (const char *e = getenv("K4LZ4_HOP2_MAX")) ctx->hop2_max_per_cu = std::max(0, atoi(e));
     ctx->hc_chain_parts = getenv("K4LZ4_HC_CHAIN_OLD") == nullptr;
+    ctx->hc_cand_lds = getenv("K4LZ4_HC_CAND_MEM") == nullptr;
     if (const char *e = getenv("K4LZ4_HC_CAND_DYNLDS")) ctx->hc_cand_dynlds = std::max(0, std::min(65536, atoi(e)));
     if (const char *e = getenv("K4LZ4_HC_SEGS")) { const int v = atoi(e); ctx->hc_segs = v >= 4 ? 4 : (v >= 2 ? 2 : (v == 1 ? 1 : 0)); }
     if (const char *e = getenv("K4LZ4_HC_MEM_PCT")) ctx->hc_mem_pct = std::max(0, std::min(100, atoi(e)));

@@ -299,10 +299,143 @@ constexpr int HC_CAND_POS_PER_WG = 1024;
 
 __device__ __forceinline__ uint32_t hc_rec_dist(const uint4 &r, int k) { return k == 0 ? r.x & 0xffffu : k == 1 ? r.x >> 16 : k == 2 ? r.y & 0xffffu : r.y >> 16; }
 
+/* Where k4_hc_cand_*'s bytes come from: the block in memory, or (blocks of at most 64 KiB, round 6) a copy of it in LDS -- a load at a
+ * byte address of its own per lane costs a CU 90-180 cycles from the caches (scripts/ubench/gather_rate.hip), the same bytes as
+ * aligned dwords out of LDS and a funnel shift a fraction of that. */
+struct HcSrcMem {
+    const uint8_t *s;
+    __device__ __forceinline__ uint32_t byte(uint32_t off) const { return s[off]; }
+    __device__ __forceinline__ uint32_t ld32(uint32_t off) const { return ld32u(s + off); }
+    __device__ __forceinline__ uint64_t ld64(uint32_t off) const { return ld64u(s + off); }
+    __device__ __forceinline__ U128u ld128(uint32_t off) const { return ld128u(s + off); }
+};
+struct HcSrcLds {
+    const uint32_t *l;           /* LDS: byte i of the block is byte i of this array; readable up to the next multiple of 4 behind offset + 16 */
+    __device__ __forceinline__ static uint32_t fun(uint32_t lo, uint32_t hi, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }
+    __device__ __forceinline__ uint32_t byte(uint32_t off) const { return (l[off >> 2] >> (8u * (off & 3u))) & 0xffu; }
+    __device__ __forceinline__ uint32_t ld32(uint32_t off) const { const uint32_t q = off >> 2, sh = 8u * (off & 3u); return fun(l[q], l[q + 1u], sh); }
+    __device__ __forceinline__ uint64_t ld64(uint32_t off) const
+    {
+        const uint32_t q = off >> 2, sh = 8u * (off & 3u);
+        const uint32_t a0 = l[q], a1 = l[q + 1u], a2 = l[q + 2u];
+        return ((uint64_t)fun(a1, a2, sh) << 32) | fun(a0, a1, sh);
+    }
+    __device__ __forceinline__ U128u ld128(uint32_t off) const
+    {
+        const uint32_t q = off >> 2, sh = 8u * (off & 3u);
+        const uint32_t a0 = l[q], a1 = l[q + 1u], a2 = l[q + 2u], a3 = l[q + 3u], a4 = l[q + 4u];
+        U128u r;
+        r.v[0] = fun(a0, a1, sh); r.v[1] = fun(a1, a2, sh); r.v[2] = fun(a2, a3, sh); r.v[3] = fun(a3, a4, sh);
+        return r;
+    }
+};
+
 /* equal bytes from a / b on, at most n (bytewise: block edges only) */
-__device__ __forceinline__ uint32_t hc_count_fwd_bytes(const uint8_t *a, const uint8_t *b, uint32_t n) { uint32_t i = 0; while (i < n && a[i] == b[i]) i++; return i; }
+template <typename SRC> __device__ __forceinline__ uint32_t hc_count_fwd_bytes(const SRC &s, uint32_t a, uint32_t b, uint32_t n) { uint32_t i = 0; while (i < n && s.byte(a + i) == s.byte(b + i)) i++; return i; }
 /* equal bytes before a / b, at most n */
-__device__ __forceinline__ uint32_t hc_count_back_bytes(const uint8_t *a, const uint8_t *b, uint32_t n) { uint32_t i = 0; while (i < n && a[-1 - (int)i] == b[-1 - (int)i]) i++; return i; }
+template <typename SRC> __device__ __forceinline__ uint32_t hc_count_back_bytes(const SRC &s, uint32_t a, uint32_t b, uint32_t n) { uint32_t i = 0; while (i < n && s.byte(a - 1u - i) == s.byte(b - 1u - i)) i++; return i; }
+
+/* One position's record from its four chain candidates c[] (HC_NONE: the chain has ended): the distances, per candidate the forward match
+ * length a search at p may use (LL64.high.cs:87-88 lowest, :120 the 4-byte test, :126 LZ4_count up to matchlimit, capped at HC_FLEN_CAP)
+ * and the equal bytes before the two positions (LZ4HC_countBack without its limits, capped at HC_BLEN_CAP).
+ * A candidate is ONE 16-byte load: the sixteen bytes from four before it -- four bytes backward, the four of the :120 test, eight
+ * forward -- where rounds 1-5 made three (4 + 8 + 8 bytes).  More only for the candidates whose four bytes backward or eight forward are
+ * all equal.  The positions at a block's edges (the first four, the last eleven) count bytewise. */
+template <typename SRC>
+__device__ __forceinline__ uint4 hc_cand_record(const SRC &src, const uint32_t U, const uint32_t p, const uint32_t (&c)[4])
+{
+    const uint32_t matchlimit = U - LASTLITERALS;
+    const uint32_t maxn = p + MINMATCH < matchlimit ? matchlimit - (p + MINMATCH) : 0u;
+    const uint32_t lim = maxn < HC_FLEN_CAP - MINMATCH ? maxn : HC_FLEN_CAP - MINMATCH;
+    const bool inner = p >= 4u && p + 12u <= U;          /* the sixteen bytes around p, and around every candidate from 4 on, are the block's */
+    uint32_t o0 = 0, o1, o2 = 0, o3 = 0;                 /* bytes p-4 .. p-1, p .. p+3, p+4 .. p+11 */
+    if (inner) { const U128u v = src.ld128(p - 4u); o0 = v.v[0]; o1 = v.v[1]; o2 = v.v[2]; o3 = v.v[3]; }
+    else o1 = src.ld32(p);
+    uint32_t d[4], fl[4], bl[4], blim[4];
+    bool chain_ok = true, fo[4], bo[4];                  /* fo / bo: the forward / backward count of candidate k is not finished yet */
+    U128u cv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        chain_ok = chain_ok && c[k] != HC_NONE && p - c[k] <= (uint32_t)DISTANCE_MAX;
+        d[k] = chain_ok ? p - c[k] : 0u;
+        cv[k].v[0] = 0u; cv[k].v[1] = 0u; cv[k].v[2] = 0u; cv[k].v[3] = 0u;
+        if (chain_ok && inner && c[k] >= 4u) cv[k] = src.ld128(c[k] - 4u);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t f = 0, bk = 0;
+        const uint32_t cc = c[k];
+        fo[k] = false; bo[k] = false;
+        blim[k] = cc < HC_BLEN_CAP ? cc : HC_BLEN_CAP;                         /* cc < p */
+        if (d[k] != 0u) {
+            if (inner && cc >= 4u) {
+                if (cv[k].v[1] == o1) {
+                    if (lim >= 8u) {
+                        const uint64_t x = (((uint64_t)(o3 ^ cv[k].v[3])) << 32) | (uint64_t)(o2 ^ cv[k].v[2]);
+                        if (x) f = MINMATCH + ((uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3);
+                        else { f = MINMATCH + 8u; fo[k] = lim > 8u; }
+                    } else {
+                        f = MINMATCH + hc_count_fwd_bytes(src, p + MINMATCH, cc + MINMATCH, lim);
+                    }
+                    const uint32_t xb = o0 ^ cv[k].v[0];                       /* blim >= 4 */
+                    if (xb) bk = (uint32_t)__clz((int)xb) >> 3;
+                    else { bk = 4u; bo[k] = blim[k] > 4u; }
+                }
+            } else if (src.ld32(cc) == o1) {
+                f = MINMATCH + hc_count_fwd_bytes(src, p + MINMATCH, cc + MINMATCH, lim);
+                bk = hc_count_back_bytes(src, p, cc, blim[k]);
+            }
+        }
+        fl[k] = f;
+        bl[k] = bk;
+    }
+    /* The counts that are not finished go on TOGETHER, eight bytes per step and candidate, forward and backward in one step: all
+     * of a step's loads are issued before the first is looked at, so a position waits for memory once per step -- at most four
+     * times (forward 8 / 16 / 24 bytes in, backward 4 / 12 / 20 / 28) -- where one candidate after the other, forward and then
+     * backward, waited up to two dozen times.  What is left below eight bytes is one more 8-byte compare that overlaps the bytes
+     * already counted (shifted out), not a byte loop. */
+    for (uint32_t t = 0; t < 4u; t++) {
+        if (!(fo[0] || fo[1] || fo[2] || fo[3] || bo[0] || bo[1] || bo[2] || bo[3])) break;      /* (per lane: the wave goes on while a lane has something open) */
+        const uint32_t i = 8u + 8u * t, bb = 4u + 8u * t;
+        const uint32_t rf = lim > i ? lim - i : 0u;                           /* (> 0 for a candidate that is open) */
+        const uint32_t fa = rf >= 8u ? i : lim - 8u;
+        uint64_t yf[4], yb[4];
+        uint32_t rb[4];
+        const uint64_t own_f = (fo[0] || fo[1] || fo[2] || fo[3]) ? src.ld64(p + MINMATCH + fa) : 0ull;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            yf[k] = fo[k] ? own_f ^ src.ld64(c[k] + MINMATCH + fa) : 0ull;
+            rb[k] = blim[k] - bb;
+            const uint32_t ba = rb[k] >= 8u ? bb + 8u : blim[k];
+            yb[k] = bo[k] ? src.ld64(p - ba) ^ src.ld64(c[k] - ba) : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (fo[k]) {
+                if (rf >= 8u) {
+                    if (yf[k]) { fl[k] += (uint32_t)(__ffsll((unsigned long long)yf[k]) - 1) >> 3; fo[k] = false; }
+                    else { fl[k] += 8u; if (rf == 8u) fo[k] = false; }
+                } else {
+                    const uint64_t y = yf[k] >> (8u * (8u - rf));
+                    fl[k] += y ? (uint32_t)(__ffsll((unsigned long long)y) - 1) >> 3 : rf;
+                    fo[k] = false;
+                }
+            }
+            if (bo[k]) {
+                if (rb[k] >= 8u) {
+                    if (yb[k]) { bl[k] += (uint32_t)__clzll((long long)yb[k]) >> 3; bo[k] = false; }
+                    else { bl[k] += 8u; if (rb[k] == 8u) bo[k] = false; }
+                } else {
+                    const uint64_t y = yb[k] << (8u * (8u - rb[k]));
+                    bl[k] += y ? (uint32_t)__clzll((long long)y) >> 3 : rb[k];
+                    bo[k] = false;
+                }
+            }
+        }
+    }
+    return make_uint4(d[0] | (d[1] << 16), d[2] | (d[3] << 16), fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24),
+                      bl[0] | (bl[1] << 8) | (bl[2] << 16) | (bl[3] << 24));
+}
 
 #ifndef K4_HC_CAND_ATTR
 #define K4_HC_CAND_ATTR
@@ -325,19 +458,11 @@ __global__ __launch_bounds__(256) K4_HC_CAND_ATTR void k4_hc_cand_kernel(HcArgs 
     const uint32_t npos = U - 3u;
     const uint32_t first = a.posBase + (rem >> 3) * (uint32_t)HC_CAND_POS_PER_WG;
     if (first >= npos) return;
-    const uint8_t *src = a.src + a.srcOff[b];
+    const HcSrcMem src{a.src + a.srcOff[b]};
     const uint32_t *prev = (const uint32_t *)(a.work + a.workOff[b]);
     uint4 *rec = (uint4 *)(prev + ((U + 3u) & ~3u));
-    /* Per position: the first four chain candidates (a chain step of 65535 or more ends the walk: LL.high.cs:114 caps the delta, and such
-     * a candidate is below lowestMatchIndex), per candidate the forward match length a search at p may use (:87-88 lowest, :120 the
-     * 4-byte test, :126 LZ4_count up to matchlimit, capped at HC_FLEN_CAP) and the equal bytes before the two positions (LZ4HC_countBack
-     * without its limits, capped at HC_BLEN_CAP).
-     * What the kernel costs is the number of loads at addresses of their own per lane (experiments/hc_cand_lds: about one lane per cycle
-     * and CU, whatever a lane reads), so a candidate is ONE such load: the sixteen bytes from four before it -- four bytes backward, the
-     * four of the :120 test, eight forward -- where rounds 1-5 made three (4 + 8 + 8 bytes).  More only for the candidates whose four
-     * bytes backward or eight forward are all equal.  The positions at a block's edges (the first four, the last eleven) count
-     * bytewise. */
-    const uint32_t matchlimit = U - LASTLITERALS;
+    /* the first four chain candidates (a chain step of 65535 or more ends the walk: LL.high.cs:114 caps the delta, and such a candidate is
+     * below lowestMatchIndex) */
     for (int j = 0; j < HC_CAND_POS_PER_WG / 256; j++) {
         const uint32_t p = first + threadIdx.x + 256u * (uint32_t)j;
         if (p >= npos) continue;
@@ -348,96 +473,89 @@ __global__ __launch_bounds__(256) K4_HC_CAND_ATTR void k4_hc_cand_kernel(HcArgs 
             const uint32_t q = c[k - 1] != HC_NONE ? prev[c[k - 1]] : HC_NONE;
             c[k] = (q != HC_NONE && c[k - 1] - q < (uint32_t)DISTANCE_MAX) ? q : HC_NONE;
         }
-        const uint32_t maxn = p + MINMATCH < matchlimit ? matchlimit - (p + MINMATCH) : 0u;
-        const uint32_t lim = maxn < HC_FLEN_CAP - MINMATCH ? maxn : HC_FLEN_CAP - MINMATCH;
-        const bool inner = p >= 4u && p + 12u <= U;          /* the sixteen bytes around p, and around every candidate from 4 on, are the block's */
-        uint32_t o0 = 0, o1, o2 = 0, o3 = 0;                 /* bytes p-4 .. p-1, p .. p+3, p+4 .. p+11 */
-        if (inner) { const U128u v = ld128u(src + p - 4u); o0 = v.v[0]; o1 = v.v[1]; o2 = v.v[2]; o3 = v.v[3]; }
-        else o1 = ld32u(src + p);
-        uint32_t d[4], fl[4], bl[4], blim[4];
-        bool chain_ok = true, fo[4], bo[4];                  /* fo / bo: the forward / backward count of candidate k is not finished yet */
-        U128u cv[4];
+        rec[p] = hc_cand_record(src, U, p, c);
+    }
+}
+
+/* Blocks of at most 64 KiB (round 6): the same records out of LDS, in two kernels with nothing but whole lines between them and memory.
+ *   k4_hc_walk_lds_kernel   one workgroup of 16 waves per block, prev[] as 16-bit positions in 128 KiB of LDS: the three dependent
+ *                           look-ups of a position's chain are LDS reads; the four distances go to the record's first two words.
+ *   k4_hc_cand_lds_kernel   one workgroup of 16 waves per block, the block's bytes in 64 KiB of LDS (two blocks per CU): reads the
+ *                           distances back, the candidates' bytes are aligned dwords out of LDS and a funnel shift (HcSrcLds). */
+constexpr int HC_LDS_WAVES = 16;
+__global__ __launch_bounds__(64 * HC_LDS_WAVES) void k4_hc_walk_lds_kernel(HcArgs a)
+{
+    __shared__ uint16_t pv[65536];
+    const long long b = (long long)blockIdx.x;
+    const int len = a.srcLen[b];
+    if (len < MFLIMIT + 1 || len > 65536 || !hc_scratch_ok(a)) return;
+    const uint32_t U = (uint32_t)len, npos = U - 3u;
+    const uint32_t *prev = (const uint32_t *)(a.work + a.workOff[b]);
+    uint4 *rec = (uint4 *)(prev + ((U + 3u) & ~3u));
+    constexpr uint32_t T = 64u * HC_LDS_WAVES;
+    /* (eight loads in flight per thread: one at a time, a block's 256 KiB of prev[] would be 64 trips to memory one after the other) */
+    for (uint32_t base = threadIdx.x; base < npos; base += 8u * T) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) v[u] = base + u * T < npos ? prev[base + u * T] : HC_NONE;
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) if (base + u * T < npos) pv[base + u * T] = (uint16_t)v[u];      /* (HC_NONE: 0xffff, which is no position of such a block) */
+    }
+    __syncthreads();
+    /* four positions per thread together: their three dependent look-ups each are LDS round trips that overlap */
+    for (uint32_t base = threadIdx.x; base < npos; base += 4u * T) {
+        uint32_t c[4], d01[4], d23[4];
+        bool ok[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) { const uint32_t p = base + u * T; c[u] = p < npos ? pv[p] : 0xffffu; ok[u] = true; d01[u] = 0u; d23[u] = 0u; }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            chain_ok = chain_ok && c[k] != HC_NONE && p - c[k] <= (uint32_t)DISTANCE_MAX;
-            d[k] = chain_ok ? p - c[k] : 0u;
-            cv[k].v[0] = 0u; cv[k].v[1] = 0u; cv[k].v[2] = 0u; cv[k].v[3] = 0u;
-            if (chain_ok && inner && c[k] >= 4u) cv[k] = ld128u(src + c[k] - 4u);
-        }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t f = 0, bk = 0;
-            const uint32_t cc = c[k];
-            fo[k] = false; bo[k] = false;
-            blim[k] = cc < HC_BLEN_CAP ? cc : HC_BLEN_CAP;                         /* cc < p */
-            if (d[k] != 0u) {
-                if (inner && cc >= 4u) {
-                    if (cv[k].v[1] == o1) {
-                        if (lim >= 8u) {
-                            const uint64_t x = (((uint64_t)(o3 ^ cv[k].v[3])) << 32) | (uint64_t)(o2 ^ cv[k].v[2]);
-                            if (x) f = MINMATCH + ((uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3);
-                            else { f = MINMATCH + 8u; fo[k] = lim > 8u; }
-                        } else {
-                            f = MINMATCH + hc_count_fwd_bytes(src + p + MINMATCH, src + cc + MINMATCH, lim);
-                        }
-                        const uint32_t xb = o0 ^ cv[k].v[0];                       /* blim >= 4 */
-                        if (xb) bk = (uint32_t)__clz((int)xb) >> 3;
-                        else { bk = 4u; bo[k] = blim[k] > 4u; }
-                    }
-                } else if (ld32u(src + cc) == o1) {
-                    f = MINMATCH + hc_count_fwd_bytes(src + p + MINMATCH, src + cc + MINMATCH, lim);
-                    bk = hc_count_back_bytes(src + p, src + cc, blim[k]);
-                }
-            }
-            fl[k] = f;
-            bl[k] = bk;
-        }
-        /* The counts that are not finished go on TOGETHER, eight bytes per step and candidate, forward and backward in one step: all
-         * of a step's loads are issued before the first is looked at, so a position waits for memory once per step -- at most four
-         * times (forward 8 / 16 / 24 bytes in, backward 4 / 12 / 20 / 28) -- where one candidate after the other, forward and then
-         * backward, waited up to two dozen times.  What is left below eight bytes is one more 8-byte compare that overlaps the bytes
-         * already counted (shifted out), not a byte loop. */
-        for (uint32_t t = 0; t < 4u; t++) {
-            if (!(fo[0] || fo[1] || fo[2] || fo[3] || bo[0] || bo[1] || bo[2] || bo[3])) break;      /* (per lane: the wave goes on while a lane has something open) */
-            const uint32_t i = 8u + 8u * t, bb = 4u + 8u * t;
-            const uint32_t rf = lim > i ? lim - i : 0u;                           /* (> 0 for a candidate that is open) */
-            const uint32_t fa = rf >= 8u ? i : lim - 8u;
-            uint64_t yf[4], yb[4];
-            uint32_t rb[4];
-            const uint64_t own_f = (fo[0] || fo[1] || fo[2] || fo[3]) ? ld64u(src + p + MINMATCH + fa) : 0ull;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                yf[k] = fo[k] ? own_f ^ ld64u(src + c[k] + MINMATCH + fa) : 0ull;
-                rb[k] = blim[k] - bb;
-                const uint32_t ba = rb[k] >= 8u ? bb + 8u : blim[k];
-                yb[k] = bo[k] ? ld64u(src + p - ba) ^ ld64u(src + c[k] - ba) : 0ull;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (fo[k]) {
-                    if (rf >= 8u) {
-                        if (yf[k]) { fl[k] += (uint32_t)(__ffsll((unsigned long long)yf[k]) - 1) >> 3; fo[k] = false; }
-                        else { fl[k] += 8u; if (rf == 8u) fo[k] = false; }
-                    } else {
-                        const uint64_t y = yf[k] >> (8u * (8u - rf));
-                        fl[k] += y ? (uint32_t)(__ffsll((unsigned long long)y) - 1) >> 3 : rf;
-                        fo[k] = false;
-                    }
-                }
-                if (bo[k]) {
-                    if (rb[k] >= 8u) {
-                        if (yb[k]) { bl[k] += (uint32_t)__clzll((long long)yb[k]) >> 3; bo[k] = false; }
-                        else { bl[k] += 8u; if (rb[k] == 8u) bo[k] = false; }
-                    } else {
-                        const uint64_t y = yb[k] << (8u * (8u - rb[k]));
-                        bl[k] += y ? (uint32_t)__clzll((long long)y) >> 3 : rb[k];
-                        bo[k] = false;
-                    }
-                }
+            for (uint32_t u = 0; u < 4u; u++) {
+                const uint32_t p = base + u * T;
+                ok[u] = ok[u] && c[u] != 0xffffu;                /* (steps and distances of 65535 and more do not exist in a block of 64 KiB) */
+                const uint32_t d = ok[u] ? p - c[u] : 0u;
+                if (k < 2) d01[u] |= d << (16 * k); else d23[u] |= d << (16 * (k - 2));
+                if (k < 3) c[u] = ok[u] ? pv[c[u]] : 0xffffu;
             }
         }
-        rec[p] = make_uint4(d[0] | (d[1] << 16), d[2] | (d[3] << 16), fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24),
-                            bl[0] | (bl[1] << 8) | (bl[2] << 16) | (bl[3] << 24));
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) { const uint32_t p = base + u * T; if (p < npos) rec[p] = make_uint4(d01[u], d23[u], 0u, 0u); }
+    }
+}
+
+#ifndef K4_HC_CAND_LDS_ATTR
+#define K4_HC_CAND_LDS_ATTR
+#endif
+#ifndef K4_HC_CAND_LDS_WAVES
+#define K4_HC_CAND_LDS_WAVES 12
+#endif
+constexpr int HC_CAND_LDS_WAVES = K4_HC_CAND_LDS_WAVES;      /* (two workgroups per CU by their LDS: with ~80 VGPRs twelve waves each are what fits) */
+__global__ __launch_bounds__(64 * HC_CAND_LDS_WAVES) K4_HC_CAND_LDS_ATTR void k4_hc_cand_lds_kernel(HcArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t ls[65536 / 4 + 8];
+    const long long b = (long long)blockIdx.x;
+    const int len = a.srcLen[b];
+    if (len < MFLIMIT + 1 || len > 65536 || !hc_scratch_ok(a)) return;
+    const uint32_t U = (uint32_t)len, npos = U - 3u;
+    const uint8_t *g = a.src + a.srcOff[b];
+    const uint32_t *prev = (const uint32_t *)(a.work + a.workOff[b]);
+    uint4 *rec = (uint4 *)(prev + ((U + 3u) & ~3u));
+    for (uint32_t v = threadIdx.x; 16u * v < U; v += 64u * HC_CAND_LDS_WAVES) {      /* the block, sixteen bytes per thread; its last bytes one by one */
+        if (16u * v + 16u <= U) { const U128u w = ld128u(g + 16u * v); ls[4u * v] = w.v[0]; ls[4u * v + 1u] = w.v[1]; ls[4u * v + 2u] = w.v[2]; ls[4u * v + 3u] = w.v[3]; }
+        else for (uint32_t q = 0; q < 4u; q++) { uint32_t w = 0; for (uint32_t r = 0; r < 4u; r++) if (16u * v + 4u * q + r < U) w |= (uint32_t)g[16u * v + 4u * q + r] << (8u * r); ls[4u * v + q] = w; }
+    }
+    if (threadIdx.x < 8u) ls[((U + 15u) & ~15u) / 4u + threadIdx.x] = 0u;       /* (read, never used: the dwords behind the last byte) */
+    __syncthreads();
+    const HcSrcLds src{ls};
+    uint2 dn = threadIdx.x < npos ? ((const uint2 *)(rec + threadIdx.x))[0] : make_uint2(0u, 0u);      /* (asked for a position ahead) */
+    for (uint32_t p = threadIdx.x; p < npos; p += 64u * HC_CAND_LDS_WAVES) {
+        const uint2 dd = dn;
+        if (p + 64u * HC_CAND_LDS_WAVES < npos) dn = ((const uint2 *)(rec + p + 64u * HC_CAND_LDS_WAVES))[0];
+        uint32_t c[4];
+        c[0] = (dd.x & 0xffffu) ? p - (dd.x & 0xffffu) : HC_NONE; c[1] = (dd.x >> 16) ? p - (dd.x >> 16) : HC_NONE;
+        c[2] = (dd.y & 0xffffu) ? p - (dd.y & 0xffffu) : HC_NONE; c[3] = (dd.y >> 16) ? p - (dd.y >> 16) : HC_NONE;
+        rec[p] = hc_cand_record(src, U, p, c);
     }
 }
 

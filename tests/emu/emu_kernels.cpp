@@ -220,7 +220,11 @@ int k4emu_encode_hc_batch(const uint8_t *src, const uint64_t *srcOff, const int3
     if (off[(size_t)n + 1] <= 65536 && !(flags & (1 << 29))) k4emu::launch_fn(dim3((unsigned)n), dim3(64 * k4::HC_CHAIN_PARTS), [=] { k4::k4_hc_chain_part_kernel(a); }, threads);
     else if (off[(size_t)n + 1] <= 65536) k4emu::launch_fn(dim3((unsigned)((n + k4::HC_CHAIN_LDS_WAVES_PER_WG - 1) / k4::HC_CHAIN_LDS_WAVES_PER_WG)), dim3(64 * k4::HC_CHAIN_LDS_WAVES_PER_WG), [=] { k4::k4_hc_chain_lds_kernel(a); }, threads);   /* as the launcher chooses */
     else k4emu::launch_fn(dim3((unsigned)((n + k4::HC_CHAIN_WAVES_PER_WG - 1) / k4::HC_CHAIN_WAVES_PER_WG)), dim3(64 * k4::HC_CHAIN_WAVES_PER_WG), [=] { k4::k4_hc_chain_kernel(a); }, threads);
-    if (off[(size_t)n + 1] >= 13 && level < 10) {
+    /* flags bit 26 (the emulator's own): the candidate records by k4_hc_cand_kernel (from memory) also where every block is at most 64 KiB */
+    if (off[(size_t)n + 1] >= 13 && off[(size_t)n + 1] <= 65536 && level < 10 && !(flags & (1 << 26))) {
+        k4emu::launch_fn(dim3((unsigned)n), dim3(64 * k4::HC_LDS_WAVES), [=] { k4::k4_hc_walk_lds_kernel(a); }, threads);
+        k4emu::launch_fn(dim3((unsigned)n), dim3(64 * k4::HC_CAND_LDS_WAVES), [=] { k4::k4_hc_cand_lds_kernel(a); }, threads);
+    } else if (off[(size_t)n + 1] >= 13 && level < 10) {
         const unsigned gy = (unsigned)((off[(size_t)n + 1] + k4::HC_CAND_POS_PER_WG - 1) / k4::HC_CAND_POS_PER_WG);
         a.candChunks = gy;
         k4emu::launch_fn(dim3((unsigned)((n + 7) / 8) * 8u * gy), dim3(256), [=] { k4::k4_hc_cand_kernel(a); }, threads);
@@ -230,7 +234,7 @@ int k4emu_encode_hc_batch(const uint8_t *src, const uint64_t *srcOff, const int3
     /* flags bits 27-28 (the emulator's own, with bit 30): 1 / 2 -- two / four waves per block (HcSegs) */
     const int nseg = 1 << ((flags >> 27) & 3);
     if ((flags & (1 << 30)) && level <= 3 && off[(size_t)n + 1] <= 65536) { recs.resize((size_t)n * (nseg == 4 ? k4::hc_seg_rec_off(4, 4) : nseg == 2 ? k4::hc_seg_rec_off(2, 2) : k4::PARSE_REC_STRIDE)); a.recs = recs.data(); }
-    a.flags = flags & ~((1 << 30) | (1 << 29) | (3 << 27));
+    a.flags = flags & ~((1 << 30) | (1 << 29) | (3 << 27) | (1 << 26));
     if (level >= 10) k4emu::launch_fn(dim3((unsigned)n), dim3(64), [=] { k4::k4_hc_parse_opt_kernel(a); }, threads);
     else if (a.recs && nseg == 4) k4emu::launch_fn(dim3((unsigned)((n + 1) / 2)), dim3(64 * k4::HC_SEG_WAVES_PER_WG), [=] { k4::k4_hc_parse_seg4_kernel(a); }, threads);
     else if (a.recs && nseg == 2) k4emu::launch_fn(dim3((unsigned)((n + 3) / 4)), dim3(64 * k4::HC_SEG_WAVES_PER_WG), [=] { k4::k4_hc_parse_seg2_kernel(a); }, threads);

@@ -546,7 +546,8 @@ def test_encode_hc_level3_from_sequence_records(emu, oracle, nseg_log2):
             cases.append((b, cap))
     src, soff, slen = pack([b for b, _ in cases])
     dst, doff, dcap = arena([c for _, c in cases])
-    out = emu.encode_hc_batch(src, soff, slen, dst, doff, dcap, level=3, flags=FLAG_RAW | (1 << 30) | (nseg_log2 << 27))
+    # (nseg_log2 0 also runs the candidate records from memory -- emulator flag bit 26 -- and the chains by one wave per block -- bit 29)
+    out = emu.encode_hc_batch(src, soff, slen, dst, doff, dcap, level=3, flags=FLAG_RAW | (1 << 30) | (nseg_log2 << 27) | ((1 << 26) | (1 << 29) if nseg_log2 == 0 else 0))
     for i, (b, cap) in enumerate(cases):
         r, w = oracle.compress_hc(b, 3, cap=cap)
         assert out[i] == r, (i, b.size, cap, out[i], r)

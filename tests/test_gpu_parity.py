@@ -603,7 +603,7 @@ def test_fast_encoder_paths_give_identical_bytes(oracle):
 
 def test_hc_level3_paths_give_identical_bytes(oracle):
     """round 6: how a level-3 batch of blocks up to 64 KiB is parsed is scheduling only -- one, two or four waves per block, each
-    from its own start and joined where their cursors meet (K4LZ4_HC_SEGS; by default four), the chains by eight waves per block or
+    from its own start and joined where their cursors meet (K4LZ4_HC_SEGS; by default four), the candidate records out of LDS or from memory (K4LZ4_HC_CAND_MEM), the chains by eight waves per block or
     by the LDS-table kernel of rounds 3-5 (K4LZ4_HC_CHAIN_OLD), sequence records or LZ4HC_encodeSequence in the loop
     (K4LZ4_NO_HC_RECORDS).  Every one of them: the oracle's bytes, ragged lengths and ragged output limits included."""
     import os
@@ -623,7 +623,8 @@ def test_hc_level3_paths_give_identical_bytes(oracle):
     src, soff, slen = pack_blocks(blocks)
     ref_dst, ref_off = make_arena(caps + 16, fill=0xCD)
     want = oracle.encode_batch(src, soff, slen, ref_dst, ref_off, caps, level=3, threads=8)
-    envs = [{}, {"K4LZ4_HC_SEGS": "1"}, {"K4LZ4_HC_SEGS": "2"}, {"K4LZ4_HC_SEGS": "4"}, {"K4LZ4_HC_CHAIN_OLD": "1"}, {"K4LZ4_NO_HC_RECORDS": "1"}]
+    envs = [{}, {"K4LZ4_HC_SEGS": "1"}, {"K4LZ4_HC_SEGS": "2"}, {"K4LZ4_HC_SEGS": "4"}, {"K4LZ4_HC_CHAIN_OLD": "1"}, {"K4LZ4_NO_HC_RECORDS": "1"},
+            {"K4LZ4_HC_CAND_MEM": "1"}]
     for env in envs:
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
