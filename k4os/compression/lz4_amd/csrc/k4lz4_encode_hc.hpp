@@ -548,10 +548,11 @@ __global__ __launch_bounds__(64 * HC_CAND_LDS_WAVES) K4_HC_CAND_LDS_ATTR void k4
     if (threadIdx.x < 8u) ls[((U + 15u) & ~15u) / 4u + threadIdx.x] = 0u;       /* (read, never used: the dwords behind the last byte) */
     __syncthreads();
     const HcSrcLds src{ls};
-    uint2 dn = threadIdx.x < npos ? ((const uint2 *)(rec + threadIdx.x))[0] : make_uint2(0u, 0u);      /* (asked for a position ahead) */
+    /* (the distances are read where they are used.  Asking for the next position's a step ahead -- `dn = rec[p + T]` at the top of the loop -- was
+     * built and gave wrong records on the GPU for workgroups of 12 and 16 waves, the same ones every run, and right ones for 8 waves, for a build
+     * limited to 64 VGPRs and under the emulator; a full s_waitcnt in front of its use changed nothing.  Not understood, not faster: gone.) */
     for (uint32_t p = threadIdx.x; p < npos; p += 64u * HC_CAND_LDS_WAVES) {
-        const uint2 dd = dn;
-        if (p + 64u * HC_CAND_LDS_WAVES < npos) dn = ((const uint2 *)(rec + p + 64u * HC_CAND_LDS_WAVES))[0];
+        const uint2 dd = ((const uint2 *)(rec + p))[0];
         uint32_t c[4];
         c[0] = (dd.x & 0xffffu) ? p - (dd.x & 0xffffu) : HC_NONE; c[1] = (dd.x >> 16) ? p - (dd.x >> 16) : HC_NONE;
         c[2] = (dd.y & 0xffffu) ? p - (dd.y & 0xffffu) : HC_NONE; c[3] = (dd.y >> 16) ? p - (dd.y >> 16) : HC_NONE;
