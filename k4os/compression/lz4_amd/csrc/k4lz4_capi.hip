@@ -1550,7 +1550,7 @@ const char *k4lz4_last_error(const k4lz4_ctx *ctx) { return ctx ? ctx->error.c_s
 int64_t k4lz4_recommended_min_batch(int kind, int32_t blockBytes, double hostGiBs)
 {
     if (kind < 0 || kind > 2 || blockBytes <= 0) return K4LZ4_E_ARG;
-    static const double floor_ms_64k[3] = {2.0, 0.55, 8.7};
+    static const double floor_ms_64k[3] = {2.0, 0.55, 2.9};      /* (HC level 3: 8.7 until round 6; profiles/r6_hc_small_batches.txt) */
     static const double box_host_GiBs[3] = {32.0, 35.0, 2.2};
     const double host = hostGiBs > 0.0 ? hostGiBs : box_host_GiBs[kind];
     double floor_ms = floor_ms_64k[kind] * (double)blockBytes / 65536.0;
