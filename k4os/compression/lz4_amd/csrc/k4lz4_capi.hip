@@ -235,7 +235,7 @@ int take_device_status(k4lz4_ctx *ctx)
     const bool nomem = (v & k4::DEV_STATUS_HC_SCRATCH) != 0, timeout = (v & k4::DEV_STATUS_PIPE_TIMEOUT) != 0;
     std::string msg;
     if (nomem) msg += "HC scratch reserved with k4lz4_ctx_reserve_hc was too small for the batch: its blocks were not encoded";
-    if (timeout) msg += std::string(nomem ? "; " : "") + "a decoder wave gave up waiting for its partner wave (scheduling time-out, not corrupt data): the affected blocks report failure";
+    if (timeout) msg += std::string(nomem ? "; " : "") + "a wave gave up waiting for its partner wave (a decoder pair, or the waves that parse one block at HC level 3: scheduling time-out, not corrupt data): the affected blocks report failure";
     return fail(ctx, nomem ? K4LZ4_E_NOMEM : K4LZ4_E_HIP, msg.c_str());
 }
 
