@@ -559,6 +559,16 @@ def test_encode_hc_level3_from_sequence_records(emu, oracle, nseg_log2):
     assert (dst[mask] == 0xCD).all()
 
 
+def test_encode_hc_level3_several_waves_per_block_stress():
+    """tests/tools/emu_stress_hc_segs.py, six cases (144 blocks): blocks of 8 192 .. 65 536 bytes stitched from random / repeated / periodic / copied /
+    corpus-class parts (matches and runs across the waves' starts, stretches without a match), two and four waves per block, ragged
+    output limits -- the oracle's bytes."""
+    import subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "emu_stress_hc_segs.py")
+    out = subprocess.run([sys.executable, tool, "6", "7"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.strip().startswith("ok 6 cases"), (out.stdout[-500:], out.stderr[-1500:])
+
+
 def test_encode_hc_limited_output(emu, oracle):
     blocks, caps, wants = [], [], []
     for name in ("dickens", "xml", "x-ray"):
