@@ -550,7 +550,8 @@ __global__ __launch_bounds__(64 * HC_CAND_LDS_WAVES) K4_HC_CAND_LDS_ATTR void k4
     const HcSrcLds src{ls};
     /* (the distances are read where they are used.  Asking for the next position's a step ahead -- `dn = rec[p + T]` at the top of the loop -- was
      * built and gave wrong records on the GPU for workgroups of 12 and 16 waves, the same ones every run, and right ones for 8 waves, for a build
-     * limited to 64 VGPRs and under the emulator; a full s_waitcnt in front of its use changed nothing.  Not understood, not faster: gone.) */
+     * limited to 64 VGPRs and under the emulator; a full s_waitcnt in front of its use changed nothing; with a trip count that is the same for every lane -- no lane leaves the loop before
+     * another -- the same read-ahead gives the right records.  Not faster either way: gone.) */
     for (uint32_t p = threadIdx.x; p < npos; p += 64u * HC_CAND_LDS_WAVES) {
         const uint2 dd = ((const uint2 *)(rec + p))[0];
         uint32_t c[4];
