@@ -1228,8 +1228,14 @@ constexpr int HC_SEG_CTL = 5;                        /* LDS words per wave: [0] 
 constexpr uint32_t HC_SEG_SPIN_MAX = 1u << 24;
 /* where wave j's records begin inside a block's slots, in records: wave 0 may have to hold the whole block's (PARSE_REC_STRIDE), wave j > 0
  * at most those of the block's last (nseg - j) / nseg */
-constexpr uint32_t hc_seg_rec_cap(int nseg, int j) { return j == 0 ? PARSE_REC_STRIDE : (PARSE_REC_STRIDE * (uint32_t)(nseg - j) + (uint32_t)nseg - 1u) / (uint32_t)nseg + 64u; }
-constexpr uint32_t hc_seg_rec_off(int nseg, int j) { return j == 0 ? 0u : hc_seg_rec_off(nseg, j - 1) + hc_seg_rec_cap(nseg, j - 1); }
+__host__ __device__ __forceinline__ constexpr uint32_t hc_seg_rec_cap(int nseg, int j) { return j == 0 ? PARSE_REC_STRIDE : (PARSE_REC_STRIDE * (uint32_t)(nseg - j) + (uint32_t)nseg - 1u) / (uint32_t)nseg + 64u; }
+/* (a loop, not a recursion: as a recursive function it was CALLED from the kernels -- s_swappc and a stack -- where its arguments were constants) */
+__host__ __device__ __forceinline__ constexpr uint32_t hc_seg_rec_off(int nseg, int j)
+{
+    uint32_t off = 0u;
+    for (int i = 0; i < j; i++) off += hc_seg_rec_cap(nseg, i);
+    return off;
+}
 struct HcSegs {
     uint32_t nseg, seg;       /* waves of this block, this wave's number */
     uint32_t *ctl;            /* LDS, HC_SEG_CTL words per wave of the block, zeroed */
